@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""Headline benchmark of the MI355X-native MVP op layer.
+
+A "step" = one pass of the completion-eval hot path over one synthetic batch:
+    calc_cd(pred, gt, calc_f1=True)  -> cd() + fscore + the cd_p/cd_t reductions
+    calc_emd(pred, gt, eps=0.004, iterations=3000)
+on pred, gt = (64, 16384, 3) uniform [0,1) clouds per GPU (BASELINE.json
+metric: "point-pairs/sec CD+EMD @2048->16384 pts, batch 64").  Inputs are
+resident in HBM before the timed region.  value = B*N*M*n_gpus / time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); the batch
+dimension is sharded (every rank evaluates its own 64 clouds: weak scaling);
+the only collective is the 5-float metric all-reduce of the eval loop.
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  roofline     -- for the dominant kernel (the persistent EMD auction kernel)
+  cpu_baseline -- the CPU oracle timed on a bounded sample of the same workload
+  extra        -- per-op times, FPS throughput, CD VALU figures.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--eps", type=float, default=0.004)
+    ap.add_argument("--iters", type=int, default=3000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="clouds in the CPU-baseline sample (0 = min(cores, 64))")
+    return ap.parse_args()
+
+
+def eval_step(cd_mod, emd_mod, fscore, pred, gt, eps, iters, ev=None):
+    """completion/model_utils.py:67-85 (calc_cd with calc_f1, calc_emd)."""
+    if ev:
+        ev[0].record()
+    dist1, dist2, _, _ = cd_mod(gt, pred)
+    cd_p = (torch.sqrt(dist1).mean(1) + torch.sqrt(dist2).mean(1)) / 2
+    cd_t = dist1.mean(1) + dist2.mean(1)
+    f1, _, _ = fscore(dist1, dist2)
+    if ev:
+        ev[1].record()
+    dist, _ = emd_mod(pred, gt, eps, iters)
+    emd_out = torch.sqrt(dist).mean(1)
+    if ev:
+        ev[2].record()
+    return cd_p, cd_t, f1, emd_out
+
+
+def cpu_baseline(args, n):
+    """The CPU oracle (C restatement of the reference kernels, OpenMP over the
+    batch dimension) on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle  # test infrastructure: timed here as the baseline, never shipped
+    oracle.build()
+    cores = os.cpu_count() or 1
+    oracle.set_num_threads(cores)
+    bs = args.cpu_sample or min(cores, 64)
+    rng = np.random.default_rng(0)
+    pred = rng.random((bs, n, 3), dtype=np.float32)
+    gt = rng.random((bs, n, 3), dtype=np.float32)
+    t0 = time.perf_counter()
+    oracle.chamfer_forward(gt, pred)
+    t1 = time.perf_counter()
+    _, _, stats = oracle.emd_forward(pred, gt, args.eps, args.iters, return_stats=True)
+    t2 = time.perf_counter()
+    return {
+        "value": bs * n * n / (t2 - t0),
+        "unit": "point-pairs/s",
+        "cores": min(cores, bs),
+        "kind": "port",
+        "sample": "%d clouds of %d pts (one per core, OpenMP over clouds), CD + EMD eps=%g iters=%d; "
+                  "CD %.2f s, EMD %.2f s, EMD rounds %d, bids/cloud %.0f" % (
+                      bs, n, args.eps, args.iters, t1 - t0, t2 - t1,
+                      int(stats[:, 0].max()), float(stats[:, 1].mean())),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from mvp_benchmark_amd.metrics import cd, emd, fscore
+    from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample, gather_points
+    from mvp_benchmark_amd import _lib
+
+    B, n = args.batch, args.points
+    g = torch.Generator().manual_seed(1000 + rank)
+    pred = torch.rand(B, n, 3, generator=g).to(dev)
+    gt = torch.rand(B, n, 3, generator=g).to(dev)
+    cd_mod, emd_mod = cd(), emd()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eval_step(cd_mod, emd_mod, fscore, pred, gt, args.eps, args.iters)
+    barrier()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        out = eval_step(cd_mod, emd_mod, fscore, pred, gt, args.eps, args.iters, evs[s])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # eval-loop aggregation: one 5-float sum all-reduce
+    sums = torch.stack([out[0].sum(), out[1].sum(), out[2].sum(), out[3].sum(),
+                        torch.tensor(float(B), device=dev)]).double()
+    if world > 1:
+        torch.distributed.all_reduce(sums)
+    sums = sums.cpu()
+
+    cd_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
+    emd_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    # ---- rank 0 only: side measurements (outside the timed region) ----
+    # auction statistics of one EMD launch (rounds, bids) via the C ABI
+    nbytes = _lib.emd_scratch_bytes(B, n)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dist = torch.zeros(B, n, device=dev)
+    ass = torch.zeros(B, n, dtype=torch.int32, device=dev)
+    _lib.call("mvp_emd_forward", dev, B, n, pred, gt, dist, ass, args.eps, args.iters, scratch, nbytes)
+    torch.cuda.synchronize()
+    stats = scratch[nbytes - B * 16:].view(torch.int64).view(B, 2).cpu()
+    rounds, bids = int(stats[:, 0].max()), float(stats[:, 1].double().mean())
+
+    # FPS throughput: (64, 16384, 3) -> 2048 and (64, 2048, 3) -> 512
+    fps = {}
+    for (fn, fm) in ((n, 2048), (2048, 512)):
+        x = torch.rand(B, fn, 3, generator=g).to(dev)
+        furthest_point_sample(x, fm)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 3
+        for _ in range(reps):
+            idx = furthest_point_sample(x, fm)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fps["fps_%d_to_%d" % (fn, fm)] = {"ms": ms, "sampled_pts_per_s": B * fm / ms * 1e3,
+                                          "point_updates_per_s": B * (fm - 1) * fn / ms * 1e3}
+        gather_points(x.transpose(1, 2).contiguous(), idx)
+
+    pairs = float(B) * n * n
+    value = pairs * world / (elapsed / args.steps)
+    emd_bytes = 32.0 * B * n  # xyz1+xyz2 in (24 B/pt) + dist+assignment out (8 B/pt)
+    achieved = emd_bytes / (emd_ms * 1e-3) / 1e9
+    line = {
+        "metric": "point-pairs/sec CD+EMD @2048->16384 pts, batch 64",
+        "value": value,
+        "unit": "point-pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "completion eval CD+F1+EMD, pred/gt (%d,%d,3) per GPU, "
+                               "EMD eps=%g iters=%d" % (B, n, args.eps, args.iters),
+                   "batch_per_gpu": B, "points": n, "parallelism": "batch-sharded x%d" % world},
+        "roofline": {"kernel": "emd_auction_kernel", "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None},
+        "extra": {
+            "cd_f1_ms": cd_ms, "emd_ms": emd_ms,
+            "emd_rounds_max": rounds, "emd_bids_per_cloud": bids,
+            "emd_reference_pair_evals_per_s": bids * n * B / (emd_ms * 1e-3),
+            "cd_pair_evals_per_s": 2 * pairs / (cd_ms * 1e-3),
+            "cd_valu_tflops_16flop_per_pair": 16 * pairs / (cd_ms * 1e-3) / 1e12,
+            "cd_hbm_GBs_20B_per_point": 20.0 * B * 2 * n / (cd_ms * 1e-3) / 1e9,
+            "metrics": {"cd_p": float(sums[0] / sums[4]), "cd_t": float(sums[1] / sums[4]),
+                        "f1": float(sums[2] / sums[4]), "emd": float(sums[3] / sums[4])},
+            **fps,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args, n)
+    print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""ctypes binding of libmvpops.so (the C ABI declared in include/mvpops.h).
+
+This is the binding a maintainer of the reference would write in place of the
+8 pybind11 modules (chamfer_3D, emd, furthest_point_sample_ext, ...): raw
+device pointers + int sizes + the current HIP stream.  See INTEGRATION.md.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (maps torch's libamdhip64.so.7 before ours resolves it)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvpops.so")
+
+MVP_OK = 0
+_ERR = {-1: "MVP_EBADSHAPE (bad shape / size guard)",
+        -2: "MVP_EBADARG (null or undersized buffer)",
+        -3: "MVP_ELAUNCH (HIP launch error)"}
+
+# name -> argument kinds: p = device pointer, i = int, f = float, q = int64
+SIGNATURES = {
+    "mvp_chamfer_forward": "iiipppppp",
+    "mvp_chamfer_backward": "iiipppppppp",
+    "mvp_emd_forward": "iippppfipq",
+    "mvp_emd_backward": "iippppp",
+    "mvp_furthest_point_sampling": "iiippp",
+    "mvp_furthest_point_sampling_with_dist": "iiippp",
+    "mvp_ball_query": "iiiffippp",
+    "mvp_knn": "iiiipppp",
+    "mvp_three_nn": "iiipppp",
+    "mvp_three_interpolate": "iiiipppp",
+    "mvp_three_interpolate_grad": "iiiipppp",
+    "mvp_gather_points": "iiiippp",
+    "mvp_gather_points_grad": "iiiippp",
+    "mvp_group_points": "iiiiippp",
+    "mvp_group_points_grad": "iiiiippp",
+}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
+       "q": ctypes.c_longlong}
+
+_lib = None
+
+
+class MvpOpsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmvpops.so; raise loudly if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvpOpsError(
+            "libmvpops.so not found at %s -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C mvp_benchmark_amd/csrc`. There is no CPU fallback."
+            % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mvp_abi_version.restype = ctypes.c_int
+    lib.mvp_last_hip_error.restype = ctypes.c_char_p
+    lib.mvp_emd_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_emd_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [_CT[k] for k in sig] + [ctypes.c_void_p]  # + stream
+    if lib.mvp_abi_version() != 1:
+        raise MvpOpsError("libmvpops.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MvpOpsError("libmvpops ops need GPU tensors (got %s); there is "
+                          "no CPU fallback" % t.device)
+    if not t.is_contiguous():
+        raise MvpOpsError("libmvpops ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def call(name, device, *args):
+    """Invoke one C-ABI entry point on `device`'s current stream."""
+    lib = load()
+    sig = SIGNATURES[name]
+    assert len(sig) == len(args), (name, len(sig), len(args))
+    cargs = []
+    for kind, a in zip(sig, args):
+        if kind == "p":
+            cargs.append(_ptr(a) if isinstance(a, torch.Tensor) else a)
+        elif kind == "f":
+            cargs.append(float(a))
+        else:
+            cargs.append(int(a))
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = getattr(lib, name)(*cargs, stream)
+    if rc != MVP_OK:
+        detail = _ERR.get(rc, "code %d" % rc)
+        if rc == -3:
+            detail += ": " + lib.mvp_last_hip_error().decode()
+        raise MvpOpsError("%s failed: %s" % (name, detail))
+
+
+def emd_scratch_bytes(b, n):
+    return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
+
+
+def exported_symbols():
+    """All entry points include/mvpops.h declares."""
+    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes"] \
+        + list(SIGNATURES)

@@ -1,0 +1,196 @@
+// gather_points / grouping_operation / three_interpolate (+ gradients) for
+// gfx950.  These are the HBM-bound rows of the hot path: a
+// gathered read of a (B,C,N) feature tensor and a streaming write.
+//
+// Replaces gather_points_kernel/_grad_kernel
+// (utils/mm3d_pn2/ops/gather_points/src/gather_points_cuda.cu:8-26,51-70),
+// group_points_kernel/_grad_kernel
+// (ops/group_points/src/group_points_cuda.cu:56-79,10-31) and
+// three_interpolate_kernel/_grad_kernel
+// (ops/interpolate/src/three_interpolate_cuda.cu:11-35,61-84).
+//
+// MI355X-first layout of the work: the reference launches one thread per
+// (b, c, output point) and re-reads idx (and the 3 weights) for every channel.
+// Here a lane owns one output point, reads its index/weights ONCE into
+// registers and walks a strip of kChan channels, so the index traffic is paid
+// once per strip instead of once per channel, the gathered reads of one strip
+// stay inside one (N x kChan) slab of L2, and the stores are 256-lane
+// coalesced rows.  grouping_operation is the same kernel with the
+// (npoint, nsample) index array flattened.
+#include "common.h"
+
+namespace mvp {
+
+constexpr int kGThreads = 256;
+constexpr int kChan = 8;  // channels per workgroup strip
+
+__global__ __launch_bounds__(kGThreads) void gather_kernel(
+    int c, int n, int m, const float *__restrict__ points,
+    const int *__restrict__ idx, float *__restrict__ out) {
+  const int p = blockIdx.x * kGThreads + threadIdx.x;
+  if (p >= m) return;
+  const int cloud = blockIdx.z;
+  const int c0 = blockIdx.y * kChan;
+  const int id = idx[(size_t)cloud * m + p];
+  const float *src = points + ((size_t)cloud * c + c0) * n + id;
+  float *dst = out + ((size_t)cloud * c + c0) * m + p;
+  const int cn = min(kChan, c - c0);
+  if (cn == kChan) {
+    float v[kChan];
+#pragma unroll
+    for (int k = 0; k < kChan; ++k) v[k] = src[(size_t)k * n];
+#pragma unroll
+    for (int k = 0; k < kChan; ++k) dst[(size_t)k * m] = v[k];
+  } else {
+    for (int k = 0; k < cn; ++k) dst[(size_t)k * m] = src[(size_t)k * n];
+  }
+}
+
+__global__ __launch_bounds__(kGThreads) void gather_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_points) {
+  const int p = blockIdx.x * kGThreads + threadIdx.x;
+  if (p >= m) return;
+  const int cloud = blockIdx.z;
+  const int c0 = blockIdx.y * kChan;
+  const int id = idx[(size_t)cloud * m + p];
+  const float *src = grad_out + ((size_t)cloud * c + c0) * m + p;
+  float *dst = grad_points + ((size_t)cloud * c + c0) * n + id;
+  const int cn = min(kChan, c - c0);
+  for (int k = 0; k < cn; ++k) atomicAdd(dst + (size_t)k * n, src[(size_t)k * m]);
+}
+
+__global__ __launch_bounds__(kGThreads) void three_interpolate_kernel(
+    int c, int m, int n, const float *__restrict__ points,
+    const int *__restrict__ idx, const float *__restrict__ weight,
+    float *__restrict__ out) {
+  const int p = blockIdx.x * kGThreads + threadIdx.x;
+  if (p >= n) return;
+  const int cloud = blockIdx.z;
+  const int c0 = blockIdx.y * kChan;
+  const int *id = idx + ((size_t)cloud * n + p) * 3;
+  const float *w = weight + ((size_t)cloud * n + p) * 3;
+  const int i0 = id[0], i1 = id[1], i2 = id[2];
+  const float w0 = w[0], w1 = w[1], w2 = w[2];
+  const float *src = points + ((size_t)cloud * c + c0) * m;
+  float *dst = out + ((size_t)cloud * c + c0) * n + p;
+  const int cn = min(kChan, c - c0);
+  for (int k = 0; k < cn; ++k) {
+    const float *row = src + (size_t)k * m;
+    // w0*p0 + w1*p1 + w2*p2 == fma(w2,p2, fma(w1,p1, w0*p0)) (oracle chain)
+    dst[(size_t)k * n] =
+        __builtin_fmaf(w2, row[i2], __builtin_fmaf(w1, row[i1], w0 * row[i0]));
+  }
+}
+
+__global__ __launch_bounds__(kGThreads) void three_interpolate_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, const float *__restrict__ weight,
+    float *__restrict__ grad_points) {
+  const int p = blockIdx.x * kGThreads + threadIdx.x;
+  if (p >= n) return;
+  const int cloud = blockIdx.z;
+  const int c0 = blockIdx.y * kChan;
+  const int *id = idx + ((size_t)cloud * n + p) * 3;
+  const float *w = weight + ((size_t)cloud * n + p) * 3;
+  const int i0 = id[0], i1 = id[1], i2 = id[2];
+  const float w0 = w[0], w1 = w[1], w2 = w[2];
+  const float *src = grad_out + ((size_t)cloud * c + c0) * n + p;
+  float *dst = grad_points + ((size_t)cloud * c + c0) * m;
+  const int cn = min(kChan, c - c0);
+  for (int k = 0; k < cn; ++k) {
+    const float g = src[(size_t)k * n];
+    float *row = dst + (size_t)k * m;
+    atomicAdd(row + i0, g * w0);
+    atomicAdd(row + i1, g * w1);
+    atomicAdd(row + i2, g * w2);
+  }
+}
+
+static bool grid_ok(long long gx, long long gy, long long gz) {
+  return gx <= 2147483647LL && gy <= 65535 && gz <= 65535;
+}
+
+}  // namespace mvp
+
+using namespace mvp;
+
+extern "C" int mvp_gather_points(int b, int c, int n, int npoints,
+                                 const float *points, const int *idx,
+                                 float *out, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0) return MVP_EBADSHAPE;
+  if (b == 0 || c == 0 || npoints == 0) return MVP_OK;
+  if (n == 0) return MVP_EBADSHAPE;
+  if (!points || !idx || !out) return MVP_EBADARG;
+  dim3 grid((npoints + kGThreads - 1) / kGThreads, (c + kChan - 1) / kChan, b);
+  if (!grid_ok(grid.x, grid.y, grid.z)) return MVP_EBADSHAPE;
+  hipLaunchKernelGGL(gather_kernel, grid, dim3(kGThreads), 0, as_stream(stream),
+                     c, n, npoints, points, idx, out);
+  return check_launch("mvp_gather_points");
+}
+
+extern "C" int mvp_gather_points_grad(int b, int c, int n, int npoints,
+                                      const float *grad_out, const int *idx,
+                                      float *grad_points, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0) return MVP_EBADSHAPE;
+  if (b == 0 || c == 0 || npoints == 0) return MVP_OK;
+  if (n == 0) return MVP_EBADSHAPE;
+  if (!grad_out || !idx || !grad_points) return MVP_EBADARG;
+  dim3 grid((npoints + kGThreads - 1) / kGThreads, (c + kChan - 1) / kChan, b);
+  if (!grid_ok(grid.x, grid.y, grid.z)) return MVP_EBADSHAPE;
+  hipLaunchKernelGGL(gather_grad_kernel, grid, dim3(kGThreads), 0,
+                     as_stream(stream), c, n, npoints, grad_out, idx,
+                     grad_points);
+  return check_launch("mvp_gather_points_grad");
+}
+
+extern "C" int mvp_group_points(int b, int c, int n, int npoints, int nsample,
+                                const float *points, const int *idx, float *out,
+                                void *stream) {
+  if (npoints < 0 || nsample < 0) return MVP_EBADSHAPE;
+  const long long flat = (long long)npoints * nsample;
+  if (flat > 2147483647LL) return MVP_EBADSHAPE;
+  return mvp_gather_points(b, c, n, (int)flat, points, idx, out, stream);
+}
+
+extern "C" int mvp_group_points_grad(int b, int c, int n, int npoints,
+                                     int nsample, const float *grad_out,
+                                     const int *idx, float *grad_points,
+                                     void *stream) {
+  if (npoints < 0 || nsample < 0) return MVP_EBADSHAPE;
+  const long long flat = (long long)npoints * nsample;
+  if (flat > 2147483647LL) return MVP_EBADSHAPE;
+  return mvp_gather_points_grad(b, c, n, (int)flat, grad_out, idx, grad_points,
+                                stream);
+}
+
+extern "C" int mvp_three_interpolate(int b, int c, int m, int n,
+                                     const float *points, const int *idx,
+                                     const float *weight, float *out,
+                                     void *stream) {
+  if (b < 0 || c < 0 || m < 0 || n < 0) return MVP_EBADSHAPE;
+  if (b == 0 || c == 0 || n == 0) return MVP_OK;
+  if (m == 0) return MVP_EBADSHAPE;
+  if (!points || !idx || !weight || !out) return MVP_EBADARG;
+  dim3 grid((n + kGThreads - 1) / kGThreads, (c + kChan - 1) / kChan, b);
+  if (!grid_ok(grid.x, grid.y, grid.z)) return MVP_EBADSHAPE;
+  hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(kGThreads), 0,
+                     as_stream(stream), c, m, n, points, idx, weight, out);
+  return check_launch("mvp_three_interpolate");
+}
+
+extern "C" int mvp_three_interpolate_grad(int b, int c, int n, int m,
+                                          const float *grad_out, const int *idx,
+                                          const float *weight,
+                                          float *grad_points, void *stream) {
+  if (b < 0 || c < 0 || m < 0 || n < 0) return MVP_EBADSHAPE;
+  if (b == 0 || c == 0 || n == 0) return MVP_OK;
+  if (m == 0) return MVP_EBADSHAPE;
+  if (!grad_out || !idx || !weight || !grad_points) return MVP_EBADARG;
+  dim3 grid((n + kGThreads - 1) / kGThreads, (c + kChan - 1) / kChan, b);
+  if (!grid_ok(grid.x, grid.y, grid.z)) return MVP_EBADSHAPE;
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(kGThreads), 0,
+                     as_stream(stream), c, n, m, grad_out, idx, weight,
+                     grad_points);
+  return check_launch("mvp_three_interpolate_grad");
+}

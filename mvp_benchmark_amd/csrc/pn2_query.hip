@@ -1,0 +1,270 @@
+// ball_query / knn / three_nn for gfx950: the brute-force neighbourhood
+// queries of the PointNet++ set-abstraction path.
+//
+// Replaces ball_query_kernel (utils/mm3d_pn2/ops/ball_query/src/
+// ball_query_cuda.cu:11-54), knn_kernel (ops/knn/src/knn_cuda.cu:58-95) and
+// three_nn_kernel (ops/interpolate/src/three_nn_cuda.cu:11-66).
+//
+// The reference gives every query one thread that walks global memory
+// serially (broadcast, uncoalesced reads).  Here:
+//   * knn / three_nn share the Chamfer skeleton: a lane owns a query in
+//     registers, candidates stream through a wave-uniform LDS tile;
+//   * ball_query uses one WAVE per centre: 64 candidates are tested per step,
+//     a ballot + prefix popcount assigns output slots in ascending index
+//     order, and the scan stops as soon as nsample hits exist -- the same
+//     "first nsample in index order" rule, 64 candidates at a time.
+// All three keep the reference's exact selection/tie semantics (see each
+// kernel) and the canonical distance chain of the oracle.
+#include "common.h"
+
+namespace mvp {
+
+// ------------------------------------------------------------- ball_query
+constexpr int kBqThreads = 256;
+constexpr int kBqWaves = kBqThreads / kWave;
+
+__global__ __launch_bounds__(kBqThreads) void ball_query_kernel(
+    int n, int m, float min_radius, float max_radius, int nsample,
+    const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    int *__restrict__ idx) {
+  const int wave = threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave;
+  const int p = blockIdx.x * kBqWaves + wave;
+  if (p >= m) return;  // wave-uniform
+  const int cloud = blockIdx.y;
+  const float *c = new_xyz + ((size_t)cloud * m + p) * 3;
+  const float *pts = xyz + (size_t)cloud * n * 3;
+  int *o = idx + ((size_t)cloud * m + p) * nsample;
+  const float max_radius2 = max_radius * max_radius;
+  const float min_radius2 = min_radius * min_radius;
+  const float nx = c[0], ny = c[1], nz = c[2];
+
+  int cnt = 0;
+  int first = 0;
+  for (int base = 0; base < n && cnt < nsample; base += kWave) {
+    const int k = base + lane;
+    bool hit = false;
+    if (k < n) {
+      const float d2 = sqdist3(nx - pts[k * 3 + 0], ny - pts[k * 3 + 1],
+                               nz - pts[k * 3 + 2]);
+      hit = d2 == 0 || (d2 >= min_radius2 && d2 < max_radius2);
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0) continue;
+    if (cnt == 0) first = base + __builtin_ctzll(mask);
+    const int pos = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    if (hit && pos < nsample) o[pos] = k;
+    cnt += __builtin_popcountll(mask);
+  }
+  // Slots beyond the hits keep the first hit (ball_query_cuda.cu:44-48); a
+  // centre with no hit keeps the caller's zeros (ball_query.py:35).
+  const int filled = cnt < nsample ? cnt : nsample;
+  const int fill = cnt > 0 ? first : 0;
+  for (int l = filled + lane; l < nsample; l += kWave) o[l] = fill;
+}
+
+// -------------------------------------------------------------------- knn
+constexpr int kQTile = 1024;  // candidates per LDS tile
+
+// Max-heap in LDS, one column per thread: slot s of thread t at [s*T + t].
+template <int T>
+__device__ __forceinline__ void knn_reheap(float *hd, int *hi, int t, int k) {
+  int root = 0;
+  int child = 1;
+  while (child < k) {
+    if (child + 1 < k && hd[(child + 1) * T + t] > hd[child * T + t]) child++;
+    if (hd[root * T + t] > hd[child * T + t]) return;
+    const float tf = hd[root * T + t];
+    hd[root * T + t] = hd[child * T + t];
+    hd[child * T + t] = tf;
+    const int ti = hi[root * T + t];
+    hi[root * T + t] = hi[child * T + t];
+    hi[child * T + t] = ti;
+    root = child;
+    child = root * 2 + 1;
+  }
+}
+
+// knn_kernel, knn_cuda.cu:58-95: admission by strict `<` against the heap
+// root (:83), reheap swapping on equality (:34), final heap_sort (:44-53).
+template <int T>
+__global__ __launch_bounds__(T) void knn_kernel(
+    int n, int m, int nsample, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, int *__restrict__ idx,
+    float *__restrict__ dist2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *tile = reinterpret_cast<float *>(smem);              // kQTile*3
+  float *hd = tile + kQTile * 3;                              // nsample*T
+  int *hi = reinterpret_cast<int *>(hd + (size_t)nsample * T);  // nsample*T
+
+  const int t = threadIdx.x;
+  const int cloud = blockIdx.y;
+  const int p = blockIdx.x * T + t;
+  const bool active = p < m;
+  const int pc = active ? p : m - 1;
+  const float *c = new_xyz + ((size_t)cloud * m + pc) * 3;
+  const float *pts = xyz + (size_t)cloud * n * 3;
+  const float nx = c[0], ny = c[1], nz = c[2];
+
+  for (int i = 0; i < nsample; ++i) {
+    hd[i * T + t] = 1e10f;
+    hi[i * T + t] = 0;
+  }
+  float rootd = 1e10f;
+
+  for (int k2 = 0; k2 < n; k2 += kQTile) {
+    const int cnt = min(kQTile, n - k2);
+    __syncthreads();
+    for (int q = t; q < cnt * 3; q += T) tile[q] = pts[(size_t)k2 * 3 + q];
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+      const float d2 = sqdist3(nx - tile[i * 3 + 0], ny - tile[i * 3 + 1],
+                               nz - tile[i * 3 + 2]);
+      if (d2 < rootd) {
+        hd[t] = d2;
+        hi[t] = k2 + i;
+        knn_reheap<T>(hd, hi, t, nsample);
+        rootd = hd[t];
+      }
+    }
+  }
+  // heap_sort
+  for (int i = nsample - 1; i > 0; i--) {
+    const float tf = hd[t];
+    hd[t] = hd[i * T + t];
+    hd[i * T + t] = tf;
+    const int ti = hi[t];
+    hi[t] = hi[i * T + t];
+    hi[i * T + t] = ti;
+    knn_reheap<T>(hd, hi, t, i);
+  }
+  if (active) {
+    int *o = idx + ((size_t)cloud * m + p) * nsample;
+    float *od = dist2 + ((size_t)cloud * m + p) * nsample;
+    for (int i = 0; i < nsample; ++i) {
+      o[i] = hi[i * T + t];
+      od[i] = hd[i * T + t];
+    }
+  }
+}
+
+// --------------------------------------------------------------- three_nn
+constexpr int kNnThreads = 256;
+
+// three_nn_kernel, three_nn_cuda.cu:11-66.  The reference keeps the three
+// bests in double initialised to 1e40 and stores them as float; comparing a
+// float d against such a double is identical to a float compare against +inf
+// (1e40 rounds to +inf on store), so float registers with +inf are exact.
+__global__ __launch_bounds__(kNnThreads) void three_nn_kernel(
+    int n, int m, const float *__restrict__ unknown,
+    const float *__restrict__ known, float *__restrict__ dist2,
+    int *__restrict__ idx) {
+  __shared__ __attribute__((aligned(16))) float tile[kQTile * 3];
+  const int t = threadIdx.x;
+  const int cloud = blockIdx.y;
+  const int p = blockIdx.x * kNnThreads + t;
+  const bool active = p < n;
+  const int pc = active ? p : n - 1;
+  const float *u = unknown + ((size_t)cloud * n + pc) * 3;
+  const float *kn = known + (size_t)cloud * m * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  float best1 = __builtin_inff(), best2 = __builtin_inff(),
+        best3 = __builtin_inff();
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int k2 = 0; k2 < m; k2 += kQTile) {
+    const int cnt = min(kQTile, m - k2);
+    __syncthreads();
+    for (int q = t; q < cnt * 3; q += kNnThreads) tile[q] = kn[(size_t)k2 * 3 + q];
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+      const float d = sqdist3(ux - tile[i * 3 + 0], uy - tile[i * 3 + 1],
+                              uz - tile[i * 3 + 2]);
+      const int k = k2 + i;
+      if (d < best3) {  // common case (no change) costs one compare
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = k;
+        } else {
+          best3 = d; besti3 = k;
+        }
+      }
+    }
+  }
+  if (active) {
+    const size_t o = ((size_t)cloud * n + p) * 3;
+    dist2[o + 0] = best1;
+    dist2[o + 1] = best2;
+    dist2[o + 2] = best3;
+    idx[o + 0] = besti1;
+    idx[o + 1] = besti2;
+    idx[o + 2] = besti3;
+  }
+}
+
+}  // namespace mvp
+
+using namespace mvp;
+
+extern "C" int mvp_ball_query(int b, int n, int m, float min_radius,
+                              float max_radius, int nsample,
+                              const float *new_xyz, const float *xyz, int *idx,
+                              void *stream) {
+  if (b < 0 || n < 0 || m < 0 || nsample < 0) return MVP_EBADSHAPE;
+  if (b == 0 || m == 0 || nsample == 0) return MVP_OK;
+  if (!new_xyz || !idx || (n > 0 && !xyz)) return MVP_EBADARG;
+  if (b > 65535) return MVP_EBADSHAPE;
+  dim3 grid((m + kBqWaves - 1) / kBqWaves, b);
+  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kBqThreads), 0,
+                     as_stream(stream), n, m, min_radius, max_radius, nsample,
+                     new_xyz, xyz, idx);
+  return check_launch("mvp_ball_query");
+}
+
+extern "C" int mvp_knn(int b, int n, int m, int nsample, const float *xyz,
+                       const float *new_xyz, int *idx, float *dist2,
+                       void *stream) {
+  if (b < 0 || n < 0 || m < 0 || nsample < 1 || nsample > 100)
+    return MVP_EBADSHAPE;
+  if (b == 0 || m == 0) return MVP_OK;
+  if (!new_xyz || !idx || !dist2 || (n > 0 && !xyz)) return MVP_EBADARG;
+  if (b > 65535) return MVP_EBADSHAPE;
+  // Heap columns live in LDS; block size shrinks with k so that
+  // tile (12 KiB) + heaps (nsample*T*8 B) stays under 64 KiB.
+  if (nsample <= 16) {
+    constexpr int T = 256;
+    const size_t lds = kQTile * 3 * 4 + (size_t)nsample * T * 8;
+    dim3 grid((m + T - 1) / T, b);
+    hipLaunchKernelGGL(knn_kernel<T>, grid, dim3(T), lds, as_stream(stream), n,
+                       m, nsample, xyz, new_xyz, idx, dist2);
+  } else if (nsample <= 32) {
+    constexpr int T = 128;
+    const size_t lds = kQTile * 3 * 4 + (size_t)nsample * T * 8;
+    dim3 grid((m + T - 1) / T, b);
+    hipLaunchKernelGGL(knn_kernel<T>, grid, dim3(T), lds, as_stream(stream), n,
+                       m, nsample, xyz, new_xyz, idx, dist2);
+  } else {
+    constexpr int T = 64;
+    const size_t lds = kQTile * 3 * 4 + (size_t)nsample * T * 8;
+    dim3 grid((m + T - 1) / T, b);
+    hipLaunchKernelGGL(knn_kernel<T>, grid, dim3(T), lds, as_stream(stream), n,
+                       m, nsample, xyz, new_xyz, idx, dist2);
+  }
+  return check_launch("mvp_knn");
+}
+
+extern "C" int mvp_three_nn(int b, int n, int m, const float *unknown,
+                            const float *known, float *dist2, int *idx,
+                            void *stream) {
+  if (b < 0 || n < 0 || m < 0) return MVP_EBADSHAPE;
+  if (b == 0 || n == 0) return MVP_OK;
+  if (!unknown || !dist2 || !idx || (m > 0 && !known)) return MVP_EBADARG;
+  if (b > 65535) return MVP_EBADSHAPE;
+  dim3 grid((n + kNnThreads - 1) / kNnThreads, b);
+  hipLaunchKernelGGL(three_nn_kernel, grid, dim3(kNnThreads), 0,
+                     as_stream(stream), n, m, unknown, known, dist2, idx);
+  return check_launch("mvp_three_nn");
+}
