@@ -4,27 +4,36 @@
 // (utils/metrics/EMD/emd_cuda.cu:23-226, 228-282, 284-316).
 //
 // The reference runs 7 kernel launches per auction round on the legacy
-// default stream (21 001 launches at the eval setting iters=3000) with all
-// state in global memory and a racy GetMax.  MI355X-first design:
+// default stream (21 001 launches at the eval setting iters=3000), every
+// bidder scans all n objects every round (O(n^2 k)), and GetMax is racy.
+// MI355X-first design:
 //   * ONE persistent launch; a 1024-lane workgroup owns one cloud and runs the
 //     whole auction with workgroup barriers (3 per round) instead of launches;
 //     rounds stop as soon as nobody is unassigned (exact: such rounds are
 //     no-ops in the reference, emd_cuda.cu:105-106,185,199);
 //   * the unassigned list is maintained incrementally (losers stay, evicted
-//     owners are appended) instead of being rebuilt by a count / prefix-sum /
-//     compaction pass over all n points each round;
-//   * object data is packed as float4 {x, y, z, price}: one coalesced 16-byte
-//     load per object per bidder-wave;
-//   * Bid: one wave per bidder.  The hot loop evaluates only the squared
-//     distance and a conservative test against the current second-best value
-//     (no sqrt, no double arithmetic); the exact reference value
-//         d = float(3.0 - (double)sqrtf(s) - (double)price)   (emd_cuda.cu:146)
-//     is computed only for the few candidates that can change {best, second
-//     best, best index}, and merged into wave-uniform state.  The filter is
-//     provably lossless (see kMargin).
+//     owners are appended) instead of a count / prefix-sum / compaction pass
+//     over all n points per round;
+//   * objects (xyz2) are bucketed once into a uniform grid (<= 12^3 cells) and
+//     stored cell-sorted as float4 {x, y, z, price}.  Per cell the workgroup
+//     keeps in LDS the exact bounding box of its members and a lower bound of
+//     their prices (prices only rise, so a stale bound stays valid);
+//   * Bid = one wave per bidder.  A bid needs the best and
+//     second-best of  v_k = float(3.0 - (double)sqrtf(|q-o_k|^2) - price_k)
+//     (emd_cuda.cu:146) over all k.  Instead of evaluating all n objects the
+//     wave (1) seeds a lower bound B2 of the second-best value from the
+//     bidder's home cell and its previous two best objects, (2) tests all
+//     cells 64 at a time against  dist(q, box) + price_lb <= 3 - B2  and
+//     (3) visits only surviving cells, where each object first passes the
+//     same conservative test on its squared distance (no sqrt, no double);
+//     only objects that can still change {best, second best, best index} get
+//     the exact double-precision value and are folded into wave-uniform state.
+//     Every skip is provably lossless (kMargin below), so bids are
+//     bit-identical to the exhaustive scan;
 //   * ties are resolved by the reference's own order, reconstructed from its
 //     thread partition (emd_cuda.cu:108-118,139-142,163-171): candidates are
-//     ordered by (chunk thread, 2048-tile, index in tile);
+//     ordered by (chunk thread, 2048-tile, index in tile) of their ORIGINAL
+//     object index;
 //   * GetMax's last-writer race (emd_cuda.cu:188-191) is made deterministic:
 //     the highest qualifying bidder index wins, via a round-tagged 64-bit
 //     atomic max -- the result of executing the reference kernel sequentially.
@@ -32,30 +41,43 @@
 
 namespace mvp {
 
+#ifndef MVP_EMD_STOP
+#define MVP_EMD_STOP 99
+#endif
+#define MVP_STAGE(k) do { if (MVP_EMD_STOP == (k)) { if (threadIdx.x == 0) { stats[0] = 1000 + (k); stats[1] = 0; } return; } } while (0)
+
 constexpr int kEmdThreads = 1024;
 constexpr int kEmdWaves = kEmdThreads / kWave;
+constexpr int kMaxG = 12;
+constexpr int kMaxCells = kMaxG * kMaxG * kMaxG;  // 1728
 
-// Filter slack.  A candidate is skipped only if
+// Filter slack.  An object is skipped only if
 //   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
 // which implies sqrtf(s) + price > (3 - B2) + kMargin - 7e-7, hence the exact
 // value  float(3.0 - sqrtf(s) - price) <= (3 - sqrtf(s) - price) + 1.3e-7
-// < B2: the candidate can change neither best, second best nor (being
-// strictly below B2 <= B1) the tie-broken best index.
+// < B2: the object can change neither best, second best nor (being strictly
+// below B2 <= B1) the tie-broken best index.  A cell is skipped with the same
+// test on (squared distance to its bounding box, price lower bound); because
+// float subtraction/multiply/fma are monotone, every member's own test value
+// is >= the cell's, so a skipped cell contains only skippable objects.
 constexpr float kMargin = 1e-5f;
 
 struct EmdScratch {
-  float4 *obj;                 // (n) x, y, z, price of every object (xyz2)
-  int *bid;                    // (n) object each person last bid on
-  float *bidinc;               // (n) its bid increment
-  int *maxinc;                 // (n) per object: max increment, float bits
-  unsigned long long *maxidx;  // (n) per object: (round+1)<<32 | winner
-  int *ass_inv;                // (n) object -> owner
+  float4 *obj;                 // (n) cell-sorted x, y, z, price of xyz2
+  unsigned long long *maxidx;  // (n) per slot: (round+1)<<32 | winner
+  int *perm;                   // (n) slot -> original object index
+  int *cellof;                 // (n) slot -> cell
+  int *bid;                    // (n) per person: slot last bid on
+  float *bidinc;               // (n) per person: its bid increment
+  int *maxinc;                 // (n) per slot: max increment, float bits
+  int *ass_inv;                // (n) slot -> owner
+  int *prev1, *prev2;          // (n) per person: best / second-best slot of
+                               //     its previous bid (seed hints only)
   int *ulist;                  // (2n) ping-pong unassigned lists
 };
 
 __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
-  // obj 16 + bid 4 + bidinc 4 + maxinc 4 + maxidx 8 + ass_inv 4 + ulist 8
-  return (size_t)n * 48;
+  return (size_t)n * 64;
 }
 
 __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
@@ -64,20 +86,21 @@ __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
   base += (size_t)n * 16;
   s.maxidx = reinterpret_cast<unsigned long long *>(base);
   base += (size_t)n * 8;
-  s.bid = reinterpret_cast<int *>(base);
-  base += (size_t)n * 4;
-  s.bidinc = reinterpret_cast<float *>(base);
-  base += (size_t)n * 4;
-  s.maxinc = reinterpret_cast<int *>(base);
-  base += (size_t)n * 4;
-  s.ass_inv = reinterpret_cast<int *>(base);
-  base += (size_t)n * 4;
-  s.ulist = reinterpret_cast<int *>(base);
+  int *ip = reinterpret_cast<int *>(base);
+  s.perm = ip;
+  s.cellof = ip + (size_t)n;
+  s.bid = ip + (size_t)2 * n;
+  s.bidinc = reinterpret_cast<float *>(ip + (size_t)3 * n);
+  s.maxinc = ip + (size_t)4 * n;
+  s.ass_inv = ip + (size_t)5 * n;
+  s.prev1 = ip + (size_t)6 * n;
+  s.prev2 = ip + (size_t)7 * n;
+  s.ulist = ip + (size_t)8 * n;
   return s;
 }
 
-// Reference merge order between two candidates of equal value: the one whose
-// (thread_in_unass, tile, k) is lexicographically smaller wins.
+// Reference merge order between two candidates (ORIGINAL object indices) of
+// equal value: lexicographically smaller (thread_in_unass, tile, k) wins.
 __device__ __forceinline__ bool emd_precedes(int ka, int kb, int n, int tpu) {
   const int tile_a = ka >> 11, tile_b = kb >> 11;
   const int kka = ka & 2047, kkb = kb & 2047;
@@ -104,32 +127,60 @@ __device__ __forceinline__ float emd_value(float s, float p) {
 // Wave-uniform running state of one bid.
 struct BidState {
   float b1, b2;  // best / second-best value
-  int bk;        // best object
-  float tm;      // filter threshold: fl(fl(3 - b2) + kMargin)
+  int bk, b2k;   // their slots (b2k is only a seed hint)
+  float tm;      // filter threshold: <= fl(fl(3 - b2) + kMargin)
 };
 
-// Fold the candidates flagged in `mask` (exact value v held per lane, object
-// index k per lane) into the uniform state, lowest lane first.
+// Fold the candidates flagged in `mask` (exact value v and slot k per lane)
+// into the uniform state, lowest lane first.
 __device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
-                                         float v, int k, int n, int tpu) {
+                                         float v, int k, int n, int tpu,
+                                         const int *__restrict__ perm) {
   while (mask) {
     const int l = __builtin_ctzll(mask);
     mask &= mask - 1;
-    const float vl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    const float vl =
+        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
     const int kl = __builtin_amdgcn_readlane(k, l);
     if (vl > st.b1) {
       st.b2 = st.b1;
+      st.b2k = st.bk;
       st.b1 = vl;
       st.bk = kl;
     } else if (vl == st.b1) {
       st.b2 = st.b1;
-      if (emd_precedes(kl, st.bk, n, tpu)) st.bk = kl;
+      if (emd_precedes(perm[kl], perm[st.bk], n, tpu)) {
+        st.b2k = st.bk;
+        st.bk = kl;
+      } else {
+        st.b2k = kl;
+      }
     } else if (vl > st.b2) {
       st.b2 = vl;
+      st.b2k = kl;
     }
   }
   // thresholds only ever tighten (the seed may already be tighter)
   st.tm = __builtin_fminf(st.tm, (3.0f - st.b2) + kMargin);
+}
+
+__device__ __forceinline__ void top2_insert(float &a1, float &a2, float v) {
+  const float lo = __builtin_fminf(a1, v);
+  a1 = __builtin_fmaxf(a1, v);
+  a2 = __builtin_fmaxf(a2, lo);
+}
+
+struct GridGeom {
+  float lox, loy, loz, invh;
+  int g;
+};
+
+__device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
+                                        float z) {
+  const int ix = min(gg.g - 1, max(0, (int)((x - gg.lox) * gg.invh)));
+  const int iy = min(gg.g - 1, max(0, (int)((y - gg.loy) * gg.invh)));
+  const int iz = min(gg.g - 1, max(0, (int)((z - gg.loz) * gg.invh)));
+  return (iz * gg.g + iy) * gg.g + ix;
 }
 
 __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
@@ -149,25 +200,147 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   xyz2 += (size_t)cloud * n * 3;
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
-  const EmdScratch sc = emd_carve(scratch + (size_t)cloud * emd_scratch_per_cloud(n), n);
+  const EmdScratch sc =
+      emd_carve(scratch + (size_t)cloud * emd_scratch_per_cloud(n), n);
 
+  // Per-cell metadata (SoA, conflict-free lane-per-cell reads).
+  __shared__ float c_minx[kMaxCells], c_miny[kMaxCells], c_minz[kMaxCells];
+  __shared__ float c_maxx[kMaxCells], c_maxy[kMaxCells], c_maxz[kMaxCells];
+  __shared__ float c_pmin[kMaxCells];
+  __shared__ int c_start[kMaxCells + 1];
+  __shared__ int s_tmp[kMaxCells];  // counts / fill cursors during the build
+  __shared__ float s_red[6][kEmdWaves];
+  __shared__ int s_wsum[kEmdWaves];
   __shared__ int s_cnt[2];
+  __shared__ int s_err;
 
-  // Initial state of emd_module.py:54-65.
+  // ------------------------------------------------------------ grid build
+  // (a) bounding box of both clouds
+  float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   for (int k = t; k < n; k += kEmdThreads) {
-    sc.obj[k] = make_float4(xyz2[k * 3 + 0], xyz2[k * 3 + 1], xyz2[k * 3 + 2], 0.f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float u = xyz1[k * 3 + a], w = xyz2[k * 3 + a];
+      mn[a] = __builtin_fminf(mn[a], __builtin_fminf(u, w));
+      mx[a] = __builtin_fmaxf(mx[a], __builtin_fmaxf(u, w));
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      mn[a] = __builtin_fminf(mn[a], __shfl_xor(mn[a], off, kWave));
+      mx[a] = __builtin_fmaxf(mx[a], __shfl_xor(mx[a], off, kWave));
+    }
+    if (lane == 0) {
+      s_red[a][wave] = mn[a];
+      s_red[3 + a][wave] = mx[a];
+    }
+  }
+  __syncthreads();
+  GridGeom gg;
+  {
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = s_red[a][0];
+      hi[a] = s_red[3 + a][0];
+      for (int w = 1; w < kEmdWaves; ++w) {
+        lo[a] = __builtin_fminf(lo[a], s_red[a][w]);
+        hi[a] = __builtin_fmaxf(hi[a], s_red[3 + a][w]);
+      }
+    }
+    float ext = __builtin_fmaxf(hi[0] - lo[0],
+                                __builtin_fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(ext > 0.f) || !(ext < 3.0e38f)) ext = 1.f;
+    // ~12 objects per cell (one 16-lane group), 2 <= G <= 12
+    int g = 2;
+    while (g < kMaxG && (g + 1) * (g + 1) * (g + 1) * 12 <= n) ++g;
+    gg.g = g;
+    gg.lox = lo[0];
+    gg.loy = lo[1];
+    gg.loz = lo[2];
+    gg.invh = (float)g / ext;
+  }
+  const int ncell = gg.g * gg.g * gg.g;
+  MVP_STAGE(1);
+
+  // (b) histogram
+  for (int c = t; c < kMaxCells; c += kEmdThreads) s_tmp[c] = 0;
+  __syncthreads();
+  for (int k = t; k < n; k += kEmdThreads)
+    atomicAdd(&s_tmp[emd_cell(gg, xyz2[k * 3 + 0], xyz2[k * 3 + 1], xyz2[k * 3 + 2])], 1);
+  __syncthreads();
+  MVP_STAGE(2);
+  // (c) exclusive prefix sum over <= 1728 cells: 2 cells per thread
+  {
+    const int c0 = 2 * t, c1 = 2 * t + 1;
+    const int v0 = c0 < ncell ? s_tmp[c0] : 0;
+    const int v1 = c1 < ncell ? s_tmp[c1] : 0;
+    int incl = v0 + v1;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int o = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += o;
+    }
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
+    const int excl = wbase + incl - (v0 + v1);
+    if (c0 <= ncell) c_start[c0] = excl;
+    if (c1 <= ncell) c_start[c1] = excl + v0;
+    __syncthreads();
+    if (c0 < kMaxCells) s_tmp[c0] = 0;
+    if (c1 < kMaxCells) s_tmp[c1] = 0;
+    __syncthreads();
+  }
+  MVP_STAGE(3);
+  // (d) scatter into cell-sorted order; initial state of emd_module.py:54-65
+  for (int k = t; k < n; k += kEmdThreads) {
+    const float x = xyz2[k * 3 + 0], y = xyz2[k * 3 + 1], z = xyz2[k * 3 + 2];
+    const int c = emd_cell(gg, x, y, z);
+    const int s = c_start[c] + atomicAdd(&s_tmp[c], 1);
+    sc.obj[s] = make_float4(x, y, z, 0.f);
+    sc.perm[s] = k;
+    sc.cellof[s] = c;
     ass[k] = -1;
     sc.ass_inv[k] = -1;
     sc.maxinc[k] = 0;  // 0.0f
     sc.maxidx[k] = 0ull;
+    sc.prev1[k] = -1;
+    sc.prev2[k] = -1;
     sc.ulist[k] = k;
   }
   if (t == 0) {
     s_cnt[0] = n;
     s_cnt[1] = 0;
+    s_err = 0;
+  }
+  __syncthreads();
+  MVP_STAGE(4);
+  // (e) exact bounding box per cell; price lower bound 0
+  for (int c = t; c < ncell; c += kEmdThreads) {
+    float bx0 = __builtin_inff(), by0 = __builtin_inff(), bz0 = __builtin_inff();
+    float bx1 = -__builtin_inff(), by1 = -__builtin_inff(), bz1 = -__builtin_inff();
+    for (int s = c_start[c]; s < c_start[c + 1]; ++s) {
+      const float4 o = sc.obj[s];
+      bx0 = __builtin_fminf(bx0, o.x);
+      by0 = __builtin_fminf(by0, o.y);
+      bz0 = __builtin_fminf(bz0, o.z);
+      bx1 = __builtin_fmaxf(bx1, o.x);
+      by1 = __builtin_fmaxf(by1, o.y);
+      bz1 = __builtin_fmaxf(bz1, o.z);
+    }
+    c_minx[c] = bx0; c_miny[c] = by0; c_minz[c] = bz0;
+    c_maxx[c] = bx1; c_maxy[c] = by1; c_maxz[c] = bz1;
+    c_pmin[c] = 0.f;
   }
   __syncthreads();
 
+  MVP_STAGE(5);
+  // ------------------------------------------------------------ the auction
   const int block_cnt = n / 1024;
   int cur = 0;
   long long n_rounds = 0, n_bids = 0;
@@ -187,19 +360,35 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     // ---------------- Bid (emd_cuda.cu:95-179): one wave per bidder
     for (int u = wave; u < U; u += kEmdWaves) {
       const int j = L[u];
-      const float x1 = xyz1[j * 3 + 0], y1 = xyz1[j * 3 + 1], z1 = xyz1[j * 3 + 2];
+      const float qx = xyz1[j * 3 + 0], qy = xyz1[j * 3 + 1], qz = xyz1[j * 3 + 2];
+      const int c0 = emd_cell(gg, qx, qy, qz);
+
+      // (1) seed: second-largest exact value among DISTINCT real objects --
+      // the home cell's members plus the previous best / second best when
+      // they live elsewhere.  Two real objects reach it, so it is a valid
+      // lower bound of the final second-best value.
       BidState st;
-      st.b1 = -1e9f;
-      st.b2 = -1e9f;
-      st.bk = -1;
-      // Seed the filter: second-largest exact value among the first 64
-      // objects (a valid lower bound of the final second best, because two
-      // real candidates reach it).  Values only -- the scan below still sees
-      // every object, so best/second/index are built by emd_fold alone.
       {
-        const float4 o = sc.obj[lane];
-        float a1 = emd_value(sqdist3(o.x - x1, o.y - y1, o.z - z1), o.w);
-        float a2 = -1e9f;
+        float a1 = -1e9f, a2 = -1e9f;
+        const int s0 = c_start[c0], s1 = c_start[c0 + 1];
+        for (int s = s0 + lane; s < s1; s += kWave) {
+          const float4 o = sc.obj[s];
+          top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
+        }
+        int have = s1 - s0;
+        const int p1 = sc.prev1[j], p2 = sc.prev2[j];
+        const bool use1 = p1 >= 0 && sc.cellof[p1] != c0;
+        const bool use2 = p2 >= 0 && sc.cellof[p2] != c0;
+        have += (use1 ? 1 : 0) + (use2 ? 1 : 0);
+        if ((lane == 0 && use1) || (lane == 1 && use2)) {
+          const float4 o = sc.obj[lane == 0 ? p1 : p2];
+          top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
+        }
+        if (have < 2) {  // wave-uniform; rare: fall back to the first 64 slots
+          const float4 o = sc.obj[lane];
+          a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
+          a2 = -1e9f;
+        }
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
           const float o1 = __shfl_xor(a1, off, kWave);
@@ -208,45 +397,112 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           a1 = __builtin_fmaxf(a1, o1);
           a2 = __builtin_fmaxf(lo, __builtin_fmaxf(a2, o2));
         }
-        st.tm = (3.0f - a2) + kMargin;
+        st.b1 = -1e9f;
+        st.b2 = -1e9f;
+        st.bk = -1;
+        st.b2k = -1;
+        const float seed_b2 =
+            __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a2)));
+        st.tm = (3.0f - seed_b2) + kMargin;
       }
-      for (int base = 0; base < n; base += 4 * kWave) {
-        float s[4], p[4];
-        bool pass[4];
-        bool anyp = false;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = base + r * kWave + lane;  // n % 1024 == 0: in range
-          const float4 o = sc.obj[k];
-          s[r] = sqdist3(o.x - x1, o.y - y1, o.z - z1);
-          p[r] = o.w;
-          const float tq = st.tm - o.w;
-          pass[r] = tq >= 0.f && s[r] <= tq * tq;
-          anyp |= pass[r];
+
+      // (2) Only cells that intersect the cube |o - q|_inf <= tm can hold a
+      // relevant object (prices are >= 0).  Enumerate that sub-box of the
+      // grid 64 cells at a time and test each cell's exact bounding box and
+      // price lower bound; (3) visit the survivors, 4 cells per step with 16
+      // lanes each.
+      int ix0, iy0, iz0, nx, ny, nz;
+      {
+        const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
+        const float fx = (qx - gg.lox) * gg.invh;
+        const float fy = (qy - gg.loy) * gg.invh;
+        const float fz = (qz - gg.loz) * gg.invh;
+        const float gm = (float)(gg.g - 1);
+        ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
+        iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
+        iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
+        nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
+        ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
+        nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
+        ix0 = __builtin_amdgcn_readfirstlane(ix0);
+        iy0 = __builtin_amdgcn_readfirstlane(iy0);
+        iz0 = __builtin_amdgcn_readfirstlane(iz0);
+        nx = __builtin_amdgcn_readfirstlane(nx);
+        ny = __builtin_amdgcn_readfirstlane(ny);
+        nz = __builtin_amdgcn_readfirstlane(nz);
+      }
+      const int nxy = nx * ny;
+      const int nsub = nxy * nz;
+      const float inv_nxy = 1.0f / (float)nxy, inv_nx = 1.0f / (float)nx;
+      const int sub = lane >> 4, sl = lane & 15;
+      for (int cb = 0; cb < nsub; cb += kWave) {
+        const int i = cb + lane;
+        bool cpass = false;
+        int c = 0;
+        if (i < nsub) {
+          // exact small-integer division via float (i < 1728, divisors <= 144)
+          const int kz = (int)(((float)i + 0.5f) * inv_nxy);
+          const int rem = i - kz * nxy;
+          const int ky = (int)(((float)rem + 0.5f) * inv_nx);
+          const int kx = rem - ky * nx;
+          c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
+          const float dx = __builtin_fmaxf(__builtin_fmaxf(c_minx[c] - qx, qx - c_maxx[c]), 0.f);
+          const float dy = __builtin_fmaxf(__builtin_fmaxf(c_miny[c] - qy, qy - c_maxy[c]), 0.f);
+          const float dz = __builtin_fmaxf(__builtin_fmaxf(c_minz[c] - qz, qz - c_maxz[c]), 0.f);
+          const float tq = st.tm - c_pmin[c];
+          cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
         }
-        if (__any(anyp)) {
+        unsigned long long cmask = __ballot(cpass);
+        while (cmask) {
+          // up to 4 surviving cells -> one per 16-lane group
+          int cc = -1;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            // Re-test against the threshold tightened by earlier groups.
-            const float tq = st.tm - p[r];
-            const bool ps = pass[r] && tq >= 0.f && s[r] <= tq * tq;
-            const unsigned long long mask = __ballot(ps);
-            if (mask) {
-              const float v = emd_value(s[r], p[r]);
-              emd_fold(st, mask, v, base + r * kWave + lane, n, tpu);
+          for (int g4 = 0; g4 < 4; ++g4) {
+            if (cmask) {
+              const int l = __builtin_ctzll(cmask);
+              cmask &= cmask - 1;
+              const int cl = __builtin_amdgcn_readlane(c, l);
+              cc = sub == g4 ? cl : cc;
             }
           }
+          int s = 0, s1 = 0;
+          if (cc >= 0) {
+            s = c_start[cc] + sl;
+            s1 = c_start[cc + 1];
+          }
+          while (__any(s < s1)) {
+            bool ps = false;
+            float sd = 0.f, pw = 0.f;
+            if (s < s1) {
+              const float4 o = sc.obj[s];
+              sd = sqdist3(o.x - qx, o.y - qy, o.z - qz);
+              pw = o.w;
+              const float tq = st.tm - pw;
+              ps = tq >= 0.f && sd <= tq * tq;
+            }
+            const unsigned long long m = __ballot(ps);
+            if (m) emd_fold(st, m, emd_value(sd, pw), s, n, tpu, sc.perm);
+            s += 16;
+          }
         }
+      }
+      if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
+        if (lane == 0) s_err = 1;
+        st.bk = 0;
+        st.b2k = -1;
       }
       if (lane == 0) {
         const float inc = st.b1 - st.b2 + eps;
         sc.bid[j] = st.bk;
         sc.bidinc[j] = inc;
+        sc.prev1[j] = st.bk;
+        sc.prev2[j] = st.b2k;
         atomic_max_float(&sc.maxinc[st.bk], inc);
       }
     }
     if (t == 0) s_cnt[cur ^ 1] = 0;
     __syncthreads();
+    MVP_STAGE(6);
 
     // ---------------- GetMax (emd_cuda.cu:181-194), deterministic
     const unsigned long long tag = (unsigned long long)(it + 1) << 32;
@@ -259,6 +515,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         atomicMax(&sc.maxidx[o], tag | (unsigned long long)(unsigned)j);
     }
     __syncthreads();
+    MVP_STAGE(7);
 
     // ---------------- Assign (emd_cuda.cu:196-215)
     for (int u = t; u < U; u += kEmdThreads) {
@@ -274,26 +531,36 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         ass[j] = o;
         sc.obj[o].w += sc.bidinc[j];
         sc.maxinc[o] = __float_as_int(-1e9f);
+        // refresh the cell's price lower bound (racing refreshes of the same
+        // cell may leave a slightly stale -- still valid -- bound)
+        const int c = sc.cellof[o];
+        float pm = __builtin_inff();
+        for (int s = c_start[c]; s < c_start[c + 1]; ++s)
+          pm = __builtin_fminf(pm, sc.obj[s].w);
+        c_pmin[c] = pm;
       } else {
         Lnext[atomicAdd(&s_cnt[cur ^ 1], 1)] = j;
       }
     }
     __syncthreads();
+    MVP_STAGE(8);
     cur ^= 1;
   }
 
   if (t == 0) {
-    stats[0] = n_rounds;
+    stats[0] = s_err ? -1 : n_rounds;
     stats[1] = n_bids;
   }
-  // ---------------- CalcDist (emd_cuda.cu:217-226)
+  // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
   __syncthreads();
   for (int j = t; j < n; j += kEmdThreads) {
-    const int k = ass[j];
-    const float dx = xyz1[j * 3 + 0] - xyz2[k * 3 + 0];
-    const float dy = xyz1[j * 3 + 1] - xyz2[k * 3 + 1];
-    const float dz = xyz1[j * 3 + 2] - xyz2[k * 3 + 2];
+    const int s = ass[j];
+    const float4 o = sc.obj[s];
+    const float dx = xyz1[j * 3 + 0] - o.x;
+    const float dy = xyz1[j * 3 + 1] - o.y;
+    const float dz = xyz1[j * 3 + 2] - o.z;
     dist[j] = sqdist3(dx, dy, dz);
+    ass[j] = sc.perm[s];
   }
 }
 
