@@ -162,7 +162,7 @@ int mvp_three_interpolate(int b, int c, int m, int n, const float *points,
 /* Replaces interpolate_ext.three_interpolate_grad_wrapper
  * (interpolate.cpp:72-85,91) -> three_interpolate_grad_kernel_launcher
  * (three_interpolate_cuda.cu:86-108).  grad_points (b,c,m) accumulated into;
- * zero on entry (three_interpolate.py:55). */
+ * zero on entry (three_interpolate.py:53). */
 int mvp_three_interpolate_grad(int b, int c, int n, int m,
                                const float *grad_out, const int *idx,
                                const float *weight, float *grad_points,
@@ -194,7 +194,7 @@ int mvp_group_points(int b, int c, int n, int npoints, int nsample,
 /* Replaces group_points_ext.backward (group_points.cpp:31-43,61) ->
  * group_points_grad_kernel_launcher (group_points_cuda.cu:33-54).
  * grad_points (b,c,n) accumulated into; zero on entry
- * (group_points.py:206). */
+ * (group_points.py:213). */
 int mvp_group_points_grad(int b, int c, int n, int npoints, int nsample,
                           const float *grad_out, const int *idx,
                           float *grad_points, void *stream);

@@ -50,6 +50,7 @@ constexpr int kEmdThreads = 1024;
 constexpr int kEmdWaves = kEmdThreads / kWave;
 constexpr int kMaxG = 12;
 constexpr int kMaxCells = kMaxG * kMaxG * kMaxG;  // 1728
+constexpr int kBidCache = 2048;
 
 // Filter slack.  An object is skipped only if
 //   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
@@ -62,40 +63,44 @@ constexpr int kMaxCells = kMaxG * kMaxG * kMaxG;  // 1728
 // is >= the cell's, so a skipped cell contains only skippable objects.
 constexpr float kMargin = 1e-5f;
 
+// Per-person record (32 B): everything a bid needs in one 2x16-byte fetch.
+struct __attribute__((aligned(16))) PersonRec {
+  float qx, qy, qz;  // the person's point (xyz1)
+  float bidinc;      // increment of its last bid
+  int bid;           // slot it last bid on
+  int prev1, prev2;  // best / second-best slot of its previous bid (seed hints)
+  int pad;
+};
+// Per-object auction state (16 B), next to the object's float4 {x,y,z,price}.
+struct __attribute__((aligned(16))) ObjState {
+  unsigned long long maxidx;  // (round+1)<<32 | winning bidder
+  int maxinc;                 // max bid increment this round, float bits
+  int ass_inv;                // owner (-1 = free)
+};
+
 struct EmdScratch {
-  float4 *obj;                 // (n) cell-sorted x, y, z, price of xyz2
-  unsigned long long *maxidx;  // (n) per slot: (round+1)<<32 | winner
-  int *perm;                   // (n) slot -> original object index
-  int *cellof;                 // (n) slot -> cell
-  int *bid;                    // (n) per person: slot last bid on
-  float *bidinc;               // (n) per person: its bid increment
-  int *maxinc;                 // (n) per slot: max increment, float bits
-  int *ass_inv;                // (n) slot -> owner
-  int *prev1, *prev2;          // (n) per person: best / second-best slot of
-                               //     its previous bid (seed hints only)
-  int *ulist;                  // (2n) ping-pong unassigned lists
+  float4 *obj;        // (n) cell-sorted x, y, z, price of xyz2
+  ObjState *ostate;   // (n) per slot
+  PersonRec *person;  // (n) per person
+  int *perm;          // (n) slot -> original object index
+  int *ulist;         // (2n) ping-pong unassigned lists
 };
 
 __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
-  return (size_t)n * 64;
+  return (size_t)n * 76;  // 16 + 16 + 32 + 4 + 8
 }
 
 __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
   EmdScratch s;
   s.obj = reinterpret_cast<float4 *>(base);
   base += (size_t)n * 16;
-  s.maxidx = reinterpret_cast<unsigned long long *>(base);
-  base += (size_t)n * 8;
-  int *ip = reinterpret_cast<int *>(base);
-  s.perm = ip;
-  s.cellof = ip + (size_t)n;
-  s.bid = ip + (size_t)2 * n;
-  s.bidinc = reinterpret_cast<float *>(ip + (size_t)3 * n);
-  s.maxinc = ip + (size_t)4 * n;
-  s.ass_inv = ip + (size_t)5 * n;
-  s.prev1 = ip + (size_t)6 * n;
-  s.prev2 = ip + (size_t)7 * n;
-  s.ulist = ip + (size_t)8 * n;
+  s.ostate = reinterpret_cast<ObjState *>(base);
+  base += (size_t)n * 16;
+  s.person = reinterpret_cast<PersonRec *>(base);
+  base += (size_t)n * 32;
+  s.perm = reinterpret_cast<int *>(base);
+  base += (size_t)n * 4;
+  s.ulist = reinterpret_cast<int *>(base);
   return s;
 }
 
@@ -209,10 +214,15 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ float c_pmin[kMaxCells];
   __shared__ int c_start[kMaxCells + 1];
   __shared__ int s_tmp[kMaxCells];  // counts / fill cursors during the build
+  __shared__ unsigned short w_list[kEmdWaves][kMaxCells];  // per-wave surviving cells
   __shared__ float s_red[6][kEmdWaves];
   __shared__ int s_wsum[kEmdWaves];
   __shared__ int s_cnt[2];
   __shared__ int s_err;
+  // this round's bids for the first kBidCache list positions (skips two
+  // dependent global round trips in GetMax / Assign)
+  __shared__ int s_bj[kBidCache], s_bo[kBidCache];
+  __shared__ float s_binc[kBidCache];
 
   // ------------------------------------------------------------ grid build
   // (a) bounding box of both clouds
@@ -304,13 +314,22 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     const int s = c_start[c] + atomicAdd(&s_tmp[c], 1);
     sc.obj[s] = make_float4(x, y, z, 0.f);
     sc.perm[s] = k;
-    sc.cellof[s] = c;
     ass[k] = -1;
-    sc.ass_inv[k] = -1;
-    sc.maxinc[k] = 0;  // 0.0f
-    sc.maxidx[k] = 0ull;
-    sc.prev1[k] = -1;
-    sc.prev2[k] = -1;
+    ObjState os;
+    os.maxidx = 0ull;
+    os.maxinc = 0;  // 0.0f
+    os.ass_inv = -1;
+    sc.ostate[k] = os;
+    PersonRec pr;
+    pr.qx = xyz1[k * 3 + 0];
+    pr.qy = xyz1[k * 3 + 1];
+    pr.qz = xyz1[k * 3 + 2];
+    pr.bidinc = 0.f;
+    pr.bid = -1;
+    pr.prev1 = -1;
+    pr.prev2 = -1;
+    pr.pad = 0;
+    sc.person[k] = pr;
     sc.ulist[k] = k;
   }
   if (t == 0) {
@@ -344,6 +363,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   const int block_cnt = n / 1024;
   int cur = 0;
   long long n_rounds = 0, n_bids = 0;
+#ifdef MVP_EMD_PROFILE
+  long long cyc_bid = 0, cyc_getmax = 0, cyc_assign = 0;
+  long long cb_seed = 0, cb_cells = 0, cb_visit = 0, cb_write = 0, cb_n = 0;
+#endif
   for (int it = 0; it < iters; ++it) {
     const int U = s_cnt[cur];
     if (U == 0) break;
@@ -357,10 +380,37 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     const int upb = (U + block_cnt - 1) / block_cnt;
     const int tpu = 1024 / upb;
 
+#ifdef MVP_EMD_PROFILE
+    const long long tp0 = __builtin_readcyclecounter();
+#endif
     // ---------------- Bid (emd_cuda.cu:95-179): one wave per bidder
+    // Software-pipelined over this wave's bidders: the list entry two
+    // bidders ahead and the person record one bidder ahead are in flight
+    // while the current bid is computed.
+    int j_cur = wave < U ? L[wave] : 0;
+    int j_nxt = wave + kEmdWaves < U ? L[wave + kEmdWaves] : 0;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 rb = make_int4(-1, -1, -1, 0);
+    if (wave < U) {
+      ra = *reinterpret_cast<const float4 *>(&sc.person[j_cur]);
+      rb = *(reinterpret_cast<const int4 *>(&sc.person[j_cur]) + 1);
+    }
     for (int u = wave; u < U; u += kEmdWaves) {
-      const int j = L[u];
-      const float qx = xyz1[j * 3 + 0], qy = xyz1[j * 3 + 1], qz = xyz1[j * 3 + 2];
+      const int j = j_cur;
+      const float qx = ra.x, qy = ra.y, qz = ra.z;
+      const int p1 = rb.y, p2 = rb.z;
+      {
+        const int un = u + kEmdWaves;
+        j_cur = j_nxt;
+        if (un < U) {
+          ra = *reinterpret_cast<const float4 *>(&sc.person[j_nxt]);
+          rb = *(reinterpret_cast<const int4 *>(&sc.person[j_nxt]) + 1);
+        }
+        j_nxt = un + kEmdWaves < U ? L[un + kEmdWaves] : 0;
+      }
+#ifdef MVP_EMD_PROFILE
+      const long long q0 = __builtin_readcyclecounter();
+#endif
       const int c0 = emd_cell(gg, qx, qy, qz);
 
       // (1) seed: second-largest exact value among DISTINCT real objects --
@@ -375,15 +425,15 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const float4 o = sc.obj[s];
           top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
         }
-        int have = s1 - s0;
-        const int p1 = sc.prev1[j], p2 = sc.prev2[j];
-        const bool use1 = p1 >= 0 && sc.cellof[p1] != c0;
-        const bool use2 = p2 >= 0 && sc.cellof[p2] != c0;
-        have += (use1 ? 1 : 0) + (use2 ? 1 : 0);
-        if ((lane == 0 && use1) || (lane == 1 && use2)) {
+        bool extra = false;
+        if ((lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0)) {
           const float4 o = sc.obj[lane == 0 ? p1 : p2];
-          top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
+          if (emd_cell(gg, o.x, o.y, o.z) != c0) {
+            extra = true;
+            top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
+          }
         }
+        const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
         if (have < 2) {  // wave-uniform; rare: fall back to the first 64 slots
           const float4 o = sc.obj[lane];
           a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
@@ -406,6 +456,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         st.tm = (3.0f - seed_b2) + kMargin;
       }
 
+#ifdef MVP_EMD_PROFILE
+      const long long q1 = __builtin_readcyclecounter();
+#endif
       // (2) Only cells that intersect the cube |o - q|_inf <= tm can hold a
       // relevant object (prices are >= 0).  Enumerate that sub-box of the
       // grid 64 cells at a time and test each cell's exact bounding box and
@@ -435,6 +488,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       const int nsub = nxy * nz;
       const float inv_nxy = 1.0f / (float)nxy, inv_nx = 1.0f / (float)nx;
       const int sub = lane >> 4, sl = lane & 15;
+      unsigned short *wl = w_list[wave];
+      int nlist = 0;
       for (int cb = 0; cb < nsub; cb += kWave) {
         const int i = cb + lane;
         bool cpass = false;
@@ -452,40 +507,65 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const float tq = st.tm - c_pmin[c];
           cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
         }
-        unsigned long long cmask = __ballot(cpass);
-        while (cmask) {
-          // up to 4 surviving cells -> one per 16-lane group
-          int cc = -1;
+        const unsigned long long cmask = __ballot(cpass);
+        if (cpass)
+          wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
+        nlist += __builtin_popcountll(cmask);
+      }
+#ifdef MVP_EMD_PROFILE
+      const long long q2 = __builtin_readcyclecounter();
+#endif
+      // (3) visit the surviving cells, 16 per step: each 16-lane group takes 4
+      // cells, so 4 independent 16-byte loads per lane are in flight at once
+      // (the auction is bound by dependent L2 round trips, not by issue).
+      for (int k0 = 0; k0 < nlist; k0 += 16) {
+        int s[4], s1[4];
+        float4 o[4];
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            if (cmask) {
-              const int l = __builtin_ctzll(cmask);
-              cmask &= cmask - 1;
-              const int cl = __builtin_amdgcn_readlane(c, l);
-              cc = sub == g4 ? cl : cc;
-            }
+        for (int r = 0; r < 4; ++r) {
+          const int k = k0 + r * 4 + sub;
+          s[r] = 0;
+          s1[r] = 0;
+          if (k < nlist) {
+            const int cc = wl[k];
+            s[r] = c_start[cc] + sl;
+            s1[r] = c_start[cc + 1];
           }
-          int s = 0, s1 = 0;
-          if (cc >= 0) {
-            s = c_start[cc] + sl;
-            s1 = c_start[cc + 1];
-          }
-          while (__any(s < s1)) {
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o[r] = s[r] < s1[r] ? sc.obj[s[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
+          const float tq = st.tm - o[r].w;
+          const bool ps = s[r] < s1[r] && tq >= 0.f && sd <= tq * tq;
+          const unsigned long long m = __ballot(ps);
+          if (m) emd_fold(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm);
+        }
+        // cells with more than 16 members
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int sr = s[r] + 16;
+          while (__any(sr < s1[r])) {
             bool ps = false;
             float sd = 0.f, pw = 0.f;
-            if (s < s1) {
-              const float4 o = sc.obj[s];
-              sd = sqdist3(o.x - qx, o.y - qy, o.z - qz);
-              pw = o.w;
+            if (sr < s1[r]) {
+              const float4 oo = sc.obj[sr];
+              sd = sqdist3(oo.x - qx, oo.y - qy, oo.z - qz);
+              pw = oo.w;
               const float tq = st.tm - pw;
               ps = tq >= 0.f && sd <= tq * tq;
             }
             const unsigned long long m = __ballot(ps);
-            if (m) emd_fold(st, m, emd_value(sd, pw), s, n, tpu, sc.perm);
-            s += 16;
+            if (m) emd_fold(st, m, emd_value(sd, pw), sr, n, tpu, sc.perm);
+            sr += 16;
           }
         }
       }
+#ifdef MVP_EMD_PROFILE
+      const long long q3 = __builtin_readcyclecounter();
+#endif
       if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
         if (lane == 0) s_err = 1;
         st.bk = 0;
@@ -493,50 +573,75 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       }
       if (lane == 0) {
         const float inc = st.b1 - st.b2 + eps;
-        sc.bid[j] = st.bk;
-        sc.bidinc[j] = inc;
-        sc.prev1[j] = st.bk;
-        sc.prev2[j] = st.b2k;
-        atomic_max_float(&sc.maxinc[st.bk], inc);
+        sc.person[j].bidinc = inc;
+        *(reinterpret_cast<int4 *>(&sc.person[j]) + 1) = make_int4(st.bk, st.bk, st.b2k, 0);
+        if (u < kBidCache) {
+          s_bj[u] = j;
+          s_bo[u] = st.bk;
+          s_binc[u] = inc;
+        }
+        atomic_max_float(&sc.ostate[st.bk].maxinc, inc);
       }
+#ifdef MVP_EMD_PROFILE
+      { const long long q4 = __builtin_readcyclecounter(); cb_seed += q1 - q0; cb_cells += q2 - q1; cb_visit += q3 - q2; cb_write += q4 - q3; cb_n += 1; }
+#endif
     }
     if (t == 0) s_cnt[cur ^ 1] = 0;
     __syncthreads();
     MVP_STAGE(6);
+#ifdef MVP_EMD_PROFILE
+    const long long tp1 = __builtin_readcyclecounter();
+#endif
 
     // ---------------- GetMax (emd_cuda.cu:181-194), deterministic
     const unsigned long long tag = (unsigned long long)(it + 1) << 32;
     for (int u = t; u < U; u += kEmdThreads) {
-      const int j = L[u];
-      const int o = sc.bid[j];
-      const float bi = sc.bidinc[j];
-      const float mi = __int_as_float(sc.maxinc[o]);
+      int j, o;
+      float bi;
+      if (u < kBidCache) {
+        j = s_bj[u]; o = s_bo[u]; bi = s_binc[u];
+      } else {
+        j = L[u]; o = sc.person[j].bid; bi = sc.person[j].bidinc;
+      }
+      const float mi = __int_as_float(sc.ostate[o].maxinc);
       if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
-        atomicMax(&sc.maxidx[o], tag | (unsigned long long)(unsigned)j);
+        atomicMax(&sc.ostate[o].maxidx, tag | (unsigned long long)(unsigned)j);
     }
     __syncthreads();
     MVP_STAGE(7);
+#ifdef MVP_EMD_PROFILE
+    const long long tp2 = __builtin_readcyclecounter();
+#endif
 
     // ---------------- Assign (emd_cuda.cu:196-215)
     for (int u = t; u < U; u += kEmdThreads) {
-      const int j = L[u];
-      const int o = sc.bid[j];
-      if (last || sc.maxidx[o] == (tag | (unsigned long long)(unsigned)j)) {
-        const int prev = sc.ass_inv[o];
+      int j, o;
+      float bi;
+      if (u < kBidCache) {
+        j = s_bj[u]; o = s_bo[u]; bi = s_binc[u];
+      } else {
+        j = L[u]; o = sc.person[j].bid; bi = sc.person[j].bidinc;
+      }
+      const ObjState os = sc.ostate[o];
+      if (last || os.maxidx == (tag | (unsigned long long)(unsigned)j)) {
+        const int prev = os.ass_inv;
         if (!last && prev != -1) {
           ass[prev] = -1;
           Lnext[atomicAdd(&s_cnt[cur ^ 1], 1)] = prev;
         }
-        sc.ass_inv[o] = j;
+        sc.ostate[o].ass_inv = j;
+        sc.ostate[o].maxinc = __float_as_int(-1e9f);
         ass[j] = o;
-        sc.obj[o].w += sc.bidinc[j];
-        sc.maxinc[o] = __float_as_int(-1e9f);
+        const float4 oo = sc.obj[o];
+        sc.obj[o].w = oo.w + bi;
         // refresh the cell's price lower bound (racing refreshes of the same
         // cell may leave a slightly stale -- still valid -- bound)
-        const int c = sc.cellof[o];
-        float pm = __builtin_inff();
-        for (int s = c_start[c]; s < c_start[c + 1]; ++s)
-          pm = __builtin_fminf(pm, sc.obj[s].w);
+        const int c = emd_cell(gg, oo.x, oo.y, oo.z);
+        float pm = oo.w + bi;
+        const int e1 = c_start[c + 1];
+#pragma unroll 8
+        for (int s = c_start[c]; s < e1; ++s)
+          pm = __builtin_fminf(pm, s == o ? pm : sc.obj[s].w);
         c_pmin[c] = pm;
       } else {
         Lnext[atomicAdd(&s_cnt[cur ^ 1], 1)] = j;
@@ -544,12 +649,21 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     }
     __syncthreads();
     MVP_STAGE(8);
+#ifdef MVP_EMD_PROFILE
+    const long long tp3 = __builtin_readcyclecounter();
+    cyc_bid += tp1 - tp0; cyc_getmax += tp2 - tp1; cyc_assign += tp3 - tp2;
+#endif
     cur ^= 1;
   }
 
   if (t == 0) {
     stats[0] = s_err ? -1 : n_rounds;
     stats[1] = n_bids;
+#ifdef MVP_EMD_PROFILE
+    stats[0] = cyc_bid;
+    stats[1] = (cyc_getmax << 32) | (cyc_assign & 0xffffffffll);
+    if (cloud == 0) printf("wave0 bids %lld: seed %lld cells %lld visit %lld write %lld cycles/bid\n", cb_n, cb_seed / (cb_n ? cb_n : 1), cb_cells / (cb_n ? cb_n : 1), cb_visit / (cb_n ? cb_n : 1), cb_write / (cb_n ? cb_n : 1));
+#endif
   }
   // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
   __syncthreads();
