@@ -1,0 +1,274 @@
+"""Glue between the completion models and the MI355X op layer -- counterpart of
+the reference's completion/model_utils.py (same function names, arguments and
+return values; every function cites the reference lines it mirrors).
+
+The operator imports are the reference's own (`model_utils.py:19-21`):
+    sys.path.append("../utils"); from metrics import ...; from mm3d_pn2 import ...
+resolved here against this repo's `utils/` shims, i.e. the HIP kernels of
+libmvpops.so.  Nothing in this file falls back to a CPU implementation of an
+operator; the pure-PyTorch helpers (`knn`, `knn_point`, ...) are pure PyTorch in
+the reference too.
+"""
+import math
+import os
+import sys
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_UTILS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "utils")
+if _UTILS not in sys.path:
+    sys.path.append(_UTILS)
+from metrics import cd, fscore, emd  # noqa: E402
+from mm3d_pn2 import (furthest_point_sample, gather_points, grouping_operation,  # noqa: E402
+                      ball_query, three_nn)
+
+
+# --------------------------------------------------------------------------
+# metrics (model_utils.py:67-85)
+# --------------------------------------------------------------------------
+def calc_cd(output, gt, calc_f1=False):
+    """Chamfer metrics of a prediction (B,M,3) against gt (B,N,3).
+
+    Mirrors model_utils.py:67-77: the operator is called as cd()(gt, output)
+    (gt is xyz1); cd_p = (mean sqrt d1 + mean sqrt d2) / 2, cd_t = mean d1 +
+    mean d2; with calc_f1 also the F-score at the default 1e-4 threshold.
+    """
+    dist1, dist2, _, _ = cd()(gt, output)
+    cd_p = (dist1.sqrt().mean(1) + dist2.sqrt().mean(1)) / 2
+    cd_t = dist1.mean(1) + dist2.mean(1)
+    if not calc_f1:
+        return cd_p, cd_t
+    f1, _, _ = fscore(dist1, dist2)
+    return cd_p, cd_t, f1
+
+
+def calc_emd(output, gt, eps=0.005, iterations=50):
+    """Auction EMD of a prediction against gt: mean over points of the matched
+    L2 distance (model_utils.py:80-85; output is xyz1 = the differentiable
+    side)."""
+    dist, _ = emd()(output, gt, eps, iterations)
+    return dist.sqrt().mean(1)
+
+
+# --------------------------------------------------------------------------
+# pure-PyTorch neighbourhood helpers (model_utils.py:242-272, 230-239)
+# --------------------------------------------------------------------------
+def knn(x, k):
+    """x (B,C,N) -> idx (B,N,k) of the k nearest points (self included), by
+    top-k of the negative squared distance (model_utils.py:242-247)."""
+    sq = (x * x).sum(dim=1, keepdim=True)                       # (B,1,N)
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)             # (B,N,N)
+    neg_dist = -sq - inner - sq.transpose(2, 1)                 # -|xi|^2 + 2 xi.xj - |xj|^2
+    return neg_dist.topk(k=k, dim=-1)[1]
+
+
+def knn_point(pk, point_input, point_output):
+    """Top-pk neighbours of every point_output (B,M,C) among point_input
+    (B,N,C): returns (negative squared distance (B,M,pk), idx (B,M,pk))
+    (model_utils.py:250-259)."""
+    inner = -2 * torch.matmul(point_output, point_input.transpose(2, 1))  # (B,M,N)
+    out_sq = (point_output * point_output).sum(dim=2, keepdim=True)        # (B,M,1)
+    in_sq = (point_input * point_input).sum(dim=2).unsqueeze(1)            # (B,1,N)
+    pairwise = -out_sq - inner - in_sq
+    return pairwise.topk(k=pk, dim=-1)
+
+
+def knn_point_all(pk, point_input, point_output):
+    """Alias kept for API parity (model_utils.py:262-272)."""
+    return knn_point(pk, point_input, point_output)
+
+
+def index_points(points, idx):
+    """points (B,N,C), idx (B,...) -> points gathered along N
+    (model_utils.py:230-239)."""
+    b = points.shape[0]
+    batch = torch.arange(b, device=points.device).view([b] + [1] * (idx.dim() - 1)).expand_as(idx)
+    return points[batch, idx, :]
+
+
+def get_edge_features(x, idx):
+    """x (B,C,1,N) or (B,C,N), idx (B,N,k) -> neighbour features (B,C,k,N)
+    (model_utils.py:113-124)."""
+    batch_size, num_points, k = idx.size()
+    if x.dim() == 4:
+        x = x.squeeze(2)
+    num_dims = x.size(1)
+    flat = x.transpose(2, 1).reshape(batch_size * num_points, num_dims)
+    base = torch.arange(batch_size, device=x.device).view(-1, 1, 1) * num_points
+    feature = flat[(idx + base).reshape(-1)]
+    return feature.view(batch_size, num_points, k, num_dims).permute(0, 3, 2, 1)
+
+
+def get_graph_feature(x, k=20, minus_center=True):
+    """DGCNN edge features of x (B,C,N): (B,2C,N,k) = [centre, neighbour -
+    centre] (or [centre, neighbour]) (model_utils.py:156-178)."""
+    idx = knn(x, k=k)
+    batch_size, num_points, _ = idx.size()
+    num_dims = x.size(1)
+    pts = x.transpose(2, 1).contiguous()                                   # (B,N,C)
+    base = torch.arange(batch_size, device=x.device).view(-1, 1, 1) * num_points
+    nbr = pts.view(batch_size * num_points, num_dims)[(idx + base).view(-1)]
+    nbr = nbr.view(batch_size, num_points, k, num_dims)
+    ctr = pts.view(batch_size, num_points, 1, num_dims).expand(-1, -1, k, -1)
+    second = nbr - ctr if minus_center else nbr
+    return torch.cat((ctr, second), dim=3).permute(0, 3, 1, 2)
+
+
+# --------------------------------------------------------------------------
+# samplers / interpolation built on the op layer
+# --------------------------------------------------------------------------
+def edge_preserve_sampling(feature_input, point_input, num_samples, k=10):
+    """FPS down-sampling that keeps, for every sampled centre, the channel-wise
+    max over its k nearest neighbours next to its own feature
+    (model_utils.py:88-110).
+
+    feature_input (B,C,N), point_input (B,N,3) ->
+      net (B,2C,S), p_idx (B,S) int32, pn_idx (B,S,k) int32, point_output (B,S,3)
+    Op calls: furthest_point_sample, gather_points x2, grouping_operation (S=1).
+    """
+    batch_size, feature_size, num_points = feature_input.size()
+
+    p_idx = furthest_point_sample(point_input, num_samples)
+    point_output = gather_points(point_input.transpose(1, 2).contiguous(), p_idx) \
+        .transpose(1, 2).contiguous()
+
+    pk = int(min(k, num_points))
+    _, pn_idx = knn_point(pk, point_input, point_output)
+    pn_idx = pn_idx.detach().int()
+    neighbor_feature = gather_points(feature_input, pn_idx.view(batch_size, num_samples * pk))
+    neighbor_feature = neighbor_feature.view(batch_size, feature_size, num_samples, pk).max(dim=3)[0]
+
+    center_feature = grouping_operation(feature_input, p_idx.unsqueeze(2)) \
+        .view(batch_size, -1, num_samples)
+
+    net = torch.cat((center_feature, neighbor_feature), 1)
+    return net, p_idx, pn_idx, point_output
+
+
+def three_nn_upsampling(target_points, source_points):
+    """Inverse-distance weights of the 3 nearest source points of every target
+    point (model_utils.py:286-293) -> idx (B,N,3) int32, weight (B,N,3)."""
+    dist, idx = three_nn(target_points, source_points)
+    dist = torch.clamp(dist, min=1e-10)
+    inv = 1.0 / dist
+    weight = inv / inv.sum(2, keepdim=True)
+    return idx, weight
+
+
+def symmetric_sample(points, num=512):
+    """FPS-sample `num` points and append their mirror image z -> -z
+    (model_utils.py:275-283) -> (B, 2*num, 3)."""
+    p1_idx = furthest_point_sample(points, num)
+    input_fps = gather_points(points.transpose(1, 2).contiguous(), p1_idx) \
+        .transpose(1, 2).contiguous()
+    flipped = input_fps * input_fps.new_tensor([1.0, 1.0, -1.0])
+    return torch.cat([input_fps, flipped], dim=1)
+
+
+def get_repulsion_loss(pred, nsample=20, radius=0.07):
+    """PU-Net repulsion loss on pred (B,N,3) (model_utils.py:181-198)."""
+    idx = knn(pred.transpose(1, 2).contiguous(), nsample).int()
+    pred_flipped = pred.transpose(1, 2).contiguous()
+    grouped_pred = grouping_operation(pred_flipped, idx.contiguous())     # (B,3,N,nsample)
+    grouped_pred = grouped_pred - pred_flipped.unsqueeze(-1)
+
+    h = 0.03
+    dist_square = (grouped_pred ** 2).sum(dim=1)
+    dist_square, _ = torch.topk(-dist_square, 5)
+    dist_square = -dist_square[:, :, 1:]                                  # drop the point itself
+    dist_square = torch.clamp(dist_square, min=1e-12)
+    dist = dist_square.sqrt()
+    weight = torch.exp(-dist_square / h ** 2)
+    return torch.mean(radius - dist * weight)
+
+
+def get_uniform_loss(pcd, percentages=[0.004, 0.006, 0.008, 0.010, 0.012], radius=1.0):
+    """PU-GAN uniform loss on pcd (B,N,3) (model_utils.py:201-227): for each
+    percentage p: FPS N -> 0.05N seeds, ball_query(0, sqrt(p*radius), p*N),
+    group, nearest-neighbour spacing inside each ball vs the expected spacing."""
+    B, N, _ = pcd.size()
+    npoint = int(N * 0.05)
+    pcd_t = pcd.transpose(1, 2).contiguous()
+    loss = 0
+    for p in percentages:
+        nsample = int(N * p)
+        r = math.sqrt(p * radius)
+        disk_area = math.pi * (radius ** 2) * p / nsample
+        new_xyz = gather_points(pcd_t, furthest_point_sample(pcd, npoint)).transpose(1, 2).contiguous()
+        idx = ball_query(0, r, nsample, pcd, new_xyz)
+        expect_len = math.sqrt(disk_area)
+
+        grouped_pcd = grouping_operation(pcd_t, idx)
+        grouped_pcd = grouped_pcd.permute(0, 2, 3, 1).contiguous().view(-1, nsample, 3)
+
+        var, _ = knn_point(2, grouped_pcd, grouped_pcd)
+        uniform_dis = -var[:, :, 1:]
+        uniform_dis = torch.sqrt(torch.abs(uniform_dis + 1e-8)).mean(dim=-1)
+        uniform_dis = (uniform_dis - expect_len) ** 2 / (expect_len + 1e-8)
+        loss = loss + uniform_dis.mean() * math.pow(p * 100, 2)
+    return loss / len(percentages)
+
+
+# --------------------------------------------------------------------------
+# folding grids (model_utils.py:125-153)
+# --------------------------------------------------------------------------
+def gen_grid(num_grid_point):
+    """(2, num_grid_point^2) square grid in [-0.05, 0.05]^2."""
+    x = torch.linspace(-0.05, 0.05, steps=num_grid_point)
+    gx, gy = torch.meshgrid(x, x, indexing="ij")
+    return torch.stack([gx, gy], dim=-1).view(2, num_grid_point ** 2)
+
+
+def gen_1d_grid(num_grid_point):
+    return torch.linspace(-0.05, 0.05, num_grid_point).view(1, num_grid_point)
+
+
+def gen_grid_up(up_ratio, grid_size=0.2):
+    """(2, up_ratio) folding grid: the most square num_x x num_y factorisation
+    of up_ratio over [-grid_size, grid_size]^2."""
+    num_x = next(i for i in range(int(math.sqrt(up_ratio)) + 1, 0, -1) if up_ratio % i == 0)
+    num_y = up_ratio // num_x
+    grid_x = torch.linspace(-grid_size, grid_size, steps=num_x)
+    grid_y = torch.linspace(-grid_size, grid_size, steps=num_y)
+    gx, gy = torch.meshgrid(grid_x, grid_y, indexing="ij")
+    return torch.stack([gx, gy], dim=-1).view(-1, 2).transpose(0, 1).contiguous()
+
+
+# --------------------------------------------------------------------------
+# small nn blocks shared by the models (model_utils.py:26-64)
+# --------------------------------------------------------------------------
+def attention(query, key, value, mask=None):
+    """Scaled dot-product attention -> (output, attention map)."""
+    scores = torch.matmul(query, key.transpose(-2, -1)) / math.sqrt(query.size(-1))
+    if mask is not None:
+        scores = scores.masked_fill(mask == 0, -1e9)
+    p_attn = F.softmax(scores, dim=-1)
+    return torch.matmul(p_attn, value), p_attn
+
+
+class EF_expansion(nn.Module):
+    """Edge-feature expansion block (model_utils.py:26-55): kNN edge features ->
+    1x1 convs -> reshape to step_ratio x points -> max over k."""
+
+    def __init__(self, input_size, output_size=64, step_ratio=2, k=4):
+        super(EF_expansion, self).__init__()
+        self.step_ratio = step_ratio
+        self.k = k
+        self.input_size = input_size
+        self.output_size = output_size
+
+        self.conv1 = nn.Conv2d(input_size * 2, output_size, 1)
+        self.conv2 = nn.Conv2d(input_size * 2 + output_size, output_size * step_ratio, 1)
+        self.conv3 = nn.Conv2d(output_size, output_size, 1)
+
+    def forward(self, x):
+        batch_size, _, num_points = x.size()
+        edge_in = get_graph_feature(x, self.k, minus_center=False).permute(0, 1, 3, 2).contiguous()  # B C K N
+        edge = F.relu(torch.cat((self.conv1(edge_in), edge_in), 1))
+        edge = F.relu(self.conv2(edge))                                                            # B C K N
+        edge = edge.permute(0, 2, 3, 1).contiguous() \
+            .view(batch_size, self.k, num_points * self.step_ratio, self.output_size) \
+            .permute(0, 3, 1, 2)
+        return self.conv3(edge).max(dim=2)[0]

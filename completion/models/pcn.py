@@ -1,0 +1,106 @@
+"""PCN (Point Completion Network) -- counterpart of the reference's
+completion/models/pcn.py (PCN_encoder :13-31, PCN_decoder :34-72, Model
+:75-112).  Same sub-module / parameter names (so reference checkpoints load
+into it), same forward(x, gt, prefix, mean_feature, alpha) contract:
+  prefix="train" -> (fine, loss_fine (B,), total scalar loss)
+  prefix="val"   -> {'out1','out2','emd','cd_p','cd_t','f1'}
+  otherwise      -> {'result': fine}
+The layers are plain PyTorch (rocBLAS/MIOpen under PyTorch-ROCm); the losses
+and metrics call the MI355X op layer through model_utils.calc_cd / calc_emd.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from model_utils import gen_grid_up, calc_emd, calc_cd
+
+
+class PCN_encoder(nn.Module):
+    """Two stacked PointNet stages: per-point MLP -> global max -> concat ->
+    per-point MLP -> global max."""
+
+    def __init__(self, output_size=1024):
+        super(PCN_encoder, self).__init__()
+        self.conv1 = nn.Conv1d(3, 128, 1)
+        self.conv2 = nn.Conv1d(128, 256, 1)
+        self.conv3 = nn.Conv1d(512, 512, 1)
+        self.conv4 = nn.Conv1d(512, output_size, 1)
+
+    def forward(self, x):
+        num_points = x.size(2)
+        local = self.conv2(F.relu(self.conv1(x)))
+        pooled = local.max(dim=2, keepdim=True)[0]
+        local = torch.cat((local, pooled.expand(-1, -1, num_points)), 1)
+        return self.conv4(F.relu(self.conv3(local))).max(dim=2)[0]
+
+
+class PCN_decoder(nn.Module):
+    """Coarse cloud from an MLP, then a folding stage that lifts a small 2-D
+    grid around every coarse point."""
+
+    def __init__(self, num_coarse, num_fine, scale, cat_feature_num):
+        super(PCN_decoder, self).__init__()
+        self.num_coarse = num_coarse
+        self.num_fine = num_fine
+        self.scale = scale
+        self.fc1 = nn.Linear(1024, 1024)
+        self.fc2 = nn.Linear(1024, 1024)
+        self.fc3 = nn.Linear(1024, num_coarse * 3)
+        # (2, scale) folding grid; not part of the checkpoint (the reference
+        # keeps it as a plain attribute)
+        self.register_buffer("grid", gen_grid_up(2 ** (int(math.log2(scale))), 0.05).contiguous(),
+                             persistent=False)
+        self.conv1 = nn.Conv1d(cat_feature_num, 512, 1)
+        self.conv2 = nn.Conv1d(512, 512, 1)
+        self.conv3 = nn.Conv1d(512, 3, 1)
+
+    def forward(self, x):
+        batch_size = x.size(0)
+        coarse = self.fc3(F.relu(self.fc2(F.relu(self.fc1(x))))).view(-1, 3, self.num_coarse)
+
+        # every coarse point repeated `scale` times: (B, 3, num_fine)
+        center = coarse.unsqueeze(3).expand(-1, -1, -1, self.scale).reshape(batch_size, 3, self.num_fine)
+        grid_feat = self.grid.detach().unsqueeze(0).repeat(batch_size, 1, self.num_coarse)
+        global_feat = x.unsqueeze(2).expand(-1, -1, self.num_fine)
+
+        feat = torch.cat((grid_feat, center, global_feat), 1)
+        fine = self.conv3(F.relu(self.conv2(F.relu(self.conv1(feat))))) + center
+        return coarse, fine
+
+
+class Model(nn.Module):
+    def __init__(self, args, num_coarse=1024):
+        super(Model, self).__init__()
+        self.num_coarse = num_coarse
+        self.num_points = args.num_points
+        self.train_loss = args.loss
+        self.eval_emd = args.eval_emd
+        self.scale = self.num_points // num_coarse
+        self.cat_feature_num = 2 + 3 + 1024
+
+        self.encoder = PCN_encoder()
+        self.decoder = PCN_decoder(num_coarse, self.num_points, self.scale, self.cat_feature_num)
+
+    def forward(self, x, gt=None, prefix="train", mean_feature=None, alpha=None):
+        out1, out2 = self.decoder(self.encoder(x))
+        out1 = out1.transpose(1, 2).contiguous()
+        out2 = out2.transpose(1, 2).contiguous()
+
+        if prefix == "train":
+            if self.train_loss == 'emd':
+                loss1 = calc_emd(out1, gt)
+                loss2 = calc_emd(out2, gt)
+            elif self.train_loss == 'cd':
+                loss1, _ = calc_cd(out1, gt)
+                loss2, _ = calc_cd(out2, gt)
+            else:
+                raise NotImplementedError('Train loss is either CD or EMD!')
+            total_train_loss = loss1.mean() + loss2.mean() * alpha
+            return out2, loss2, total_train_loss
+        if prefix == "val":
+            emd = calc_emd(out2, gt, eps=0.004, iterations=3000) if self.eval_emd else 0
+            cd_p, cd_t, f1 = calc_cd(out2, gt, calc_f1=True)
+            return {'out1': out1, 'out2': out2, 'emd': emd, 'cd_p': cd_p, 'cd_t': cd_t, 'f1': f1}
+        return {'result': out2}

@@ -1,0 +1,247 @@
+"""Completion training / validation entry point -- counterpart of the
+reference's completion/train.py (`python train.py -c cfgs/<model>.yaml`, run
+from completion/; same cfg keys, metric names, checkpoint layout, LR / alpha
+schedules).
+
+What changed, MI355X-first: the reference wraps the model in single-process
+`torch.nn.DataParallel` (train.py:49) and back-propagates a per-replica loss
+vector (`net_loss.backward(ones(ngpu))`, :141).  Here every GPU is its own
+process (`python -m torch.distributed.run --nproc-per-node N train.py -c ...`):
+the batch dimension is sharded across ranks, the model is wrapped in
+DistributedDataParallel (bucketed gradient all-reduce over RCCL/xGMI overlapped
+with backward), each rank back-propagates its scalar loss, and the validation
+meters are combined with one small sum all-reduce.  `batch_size` in the cfg
+stays the GLOBAL batch (the reference's DataParallel also splits it across
+GPUs); each rank takes batch_size / world samples per step.
+"""
+import argparse
+import datetime
+import importlib
+import logging
+import math
+import os
+import random
+import sys
+import warnings
+
+import torch
+import torch.optim as optim
+import yaml
+
+from dataset import build_dataset
+from train_utils import (AttrDict, AverageValueMeter, get_rank, get_world_size, init_distributed,
+                         load_model, save_model, shard_indices, unwrap)
+
+warnings.filterwarnings("ignore")
+
+
+def _floats(text):
+    return [float(v.strip()) for v in str(text).split(',')]
+
+
+def _ints(text):
+    return [int(v.strip()) for v in str(text).split(',')]
+
+
+def alpha_for_epoch(args, epoch):
+    """varying_constant schedule (train.py:101-108)."""
+    if not args.varying_constant:
+        return None
+    epochs, values = _ints(args.varying_constant_epochs), _floats(args.varying_constant)
+    assert len(values) == len(epochs) + 1
+    for ind, ep in enumerate(epochs):
+        if epoch < ep:
+            return values[ind]
+    return values[-1]
+
+
+def lr_for_epoch(args, epoch, lr):
+    """Manual LR decay (train.py:110-120); returns the LR to use in `epoch`."""
+    if not args.lr_decay:
+        return lr
+    if args.lr_decay_interval and args.lr_step_decay_epochs:
+        raise ValueError('lr_decay_interval and lr_step_decay_epochs are mutually exclusive!')
+    if args.lr_decay_interval:
+        if epoch > 0 and epoch % args.lr_decay_interval == 0:
+            lr = lr * args.lr_decay_rate
+    elif args.lr_step_decay_epochs:
+        decay_epochs, decay_rates = _ints(args.lr_step_decay_epochs), _floats(args.lr_step_decay_rates)
+        if epoch in decay_epochs:
+            lr = lr * decay_rates[decay_epochs.index(epoch)]
+    if args.lr_clip:
+        lr = max(lr, args.lr_clip)
+    return lr
+
+
+def make_loader(dataset, args, rank, world, shuffle, epoch=0, seed=0):
+    """This rank's shard of the dataset, batch_size/world samples per step.
+    Returns (loader, valid flags per sample of the shard)."""
+    indices, valid = shard_indices(len(dataset), rank, world, shuffle=shuffle, seed=seed, epoch=epoch)
+    per_rank = max(1, int(args.batch_size) // world)
+    subset = torch.utils.data.Subset(dataset, indices)
+    loader = torch.utils.data.DataLoader(subset, batch_size=per_rank, shuffle=False,
+                                         num_workers=int(args.workers or 0))
+    return loader, valid
+
+
+def build_model(args, device, world):
+    model_module = importlib.import_module('.%s' % args.model_name, 'models')
+    net = model_module.Model(args).to(device)
+    if hasattr(model_module, 'weights_init'):
+        net.apply(model_module.weights_init)
+    if world > 1:
+        ids = [device.index] if device.type == "cuda" else None
+        net = torch.nn.parallel.DistributedDataParallel(net, device_ids=ids)
+    return net
+
+
+def train_one_epoch(net, optimizer, loader, device, alpha, meter, log_fn=None):
+    unwrap(net).train()
+    for i, data in enumerate(loader):
+        optimizer.zero_grad()
+        _, inputs, gt = data
+        inputs = inputs.float().to(device).transpose(2, 1).contiguous()
+        gt = gt.float().to(device)
+        out2, loss2, net_loss = net(inputs, gt, alpha=alpha)
+        net_loss = net_loss.mean()
+        net_loss.backward()          # DDP all-reduces (averages) the gradients
+        optimizer.step()
+        meter.update(net_loss.item())
+        if log_fn:
+            log_fn(i, loss2.mean().item(), net_loss.item())
+
+
+def val(net, curr_epoch_num, val_loss_meters, loader, valid, best_epoch_losses, device, log_dir=None):
+    """Validation pass (train.py:156-192): per-batch means weighted by batch
+    size, summed over ranks; best-so-far checkpoints per metric."""
+    logging.info('Testing...')
+    for v in val_loss_meters.values():
+        v.reset()
+    unwrap(net).eval()
+    model = unwrap(net)      # no gradient sync needed in eval
+    seen = 0
+    with torch.no_grad():
+        for data in loader:
+            label, inputs, gt = data
+            curr = gt.shape[0]
+            keep = torch.tensor(valid[seen:seen + curr], dtype=torch.bool)
+            seen += curr
+            inputs = inputs.float().to(device).transpose(2, 1).contiguous()
+            gt = gt.float().to(device)
+            result_dict = model(inputs, gt, prefix="val")
+            n_keep = int(keep.sum())
+            if n_keep == 0:
+                continue
+            for k, v in val_loss_meters.items():
+                r = result_dict[k]
+                r = r[keep.to(r.device)] if torch.is_tensor(r) and r.dim() > 0 else r
+                v.update(float(r.mean()) if torch.is_tensor(r) else float(r), n_keep)
+    for v in val_loss_meters.values():
+        v.all_reduce(device)
+
+    fmt = 'best_%s: %f [epoch %d]; '
+    best_log = ''
+    for loss_type, (curr_best_epoch, curr_best_loss) in best_epoch_losses.items():
+        avg = val_loss_meters[loss_type].avg
+        better = avg > curr_best_loss if loss_type == 'f1' else avg < curr_best_loss
+        if better:
+            best_epoch_losses[loss_type] = (curr_epoch_num, avg)
+            if log_dir:
+                save_model('%s/best_%s_network.pth' % (log_dir, loss_type), net)
+            logging.info('Best %s net saved!' % loss_type)
+            best_log += fmt % (loss_type, avg, curr_epoch_num)
+        else:
+            best_log += fmt % (loss_type, curr_best_loss, curr_best_epoch)
+    curr_log = ''.join('curr_%s: %f; ' % (k, m.avg) for k, m in val_loss_meters.items())
+    logging.info(curr_log)
+    logging.info(best_log)
+    return {k: m.avg for k, m in val_loss_meters.items()}
+
+
+def train(args, log_dir, exp_name):
+    rank, world, device = init_distributed()
+    logging.info(str(args))
+    metrics = ['cd_p', 'cd_t', 'emd', 'f1'] if args.eval_emd else ['cd_p', 'cd_t', 'f1']
+    best_epoch_losses = {m: (0, 0) if m == 'f1' else (0, math.inf) for m in metrics}
+    train_loss_meter = AverageValueMeter()
+    val_loss_meters = {m: AverageValueMeter() for m in metrics}
+
+    dataset = build_dataset(args, "train")
+    dataset_test = build_dataset(args, "val")
+    logging.info('Length of train dataset:%d', len(dataset))
+    logging.info('Length of test dataset:%d', len(dataset_test))
+
+    seed = int(args.manual_seed) if args.manual_seed else random.randint(1, 10000)
+    logging.info('Random Seed: %d' % seed)
+    random.seed(seed)
+    torch.manual_seed(seed)               # identical initial weights on every rank
+    net = build_model(args, device, world)
+    torch.manual_seed(seed + 1000 * (rank + 1))   # per-rank streams for dropout / rsample
+
+    lr = args.lr
+    opt_cls = getattr(optim, args.optimizer)
+    params = unwrap(net).parameters()
+    if args.optimizer == 'Adagrad':
+        optimizer = opt_cls(params, lr=lr, initial_accumulator_value=args.initial_accum_val)
+    else:
+        betas = tuple(_floats(args.betas))
+        optimizer = opt_cls(params, lr=lr, weight_decay=args.weight_decay, betas=betas)
+
+    if args.load_model:
+        load_model(args.load_model, net, map_location=device)
+        logging.info("%s's previous weights loaded." % args.model_name)
+
+    loader_test, valid_test = make_loader(dataset_test, args, rank, world, shuffle=False)
+    last = None
+    for epoch in range(args.start_epoch, args.nepoch):
+        train_loss_meter.reset()
+        alpha = alpha_for_epoch(args, epoch)
+        lr = lr_for_epoch(args, epoch, lr)
+        for group in optimizer.param_groups:
+            group['lr'] = lr
+        loader, _ = make_loader(dataset, args, rank, world, shuffle=True, epoch=epoch, seed=seed)
+
+        def log_fn(i, fine, total, _epoch=epoch, _lr=lr, _alpha=alpha):
+            if i % args.step_interval_to_print == 0:
+                logging.info(exp_name + ' train [%d: %d/%d]  loss_type: %s, fine_loss: %f total_loss: %f lr: %f'
+                             % (_epoch, i, len(dataset) / args.batch_size, args.loss, fine, total, _lr)
+                             + ' alpha: ' + str(_alpha))
+
+        train_one_epoch(net, optimizer, loader, device, alpha, train_loss_meter, log_fn)
+
+        if epoch % args.epoch_interval_to_save == 0:
+            save_model('%s/network.pth' % log_dir, net)
+            logging.info("Saving net...")
+        if epoch % args.epoch_interval_to_val == 0 or epoch == args.nepoch - 1:
+            last = val(net, epoch, val_loss_meters, loader_test, valid_test, best_epoch_losses, device, log_dir)
+    return last
+
+
+def load_config(path):
+    return AttrDict(yaml.safe_load(open(path)))
+
+
+def main():
+    parser = argparse.ArgumentParser(description='Train config file')
+    parser.add_argument('-c', '--config', help='path to config file', required=True)
+    arg = parser.parse_args()
+    args = load_config(arg.config)
+
+    time = datetime.datetime.now().isoformat()[:19]
+    if args.load_model:
+        exp_name = os.path.basename(os.path.dirname(args.load_model))
+        log_dir = os.path.dirname(args.load_model)
+    else:
+        exp_name = args.model_name + '_' + args.loss + '_' + args.flag + '_' + time
+        log_dir = os.path.join(args.work_dir, exp_name)
+    os.makedirs(log_dir, exist_ok=True)
+    handlers = [logging.StreamHandler(sys.stdout)]
+    if int(os.environ.get("RANK", "0")) == 0:
+        handlers.append(logging.FileHandler(os.path.join(log_dir, 'train.log')))
+    logging.basicConfig(level=logging.INFO if int(os.environ.get("RANK", "0")) == 0 else logging.WARNING,
+                        handlers=handlers)
+    train(args, log_dir, exp_name)
+
+
+if __name__ == "__main__":
+    main()

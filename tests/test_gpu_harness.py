@@ -1,0 +1,158 @@
+"""GPU tests of the callers either side of the op layer (SURVEY 8a rows
+F1-F3, G1): model_utils compositions checked against the same composition of
+oracle ops in NumPy, and the PCN train / val / test entry points end to end on
+synthetic data."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT, rand_clouds
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+COMPLETION = os.path.join(ROOT, "completion")
+if COMPLETION not in sys.path:
+    sys.path.insert(0, COMPLETION)
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_calc_cd_and_calc_emd_formulas(oracle):
+    import model_utils as mu
+    out, gt = rand_clouds(0, 3, 1024, 3), rand_clouds(1, 3, 2048, 3)
+    cd_p, cd_t, f1 = mu.calc_cd(dev(out), dev(gt), calc_f1=True)
+    d1, d2, _, _ = oracle.chamfer_forward(gt, out)          # gt is xyz1 (model_utils.py:70)
+    np.testing.assert_allclose(cd_p.cpu().numpy(), (np.sqrt(d1).mean(1) + np.sqrt(d2).mean(1)) / 2, rtol=1e-6)
+    np.testing.assert_allclose(cd_t.cpu().numpy(), d1.mean(1) + d2.mean(1), rtol=1e-6)
+    p1, p2 = (d1 < 1e-4).mean(1), (d2 < 1e-4).mean(1)
+    want = np.where(p1 + p2 > 0, 2 * p1 * p2 / np.maximum(p1 + p2, 1e-30), 0)
+    np.testing.assert_allclose(f1.cpu().numpy(), want, rtol=1e-5, atol=1e-7)
+    out2 = rand_clouds(2, 2, 1024, 3)
+    gt2 = rand_clouds(3, 2, 1024, 3)
+    e = mu.calc_emd(dev(out2), dev(gt2))                    # eps 0.005, 50 iterations
+    od, _ = oracle.emd_forward(out2, gt2, 0.005, 50)
+    np.testing.assert_allclose(e.cpu().numpy(), np.sqrt(od).mean(1), rtol=1e-6)
+
+
+def test_edge_preserve_sampling_composition(oracle):
+    import model_utils as mu
+    B, C, N, S, k = 2, 16, 768, 384, 10
+    feat, pts = rand_clouds(0, B, C, N), rand_clouds(1, B, N, 3)
+    net, p_idx, pn_idx, point_output = mu.edge_preserve_sampling(dev(feat), dev(pts), S, k)
+    o_idx = oracle.furthest_point_sample(pts, S)
+    np.testing.assert_array_equal(p_idx.cpu().numpy(), o_idx)
+    o_pts = oracle.gather_points(np.ascontiguousarray(pts.transpose(0, 2, 1)), o_idx).transpose(0, 2, 1)
+    np.testing.assert_array_equal(point_output.cpu().numpy(), o_pts)
+    pn = pn_idx.cpu().numpy()                                # torch top-k indices: reuse them
+    nb = oracle.gather_points(feat, pn.reshape(B, S * k)).reshape(B, C, S, k).max(3)
+    ctr = oracle.grouping_operation(feat, o_idx[:, :, None]).reshape(B, C, S)
+    np.testing.assert_array_equal(net.cpu().numpy(), np.concatenate([ctr, nb], 1))
+    # the torch kNN picked true nearest neighbours
+    d2 = ((o_pts[:, :, None] - pts[:, None]) ** 2).sum(-1)
+    assert (np.sort(np.take_along_axis(d2, pn.astype(np.int64), -1), -1)[..., -1]
+            <= np.sort(d2, -1)[..., k - 1] * (1 + 1e-4) + 1e-7).all()
+
+
+def test_three_nn_upsampling_and_symmetric_sample(oracle):
+    import model_utils as mu
+    tgt, src = rand_clouds(0, 2, 768, 3), rand_clouds(1, 2, 384, 3)
+    idx, w = mu.three_nn_upsampling(dev(tgt), dev(src))
+    od, oi = oracle.three_nn(tgt, src)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oi)
+    inv = 1.0 / np.maximum(od, 1e-10)
+    np.testing.assert_allclose(w.cpu().numpy(), inv / inv.sum(2, keepdims=True), rtol=1e-5)
+    sym = mu.symmetric_sample(dev(tgt), 64)
+    i = oracle.furthest_point_sample(tgt, 64)
+    half = np.take_along_axis(tgt, i[..., None].astype(np.int64), 1)
+    np.testing.assert_array_equal(sym.cpu().numpy(), np.concatenate([half, half * [1, 1, -1]], 1).astype(np.float32))
+
+
+def test_uniform_and_repulsion_losses_run(oracle):
+    import model_utils as mu
+    pcd = dev(rand_clouds(0, 2, 1024, 3)).requires_grad_()
+    loss = mu.get_uniform_loss(pcd)
+    assert torch.isfinite(loss) and loss.item() > 0
+    loss.backward()
+    assert torch.isfinite(pcd.grad).all() and pcd.grad.abs().sum() > 0
+    # first percentage, composed from oracle ops: same seeds / balls
+    x = pcd.detach().cpu().numpy()
+    seeds = oracle.furthest_point_sample(x, int(1024 * 0.05))
+    new_xyz = np.take_along_axis(x, seeds[..., None].astype(np.int64), 1)
+    idx = oracle.ball_query(0, math.sqrt(0.004), int(1024 * 0.004), x, new_xyz)
+    from mvp_benchmark_amd.mm3d_pn2 import ball_query, furthest_point_sample
+    np.testing.assert_array_equal(ball_query(0, math.sqrt(0.004), 4, pcd.detach(), dev(new_xyz)).cpu().numpy(), idx)
+    rep = mu.get_repulsion_loss(dev(rand_clouds(1, 2, 512, 3)))
+    assert torch.isfinite(rep)
+
+
+def _pcn_args(tmp, **kw):
+    import train
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", "pcn.yaml"))
+    args.update(batch_size=4, nepoch=2, work_dir=str(tmp), synthetic=True, synthetic_train_shapes=1,
+                synthetic_val_shapes=1, manual_seed=7, step_interval_to_print=1000, lr=1e-3)
+    args.update(kw)
+    return args
+
+
+def test_pcn_train_val_test_end_to_end(tmp_path):
+    """completion/train.py + test.py on synthetic MVP-shaped data: losses are
+    finite and go down, val returns the reference's metric names, the
+    checkpoint round-trips into test.py which writes the submission array."""
+    import test as test_entry
+    import train
+    args = _pcn_args(tmp_path, eval_emd=True)
+    log_dir = str(tmp_path / "run")
+    os.makedirs(log_dir)
+    metrics = train.train(args, log_dir, "pcn_test")
+    assert set(metrics) == {'cd_p', 'cd_t', 'emd', 'f1'}
+    assert all(math.isfinite(v) for v in metrics.values())
+    assert 0 < metrics['cd_t'] < 1 and 0 < metrics['emd'] < 1
+    assert os.path.exists(os.path.join(log_dir, "network.pth"))
+    assert os.path.exists(os.path.join(log_dir, "best_cd_t_network.pth"))
+    args2 = _pcn_args(tmp_path, load_model=os.path.join(log_dir, "network.pth"))
+    res = test_entry.test(args2, log_dir)
+    assert res.shape == (26, 2048, 3) and np.isfinite(res).all()
+    assert os.path.exists(os.path.join(log_dir, "results.npy")) or os.path.exists(os.path.join(log_dir, "results.h5"))
+
+
+def test_pcn_training_reduces_chamfer_loss():
+    import train
+    from models import pcn
+    args = _pcn_args("/tmp")
+    torch.manual_seed(0)
+    net = pcn.Model(args).to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(0)
+    gt = torch.rand(4, 2048, 3, generator=g).to(DEV) * 0.5
+    x = gt[:, :2048].transpose(2, 1).contiguous()
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        _, _, loss = net(x, gt, alpha=1.0)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(math.isfinite(v) for v in losses)
+    assert losses[-1] < 0.5 * losses[0]
+
+
+def test_pcn_eval_config2_shapes():
+    """BASELINE config 2: PCN eval 2048 -> 16384 points, batch 32, CD+F1+EMD."""
+    import train
+    from models import pcn
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", "pcn_eval16k.yaml"))
+    torch.manual_seed(1)
+    net = pcn.Model(args).to(DEV).eval()
+    g = torch.Generator().manual_seed(0)
+    partial = torch.rand(32, 3, 2048, generator=g).to(DEV)
+    gt = torch.rand(32, 16384, 3, generator=g).to(DEV)
+    with torch.no_grad():
+        r = net(partial, gt, prefix="val")
+    assert r['out2'].shape == (32, 16384, 3)
+    for k in ('cd_p', 'cd_t', 'f1', 'emd'):
+        assert r[k].shape == (32,) and torch.isfinite(r[k]).all(), k

@@ -1,0 +1,211 @@
+"""CPU tests of the completion harness: schedules,
+meters, dataset sharding, checkpoint layout, and -- with a world_size-2 gloo
+process group -- the DDP train step, the sharded validation with its small sum
+all-reduce, and the sharded test/submission writer.  The GPU operators are not
+involved here (fake models); their parity is covered by the -m gpu tests."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+COMPLETION = os.path.join(ROOT, "completion")
+if COMPLETION not in sys.path:
+    sys.path.insert(0, COMPLETION)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_cfg_keys_match_reference_set():
+    import yaml
+    want = {'batch_size', 'workers', 'nepoch', 'model_name', 'load_model', 'start_epoch', 'num_points',
+            'work_dir', 'flag', 'loss', 'manual_seed', 'use_mean_feature', 'step_interval_to_print',
+            'epoch_interval_to_save', 'epoch_interval_to_val', 'varying_constant',
+            'varying_constant_epochs', 'lr', 'lr_decay', 'lr_decay_interval', 'lr_decay_rate',
+            'lr_step_decay_epochs', 'lr_step_decay_rates', 'lr_clip', 'optimizer', 'weight_decay',
+            'betas', 'save_vis', 'eval_emd'}
+    for name in ("pcn", "ecg", "vrcnet"):
+        cfg = yaml.safe_load(open(os.path.join(COMPLETION, "cfgs", name + ".yaml")))
+        assert want <= set(cfg), name
+        assert cfg["model_name"] == name and cfg["batch_size"] == 32 and cfg["num_points"] == 2048
+    v = yaml.safe_load(open(os.path.join(COMPLETION, "cfgs", "vrcnet.yaml")))
+    assert {'layers', 'distribution_loss', 'knn_list', 'pk', 'local_folding', 'points_label',
+            'num_coarse_raw', 'num_fps', 'num_coarse'} <= set(v)
+
+
+def test_schedules_and_meter():
+    import train
+    from train_utils import AttrDict, AverageValueMeter
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", "pcn.yaml"))
+    # varying_constant 0.01,0.1,0.5,1 at epochs 5,15,30 (train.py:101-108)
+    assert [train.alpha_for_epoch(args, e) for e in (0, 4, 5, 14, 15, 29, 30, 99)] == \
+        [0.01, 0.01, 0.1, 0.1, 0.5, 0.5, 1.0, 1.0]
+    lr = args.lr
+    seen = []
+    for e in range(0, 121):
+        lr = train.lr_for_epoch(args, e, lr)
+        seen.append(lr)
+    assert seen[0] == seen[39] == 1e-4
+    assert math.isclose(seen[40], 0.7e-4) and math.isclose(seen[80], 0.49e-4) and math.isclose(seen[120], 0.343e-4)
+    a = AttrDict(lr_decay=True, lr_decay_interval=None, lr_step_decay_epochs="2, 4", lr_step_decay_rates="0.5, 0.1",
+                 lr_clip=1e-3)
+    out, lr = [], 1.0
+    for e in range(6):
+        lr = train.lr_for_epoch(a, e, lr)
+        out.append(lr)
+    assert out == [1.0, 1.0, 0.5, 0.5, 0.05, 0.05]
+    m = AverageValueMeter()
+    m.update(1.0, 32)
+    m.update(3.0, 8)          # weighted by batch size (train.py:172-173)
+    assert math.isclose(m.avg, (32 + 24) / 40)
+
+
+def test_shard_indices_cover_every_sample_once():
+    from train_utils import shard_indices
+    for n, world in [(10, 4), (64, 8), (7, 2), (5, 8)]:
+        got = []
+        for r in range(world):
+            idx, valid = shard_indices(n, r, world)
+            assert len(idx) == -(-n // world)
+            got += [i for i, v in zip(idx, valid) if v]
+        assert sorted(got) == list(range(n))
+    a, _ = shard_indices(100, 0, 4, shuffle=True, seed=3, epoch=1)
+    b, _ = shard_indices(100, 0, 4, shuffle=True, seed=3, epoch=2)
+    assert a != b and len(set(a)) == 25
+
+
+def test_synthetic_dataset_matches_mvp_layout():
+    from dataset import SyntheticMVP, VIEWS_PER_SHAPE
+    ds = SyntheticMVP("train", num_shapes=3, num_points=4096)
+    assert len(ds) == 3 * VIEWS_PER_SHAPE == 78
+    l0, p0, c0 = ds[0]
+    l1, p1, c1 = ds[25]
+    l2, p2, c2 = ds[26]
+    assert p0.shape == (2048, 3) and c0.shape == (4096, 3) and p0.dtype == torch.float32
+    assert torch.equal(c0, c1) and not torch.equal(c0, c2)        # index // 26 pairing
+    assert not torch.equal(p0, p1)
+    assert torch.equal(ds[0][1], p0)                               # deterministic
+    t = SyntheticMVP("test", num_shapes=1)
+    assert t[0].shape == (2048, 3)
+
+
+def test_pcn_shapes_and_checkpoint_layout(tmp_path):
+    import train
+    from models import pcn
+    from train_utils import load_model, save_model
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", "pcn.yaml"))
+    net = pcn.Model(args)
+    assert sum(p.numel() for p in net.parameters()) == 6861059     # 6.86 M
+    keys = set(net.state_dict())
+    assert {'encoder.conv1.weight', 'encoder.conv4.bias', 'decoder.fc1.weight', 'decoder.fc3.bias',
+            'decoder.conv1.weight', 'decoder.conv3.bias'} <= keys
+    assert not any('grid' in k for k in keys)                      # reference keeps grid out of the ckpt
+    out = net(torch.rand(2, 3, 2048), prefix="test")
+    assert out['result'].shape == (2, 2048, 3)
+    path = str(tmp_path / "network.pth")
+    save_model(path, net)
+    assert set(torch.load(path)) == {'net_state_dict'}             # train_utils.py:29-34
+    other = pcn.Model(args)
+    load_model(path, other)
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), other.state_dict().values()))
+    args16 = train.load_config(os.path.join(COMPLETION, "cfgs", "pcn_eval16k.yaml"))
+    assert pcn.Model(args16)(torch.rand(1, 3, 2048), prefix="test")['result'].shape == (1, 16384, 3)
+
+
+# ------------------------------------------------------------ world_size 2
+class _FakeNet(torch.nn.Module):
+    """Stands in for a completion model without touching the GPU ops."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(3, 3)
+
+    def forward(self, x, gt=None, prefix="train", alpha=None):
+        pred = self.lin(x.transpose(2, 1))                        # (B, N, 3)
+        if prefix == "train":
+            loss = ((pred - gt[:, :pred.shape[1]]) ** 2).mean(dim=(1, 2))
+            return pred, loss, loss.mean() * (alpha or 1.0)
+        if prefix == "val":
+            d = ((pred - gt[:, :pred.shape[1]]) ** 2).mean(dim=(1, 2))
+            return {'cd_p': d.sqrt(), 'cd_t': d, 'f1': 1.0 / (1.0 + d), 'emd': 2 * d}
+        return {'result': pred}
+
+
+def _worker(rank, world, port, tmp, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, COMPLETION)
+    import train
+    from dataset import SyntheticMVP
+    from train_utils import AttrDict, AverageValueMeter, init_distributed, unwrap
+    torch.manual_seed(0)
+    r, w, device = init_distributed("gloo")
+    assert (r, w) == (rank, world) and device.type == "cpu"
+    args = AttrDict(batch_size=8, workers=0)
+    ds = SyntheticMVP("val", num_shapes=1, num_points=2048)        # 26 samples: uneven over 2 ranks x batch 4
+    net = _FakeNet()
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    # -- validation: sharded + one sum all-reduce
+    loader, valid = train.make_loader(ds, args, r, w, shuffle=False)
+    meters = {m: AverageValueMeter() for m in ['cd_p', 'cd_t', 'emd', 'f1']}
+    best = {m: (0, 0) if m == 'f1' else (0, math.inf) for m in meters}
+    res = train.val(ddp, 0, meters, loader, valid, best, device, log_dir=tmp)
+    # -- one DDP training step on this rank's shard
+    opt = torch.optim.SGD(unwrap(ddp).parameters(), lr=0.1)
+    tl, _ = train.make_loader(ds, AttrDict(batch_size=26 * 2, workers=0), r, w, shuffle=False)
+    meter = AverageValueMeter()
+    train.train_one_epoch(ddp, opt, tl, device, 1.0, meter)
+    q.put((rank, res, [p.detach().numpy().tolist() for p in net.parameters()], meters['cd_t'].count))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_val_and_ddp_step(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference
+    sys.path.insert(0, COMPLETION)
+    import train
+    from dataset import SyntheticMVP
+    from train_utils import AttrDict, AverageValueMeter
+    torch.manual_seed(0)
+    net = _FakeNet()
+    ds = SyntheticMVP("val", num_shapes=1, num_points=2048)
+    loader, valid = train.make_loader(ds, AttrDict(batch_size=8, workers=0), 0, 1, shuffle=False)
+    meters = {m: AverageValueMeter() for m in ['cd_p', 'cd_t', 'emd', 'f1']}
+    best = {m: (0, 0) if m == 'f1' else (0, math.inf) for m in meters}
+    ref = train.val(net, 0, meters, loader, valid, best, torch.device("cpu"))
+    for rank, res, params, count in out:
+        assert count == 26                       # every sample counted exactly once across ranks
+        for k in ref:
+            assert math.isclose(res[k], ref[k], rel_tol=1e-5), (k, res[k], ref[k])
+    # both ranks hold identical parameters after the DDP step ...
+    for a, b in zip(out[0][2], out[1][2]):
+        assert a == b
+    # ... equal to one full-batch step in a single process
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    tl, _ = train.make_loader(ds, AttrDict(batch_size=26, workers=0), 0, 1, shuffle=False)
+    train.train_one_epoch(net, opt, tl, torch.device("cpu"), 1.0, AverageValueMeter())
+    for a, b in zip(out[0][2], net.parameters()):
+        assert torch.allclose(torch.tensor(a), b.detach(), rtol=1e-5, atol=1e-6)
+    assert os.path.exists(os.path.join(str(tmp_path), "best_cd_t_network.pth"))   # rank 0 wrote it
