@@ -17,14 +17,17 @@
 //     whole kernel (P = ceil(N/BS) <= 16 points per lane => N <= 16384):
 //     per round there is no global/LDS traffic for point data at all, HBM is
 //     touched once (12 B/point in, 4 B/sample out);
-//   * the arg-max is ONE packed 64-bit max reduction
-//       key = float_bits(best) << 32 | (BS-1 - bitrev(t)) << 20 | k
-//     done with wave64 cross-lane ops and one LDS hop across the <=16 waves
-//     (double-buffered by round parity => a single barrier per round instead
-//     of ~11).  The key reproduces the reference's tie rule exactly: inside a
-//     thread the first strict maximum in k order (:69-70); across threads the
-//     tree `v2 > v1 ? i2 : i1` (:17-23) lets the slot with the smallest
-//     bit-reversed thread id win among equal maxima.
+//   * the hot loop only updates the running minima and their per-lane maximum
+//     (no index tracking); the arg-max is ONE packed 64-bit max reduction
+//       key = float_bits(best) << 32 | (BS-1 - bitrev(t)) << 20 | t
+//     done with DPP row operations inside the wave and one LDS hop across the
+//     <=16 waves.  Only the winning lane then resolves which of its points
+//     holds the maximum and publishes index + coordinates from its registers
+//     through LDS (2 barriers per round instead of ~11, no global read for the
+//     selected point).  The key reproduces the reference's tie rule exactly:
+//     inside a thread the first strict maximum in k order (:69-70); across
+//     threads the tree `v2 > v1 ? i2 : i1` (:17-23) lets the slot with the
+//     smallest bit-reversed thread id win among equal maxima.
 //   * N > 16384 falls back to a streaming variant (temp in global memory).
 #include <cmath>
 
@@ -32,13 +35,43 @@
 
 namespace mvp {
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS
+// operations, not for its outstanding global stores (__syncthreads() would also
+// drain vmcnt, putting the L2 round trip of the per-round `idxs[j]` store on
+// the critical path of every round).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// One DPP data-movement step on a 32-bit value (rows = 16 lanes).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
+  const unsigned lo = dpp_u32<CTRL, ROW_MASK>((unsigned)v);
+  const unsigned hi = dpp_u32<CTRL, ROW_MASK>((unsigned)(v >> 32));
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return o > v ? o : v;
+}
+
+// Wave64 max of a u64 using DPP moves only (no LDS crossbar): butterfly inside
+// each 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror), then
+// row_bcast15 / row_bcast31 so that lane 63 holds the maximum of all lanes;
+// the result is broadcast from lane 63.
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const unsigned long long o = __shfl_xor(v, off, kWave);
-    v = o > v ? o : v;
-  }
-  return v;
+  v = dpp_max_step<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max_step<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max_step<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_max_step<0x140, 0xF>(v);  // row_mirror
+  v = dpp_max_step<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
+  v = dpp_max_step<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // P > 0: register-resident (n <= P*BS).  P == 0: streaming fallback.
@@ -60,11 +93,13 @@ __global__ __launch_bounds__(1024) void fps_kernel(
   idxs += (size_t)cloud * m;
 
   __shared__ unsigned long long wbest[2][16];
+  __shared__ float s_sel[2][4];  // {old as int bits, x, y, z} of the selected point
 
   // bit-reverse t within log2bs bits; smaller reversed id wins ties.
   const unsigned rev = log2bs ? (__brev((unsigned)t) >> (32 - log2bs)) : 0u;
+  // key = best bits << 32 | (bs-1-rev) << 20 | t  (t < 1024 < 2^20)
   const unsigned long long tiekey =
-      (unsigned long long)((unsigned)(bs - 1) - rev) << 20;
+      ((unsigned long long)((unsigned)(bs - 1) - rev) << 20) | (unsigned)t;
 
   float px[P > 0 ? P : 1], py[P > 0 ? P : 1], pz[P > 0 ? P : 1],
       pt[P > 0 ? P : 1];
@@ -87,19 +122,23 @@ __global__ __launch_bounds__(1024) void fps_kernel(
       for (int k = t; k < n; k += bs) temp[k] = 1e10f;
   }
 
+  if (t < 32) wbest[t >> 4][t & 15] = 0ull;  // slots of absent waves never win
+  __syncthreads();
   int old = 0;
   if (t == 0) idxs[0] = old;
+  float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+  if (!WITH_DIST) {
+    x1 = dataset[0];
+    y1 = dataset[1];
+    z1 = dataset[2];
+  }
 
   for (int j = 1; j < m; ++j) {
-    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
-    if (!WITH_DIST) {
-      x1 = dataset[(size_t)old * 3 + 0];
-      y1 = dataset[(size_t)old * 3 + 1];
-      z1 = dataset[(size_t)old * 3 + 2];
-    }
     float best = -1.f;
-    int besti = 0;
+    int besti = 0;  // only tracked by the streaming variant
     if (P > 0) {
+      // Update the running min-distances; the arg-max index is NOT tracked
+      // here: only the winning lane resolves it afterwards.
 #pragma unroll
       for (int i = 0; i < P; ++i) {
         const int k = t + i * bs;
@@ -109,11 +148,8 @@ __global__ __launch_bounds__(1024) void fps_kernel(
         } else {
           d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
         }
-        const float d2 = d < pt[i] ? d : pt[i];
-        pt[i] = d2;
-        const bool gt = d2 > best;
-        besti = gt ? k : besti;
-        best = gt ? d2 : best;
+        pt[i] = d < pt[i] ? d : pt[i];
+        best = __builtin_fmaxf(best, pt[i]);
       }
     } else {
       for (int k = live ? t : n; k < n; k += bs) {
@@ -133,24 +169,67 @@ __global__ __launch_bounds__(1024) void fps_kernel(
         best = gt ? d2 : best;
       }
     }
-    // best >= 0 here (every thread owns at least point t < n), so its bit
-    // pattern orders like an unsigned integer.
+    // best >= 0 here (every live thread owns at least point t < n), so its
+    // bit pattern orders like an unsigned integer.
     unsigned long long key =
-        ((unsigned long long)__float_as_uint(best) << 32) | tiekey |
-        (unsigned long long)(unsigned)besti;
+        ((unsigned long long)__float_as_uint(best) << 32) | tiekey;
     if (!live) key = 0;
     key = wave_max_u64(key);
     if (nwaves > 1) {
       if (lane == 0) wbest[j & 1][wave] = key;
-      __syncthreads();
-      unsigned long long v = wbest[j & 1][0];
-      for (int w = 1; w < nwaves; ++w) {
-        const unsigned long long o = wbest[j & 1][w];
-        v = o > v ? o : v;
-      }
-      key = v;
+      lds_barrier();
+      // 16 wave maxima -> block maximum: ONE LDS read per wave (lanes 0-15
+      // take one entry each; slots of absent waves hold 0), a 4-step DPP
+      // butterfly inside that 16-lane row, broadcast from lane 0.
+      unsigned long long v = lane < 16 ? wbest[j & 1][lane] : 0ull;
+      v = dpp_max_step<0xB1, 0xF>(v);
+      v = dpp_max_step<0x4E, 0xF>(v);
+      v = dpp_max_step<0x141, 0xF>(v);
+      v = dpp_max_step<0x140, 0xF>(v);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+      key = ((unsigned long long)hi << 32) | lo;
     }
-    old = __builtin_amdgcn_readfirstlane((int)(key & 0xFFFFFu));
+    const int tstar = (int)(key & 0xFFFFFu);  // winning thread
+    if (wave == (tstar >> 6)) {               // wave-uniform
+      // The winning lane resolves its first (lowest k) maximum -- the
+      // reference's per-thread strict `>` scan (:69-70) -- and publishes the
+      // selected point from its registers.
+      const float vbest = __uint_as_float((unsigned)(key >> 32));
+      int sel = P > 0 ? t : besti;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      if (P > 0) {
+#pragma unroll
+        for (int i = P - 1; i >= 0; --i) {
+          const bool hit = pt[i] == vbest;
+          sel = hit ? t + i * bs : sel;
+          if (!WITH_DIST) {
+            sx = hit ? px[i] : sx;
+            sy = hit ? py[i] : sy;
+            sz = hit ? pz[i] : sz;
+          }
+        }
+      }
+      if (t == tstar) {
+        s_sel[j & 1][0] = __int_as_float(sel);
+        s_sel[j & 1][1] = sx;
+        s_sel[j & 1][2] = sy;
+        s_sel[j & 1][3] = sz;
+      }
+    }
+    lds_barrier();
+    old = __builtin_amdgcn_readfirstlane(__float_as_int(s_sel[j & 1][0]));
+    if (!WITH_DIST) {
+      if (P > 0) {
+        x1 = s_sel[j & 1][1];
+        y1 = s_sel[j & 1][2];
+        z1 = s_sel[j & 1][3];
+      } else {
+        x1 = dataset[(size_t)old * 3 + 0];
+        y1 = dataset[(size_t)old * 3 + 1];
+        z1 = dataset[(size_t)old * 3 + 2];
+      }
+    }
     if (t == 0) idxs[j] = old;
   }
 

@@ -1,0 +1,53 @@
+"""Micro-benchmarks of the non-EMD ops (SURVEY 8d M2/M4/M5 shapes)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mvp_benchmark_amd.metrics import cd
+from mvp_benchmark_amd.mm3d_pn2 import (furthest_point_sample, knn, three_nn, three_interpolate,
+                                        gather_points, grouping_operation, ball_query)
+dev = "cuda:0"
+g = torch.Generator().manual_seed(0)
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+def R(*shape):
+    return torch.rand(*shape, generator=g).to(dev)
+
+if which in ("all", "fps"):
+    for (b, n, m) in [(64, 16384, 2048), (64, 2048, 512), (64, 2048, 2048), (64, 3072, 1536), (64, 1536, 768), (64, 768, 384), (32, 2048, 2048)]:
+        x = R(b, n, 3)
+        ms = timeit(lambda: furthest_point_sample(x, m))
+        print("fps (%d,%d)->%d: %.3f ms  %.3g sampled pts/s  %.3g updates/s  %.2f us/round" % (b, n, m, ms, b * m / ms * 1e3, b * (m - 1) * n / ms * 1e3, ms * 1e3 / (m - 1)), flush=True)
+if which in ("all", "cd"):
+    for (b, n, m) in [(64, 16384, 16384), (64, 2048, 16384), (32, 16384, 16384), (64, 2048, 2048), (64, 2048, 3072), (4, 2048, 2048)]:
+        a, c = R(b, n, 3), R(b, m, 3)
+        ms = timeit(lambda: cd()(a, c))
+        print("cd (%d,%d)x(%d): %.3f ms  %.3g pair-evals/s (2 dirs)  %.1f TFLOP/s@16" % (b, n, m, ms, 2.0 * b * n * m / ms * 1e3, 16.0 * b * n * m / ms * 1e3 / 1e12), flush=True)
+if which in ("all", "pn2"):
+    for (b, n, k) in [(64, 2048, 16), (64, 16384, 16), (64, 2048, 10), (64, 2048, 20)]:
+        x = R(b, n, 3)
+        ms = timeit(lambda: knn(k, x, x, False), 3)
+        print("knn k=%d (%d,%d): %.3f ms  %.3g evals/s" % (k, b, n, ms, 1.0 * b * n * n / ms * 1e3), flush=True)
+    for (b, n, m, c) in [(64, 768, 384, 512), (64, 1536, 768, 256), (64, 3072, 1536, 128)]:
+        tgt, src, f = R(b, n, 3), R(b, m, 3), R(b, c, m)
+        ms = timeit(lambda: three_nn(tgt, src))
+        dist, idx = three_nn(tgt, src)
+        w = torch.rand(b, n, 3, device=dev)
+        ms2 = timeit(lambda: three_interpolate(f, idx, w))
+        print("three_nn (%d,%d<-%d): %.3f ms; three_interpolate C=%d: %.3f ms  %.1f GB/s (8 B/out elem)" % (b, n, m, ms, c, ms2, 8.0 * b * c * n / ms2 / 1e6), flush=True)
+    for (b, c, n, m) in [(64, 3, 3072, 1536), (64, 64, 3072, 15360), (64, 128, 1536, 7680), (64, 256, 768, 3840)]:
+        f = R(b, c, n); idx = torch.randint(0, n, (b, m), generator=g, dtype=torch.int32).to(dev)
+        ms = timeit(lambda: gather_points(f, idx))
+        print("gather (%d,%d,%d)->%d: %.3f ms  %.1f GB/s (8 B/out elem)" % (b, c, n, m, ms, 8.0 * b * c * m / ms / 1e6), flush=True)
+    for (n, m, r, s) in [(1024, 51, 0.0632, 4), (2048, 102, 0.1095, 24)]:
+        x = R(64, n, 3); ctr = x[:, :m].contiguous()
+        ms = timeit(lambda: ball_query(0.0, r, s, x, ctr))
+        print("ball_query (64,%d) M=%d S=%d: %.3f ms" % (n, m, s, ms), flush=True)
