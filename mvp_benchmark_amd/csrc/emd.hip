@@ -50,7 +50,9 @@ constexpr int kEmdThreads = 1024;
 constexpr int kEmdWaves = kEmdThreads / kWave;
 constexpr int kMaxG = 12;
 constexpr int kMaxCells = kMaxG * kMaxG * kMaxG;  // 1728
-constexpr int kBidCache = 2048;
+constexpr int kBidCache = 1024;  // list positions whose bid is cached in LDS
+constexpr int kRecCap = 512;     // list positions whose person record is cached in LDS
+constexpr int kListCap = 512;    // per-wave surviving-cell list (flushed when full)
 
 // Filter slack.  An object is skipped only if
 //   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
@@ -175,6 +177,36 @@ __device__ __forceinline__ void top2_insert(float &a1, float &a2, float v) {
   a2 = __builtin_fmaxf(a2, lo);
 }
 
+// DPP move with an identity fill for lanes the control/row mask does not write.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float identity, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v),
+                                                    CTRL, ROW_MASK, 0xF, false));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void top2_dpp_step(float &a1, float &a2) {
+  const float o1 = dpp_f32<CTRL, ROW_MASK>(-1e9f, a1);
+  const float o2 = dpp_f32<CTRL, ROW_MASK>(-1e9f, a2);
+  const float lo = __builtin_fminf(a1, o1);
+  a1 = __builtin_fmaxf(a1, o1);
+  a2 = __builtin_fmaxf(lo, __builtin_fmaxf(a2, o2));
+}
+
+// Second-largest value (with multiplicity) over the wave's per-lane (a1, a2)
+// top-2 pairs, using DPP row operations only; every step merges disjoint lane
+// sets, masked-out lanes merge with the identity (-1e9, -1e9).  Valid in lane
+// 63, returned wave-uniform.
+__device__ __forceinline__ float wave_second_largest(float a1, float a2) {
+  top2_dpp_step<0xB1, 0xF>(a1, a2);   // quad_perm [1,0,3,2]
+  top2_dpp_step<0x4E, 0xF>(a1, a2);   // quad_perm [2,3,0,1]
+  top2_dpp_step<0x141, 0xF>(a1, a2);  // row_half_mirror
+  top2_dpp_step<0x140, 0xF>(a1, a2);  // row_mirror
+  top2_dpp_step<0x142, 0xA>(a1, a2);  // row_bcast15 -> rows 1, 3
+  top2_dpp_step<0x143, 0xC>(a1, a2);  // row_bcast31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 63));
+}
+
 struct GridGeom {
   float lox, loy, loz, invh;
   int g;
@@ -214,15 +246,20 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ float c_pmin[kMaxCells];
   __shared__ int c_start[kMaxCells + 1];
   __shared__ int s_tmp[kMaxCells];  // counts / fill cursors during the build
-  __shared__ unsigned short w_list[kEmdWaves][kMaxCells];  // per-wave surviving cells
+  __shared__ unsigned short w_list[kEmdWaves][kListCap];  // per-wave surviving cells
   __shared__ float s_red[6][kEmdWaves];
   __shared__ int s_wsum[kEmdWaves];
   __shared__ int s_cnt[2];
   __shared__ int s_err;
   // this round's bids for the first kBidCache list positions (skips two
   // dependent global round trips in GetMax / Assign)
-  __shared__ int s_bj[kBidCache], s_bo[kBidCache];
+  __shared__ int s_bj[kBidCache], s_bo[kBidCache], s_b2k[kBidCache];
   __shared__ float s_binc[kBidCache];
+  // person records {qx,qy,qz,-} / {j, prev1, prev2, -} of the first kRecCap
+  // entries of the current / next unassigned list: in the long tail of the
+  // auction a bid starts from LDS instead of two dependent global reads
+  __shared__ float4 s_rq[2][kRecCap];
+  __shared__ int4 s_ri[2][kRecCap];
 
   // ------------------------------------------------------------ grid build
   // (a) bounding box of both clouds
@@ -264,7 +301,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     float ext = __builtin_fmaxf(hi[0] - lo[0],
                                 __builtin_fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
     if (!(ext > 0.f) || !(ext < 3.0e38f)) ext = 1.f;
-    // ~12 objects per cell (one 16-lane group), 2 <= G <= 12
+    // ~12 objects per cell (one 32-lane half-wave), 2 <= G <= 12
     int g = 2;
     while (g < kMaxG && (g + 1) * (g + 1) * (g + 1) * 12 <= n) ++g;
     gg.g = g;
@@ -332,6 +369,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     sc.person[k] = pr;
     sc.ulist[k] = k;
   }
+  if (t < kRecCap) {  // round 0: list position u holds person u
+    s_rq[0][t] = make_float4(xyz1[t * 3 + 0], xyz1[t * 3 + 1], xyz1[t * 3 + 2], 0.f);
+    s_ri[0][t] = make_int4(t, -1, -1, 0);
+  }
   if (t == 0) {
     s_cnt[0] = n;
     s_cnt[1] = 0;
@@ -366,6 +407,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
   long long cyc_bid = 0, cyc_getmax = 0, cyc_assign = 0;
   long long cb_seed = 0, cb_cells = 0, cb_visit = 0, cb_write = 0, cb_n = 0;
+  long long cn_sub = 0, cn_list = 0, cn_fold = 0, cn_over = 0;
 #endif
   for (int it = 0; it < iters; ++it) {
     const int U = s_cnt[cur];
@@ -384,30 +426,28 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     const long long tp0 = __builtin_readcyclecounter();
 #endif
     // ---------------- Bid (emd_cuda.cu:95-179): one wave per bidder
-    // Software-pipelined over this wave's bidders: the list entry two
-    // bidders ahead and the person record one bidder ahead are in flight
-    // while the current bid is computed.
-    int j_cur = wave < U ? L[wave] : 0;
-    int j_nxt = wave + kEmdWaves < U ? L[wave + kEmdWaves] : 0;
+    // A bidder's record comes from the LDS cache (list position < kRecCap)
+    // or, in the heavy early rounds, from global memory with the next
+    // bidder's list entry and record prefetched one bid ahead.
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    int4 rb = make_int4(-1, -1, -1, 0);
-    if (wave < U) {
-      ra = *reinterpret_cast<const float4 *>(&sc.person[j_cur]);
-      rb = *(reinterpret_cast<const int4 *>(&sc.person[j_cur]) + 1);
-    }
+    int4 rb = make_int4(0, -1, -1, 0);
+    auto load_rec = [&](int u) {
+      if (u < kRecCap) {
+        ra = s_rq[cur][u];
+        rb = s_ri[cur][u];
+      } else if (u < U) {
+        const int jj = L[u];
+        ra = *reinterpret_cast<const float4 *>(&sc.person[jj]);
+        const int4 g = *(reinterpret_cast<const int4 *>(&sc.person[jj]) + 1);
+        rb = make_int4(jj, g.y, g.z, 0);
+      }
+    };
+    load_rec(wave);
     for (int u = wave; u < U; u += kEmdWaves) {
-      const int j = j_cur;
+      const int j = rb.x;
       const float qx = ra.x, qy = ra.y, qz = ra.z;
       const int p1 = rb.y, p2 = rb.z;
-      {
-        const int un = u + kEmdWaves;
-        j_cur = j_nxt;
-        if (un < U) {
-          ra = *reinterpret_cast<const float4 *>(&sc.person[j_nxt]);
-          rb = *(reinterpret_cast<const int4 *>(&sc.person[j_nxt]) + 1);
-        }
-        j_nxt = un + kEmdWaves < U ? L[un + kEmdWaves] : 0;
-      }
+      load_rec(u + kEmdWaves);  // prefetch (consumed next iteration)
 #ifdef MVP_EMD_PROFILE
       const long long q0 = __builtin_readcyclecounter();
 #endif
@@ -439,20 +479,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
           a2 = -1e9f;
         }
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-          const float o1 = __shfl_xor(a1, off, kWave);
-          const float o2 = __shfl_xor(a2, off, kWave);
-          const float lo = __builtin_fminf(a1, o1);
-          a1 = __builtin_fmaxf(a1, o1);
-          a2 = __builtin_fmaxf(lo, __builtin_fmaxf(a2, o2));
-        }
         st.b1 = -1e9f;
         st.b2 = -1e9f;
         st.bk = -1;
         st.b2k = -1;
-        const float seed_b2 =
-            __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a2)));
+        const float seed_b2 = wave_second_largest(a1, a2);
         st.tm = (3.0f - seed_b2) + kMargin;
       }
 
@@ -486,10 +517,61 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       }
       const int nxy = nx * ny;
       const int nsub = nxy * nz;
-      const float inv_nxy = 1.0f / (float)nxy, inv_nx = 1.0f / (float)nx;
-      const int sub = lane >> 4, sl = lane & 15;
+      // approximate reciprocals are enough: (i + 0.5) / m is >= 0.5/144 away
+      // from an integer, far above the 1 ulp error of v_rcp_f32
+      const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
+      const int sub = lane >> 5, sl = lane & 31;
       unsigned short *wl = w_list[wave];
       int nlist = 0;
+      // (3) visit listed cells, 8 per step: each 32-lane half-wave takes 4
+      // cells, so 4 independent 16-byte loads per lane are in flight at once
+      // (the auction is bound by dependent L2 round trips, not by issue).
+      auto visit = [&]() {
+        for (int k0 = 0; k0 < nlist; k0 += 8) {
+          int s[4], s1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = k0 + r * 2 + sub;
+            s[r] = 0;
+            s1[r] = 0;
+            if (k < nlist) {
+              const int cc = wl[k];
+              s[r] = c_start[cc] + sl;
+              s1[r] = c_start[cc + 1];
+            }
+          }
+          bool more = true;
+          while (more) {
+            float4 o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              o[r] = s[r] < s1[r] ? sc.obj[s[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
+              const float tq = st.tm - o[r].w;
+              const bool ps = s[r] < s1[r] && tq >= 0.f && sd <= tq * tq;
+              const unsigned long long m = __ballot(ps);
+              if (m) emd_fold(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm);
+#ifdef MVP_EMD_PROFILE
+              cn_fold += __builtin_popcountll(m);
+#endif
+            }
+            // cells with more than 32 members (rare): next 32
+            bool mine = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s[r] += 32;
+              mine |= s[r] < s1[r];
+            }
+            more = __any(mine);
+          }
+        }
+#ifdef MVP_EMD_PROFILE
+        cn_list += nlist;
+#endif
+        nlist = 0;
+      };
       for (int cb = 0; cb < nsub; cb += kWave) {
         const int i = cb + lane;
         bool cpass = false;
@@ -511,58 +593,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         if (cpass)
           wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
         nlist += __builtin_popcountll(cmask);
+        if (nlist > kListCap - kWave) visit();  // keep room for the next 64
       }
 #ifdef MVP_EMD_PROFILE
+      cn_sub += nsub;
       const long long q2 = __builtin_readcyclecounter();
 #endif
-      // (3) visit the surviving cells, 16 per step: each 16-lane group takes 4
-      // cells, so 4 independent 16-byte loads per lane are in flight at once
-      // (the auction is bound by dependent L2 round trips, not by issue).
-      for (int k0 = 0; k0 < nlist; k0 += 16) {
-        int s[4], s1[4];
-        float4 o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = k0 + r * 4 + sub;
-          s[r] = 0;
-          s1[r] = 0;
-          if (k < nlist) {
-            const int cc = wl[k];
-            s[r] = c_start[cc] + sl;
-            s1[r] = c_start[cc + 1];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          o[r] = s[r] < s1[r] ? sc.obj[s[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
-          const float tq = st.tm - o[r].w;
-          const bool ps = s[r] < s1[r] && tq >= 0.f && sd <= tq * tq;
-          const unsigned long long m = __ballot(ps);
-          if (m) emd_fold(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm);
-        }
-        // cells with more than 16 members
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int sr = s[r] + 16;
-          while (__any(sr < s1[r])) {
-            bool ps = false;
-            float sd = 0.f, pw = 0.f;
-            if (sr < s1[r]) {
-              const float4 oo = sc.obj[sr];
-              sd = sqdist3(oo.x - qx, oo.y - qy, oo.z - qz);
-              pw = oo.w;
-              const float tq = st.tm - pw;
-              ps = tq >= 0.f && sd <= tq * tq;
-            }
-            const unsigned long long m = __ballot(ps);
-            if (m) emd_fold(st, m, emd_value(sd, pw), sr, n, tpu, sc.perm);
-            sr += 16;
-          }
-        }
-      }
+      visit();
 #ifdef MVP_EMD_PROFILE
       const long long q3 = __builtin_readcyclecounter();
 #endif
@@ -578,6 +615,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         if (u < kBidCache) {
           s_bj[u] = j;
           s_bo[u] = st.bk;
+          s_b2k[u] = st.b2k;
           s_binc[u] = inc;
         }
         atomic_max_float(&sc.ostate[st.bk].maxinc, inc);
@@ -614,25 +652,36 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #endif
 
     // ---------------- Assign (emd_cuda.cu:196-215)
+    const int nxt = cur ^ 1;
     for (int u = t; u < U; u += kEmdThreads) {
-      int j, o;
+      int j, o, b2k;
       float bi;
       if (u < kBidCache) {
-        j = s_bj[u]; o = s_bo[u]; bi = s_binc[u];
+        j = s_bj[u]; o = s_bo[u]; bi = s_binc[u]; b2k = s_b2k[u];
       } else {
-        j = L[u]; o = sc.person[j].bid; bi = sc.person[j].bidinc;
+        j = L[u];
+        const int4 g = *(reinterpret_cast<const int4 *>(&sc.person[j]) + 1);
+        o = g.x; b2k = g.z; bi = sc.person[j].bidinc;
       }
       const ObjState os = sc.ostate[o];
+      const float4 oo = sc.obj[o];  // independent of `os`: same round trip
       if (last || os.maxidx == (tag | (unsigned long long)(unsigned)j)) {
         const int prev = os.ass_inv;
         if (!last && prev != -1) {
+          // the evicted owner bids again next round
           ass[prev] = -1;
-          Lnext[atomicAdd(&s_cnt[cur ^ 1], 1)] = prev;
+          const int pos = atomicAdd(&s_cnt[nxt], 1);
+          Lnext[pos] = prev;
+          if (pos < kRecCap) {
+            const float4 pa = *reinterpret_cast<const float4 *>(&sc.person[prev]);
+            const int4 pb = *(reinterpret_cast<const int4 *>(&sc.person[prev]) + 1);
+            s_rq[nxt][pos] = pa;
+            s_ri[nxt][pos] = make_int4(prev, pb.y, pb.z, 0);
+          }
         }
         sc.ostate[o].ass_inv = j;
         sc.ostate[o].maxinc = __float_as_int(-1e9f);
         ass[j] = o;
-        const float4 oo = sc.obj[o];
         sc.obj[o].w = oo.w + bi;
         // refresh the cell's price lower bound (racing refreshes of the same
         // cell may leave a slightly stale -- still valid -- bound)
@@ -644,7 +693,18 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           pm = __builtin_fminf(pm, s == o ? pm : sc.obj[s].w);
         c_pmin[c] = pm;
       } else {
-        Lnext[atomicAdd(&s_cnt[cur ^ 1], 1)] = j;
+        // lost: stays in the list, record carried over through LDS
+        const int pos = atomicAdd(&s_cnt[nxt], 1);
+        Lnext[pos] = j;
+        if (pos < kRecCap) {
+          float4 pa;
+          if (u < kRecCap)
+            pa = s_rq[cur][u];
+          else
+            pa = *reinterpret_cast<const float4 *>(&sc.person[j]);
+          s_rq[nxt][pos] = pa;
+          s_ri[nxt][pos] = make_int4(j, o, b2k, 0);
+        }
       }
     }
     __syncthreads();
@@ -662,7 +722,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
     stats[0] = cyc_bid;
     stats[1] = (cyc_getmax << 32) | (cyc_assign & 0xffffffffll);
-    if (cloud == 0) printf("wave0 bids %lld: seed %lld cells %lld visit %lld write %lld cycles/bid\n", cb_n, cb_seed / (cb_n ? cb_n : 1), cb_cells / (cb_n ? cb_n : 1), cb_visit / (cb_n ? cb_n : 1), cb_write / (cb_n ? cb_n : 1));
+    if (cloud == 0) printf("wave0 bids %lld: seed %lld cells %lld visit %lld write %lld cycles/bid | per bid: cells tested %.1f visited %.1f folds %.2f overflow-steps %.2f\n", cb_n, cb_seed / (cb_n ? cb_n : 1), cb_cells / (cb_n ? cb_n : 1), cb_visit / (cb_n ? cb_n : 1), cb_write / (cb_n ? cb_n : 1), (double)cn_sub / (cb_n ? cb_n : 1), (double)cn_list / (cb_n ? cb_n : 1), (double)cn_fold / (cb_n ? cb_n : 1), (double)cn_over / (cb_n ? cb_n : 1));
 #endif
   }
   // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
