@@ -184,6 +184,13 @@ def main():
     value = pairs * world / (elapsed / args.steps)
     emd_bytes = 32.0 * B * n  # xyz1+xyz2 in (24 B/pt) + dist+assignment out (8 B/pt)
     achieved = emd_bytes / (emd_ms * 1e-3) / 1e9
+    traffic = None  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["emd_auction_kernel"]
+        if (tr["batch"], tr["points"], tr["eps"], tr["iters"]) == (B, n, args.eps, args.iters):
+            traffic = (tr["FETCH_SIZE_KB"] + tr["WRITE_SIZE_KB"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        pass
     line = {
         "metric": "point-pairs/sec CD+EMD @2048->16384 pts, batch 64",
         "value": value,
@@ -202,7 +209,7 @@ def main():
                    "batch_per_gpu": B, "points": n, "parallelism": "batch-sharded x%d" % world},
         "roofline": {"kernel": "emd_auction_kernel", "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None},
+                     "traffic": traffic},
         "extra": {
             "cd_f1_ms": cd_ms, "emd_ms": emd_ms,
             "emd_rounds_max": rounds, "emd_bids_per_cloud": bids,
