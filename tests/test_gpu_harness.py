@@ -156,3 +156,41 @@ def test_pcn_eval_config2_shapes():
     assert r['out2'].shape == (32, 16384, 3)
     for k in ('cd_p', 'cd_t', 'f1', 'emd'):
         assert r[k].shape == (32,) and torch.isfinite(r[k]).all(), k
+
+
+@pytest.mark.parametrize("name", ["ecg", "vrcnet"])
+def test_ecg_vrcnet_train_val_test_steps(name):
+    """BASELINE config 3 family: one optimisation step + val + test forward of
+    ECG / VRCNet on MVP-shaped synthetic clouds; every op of the layer is
+    exercised forward and backward (FPS, gather, group, three_nn/interpolate,
+    ball_query, CD, EMD)."""
+    import importlib
+    import train
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", name + ".yaml"))
+    args.update(eval_emd=True, load_model=None)
+    torch.manual_seed(3)
+    net = importlib.import_module("models." + name).Model(args).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    gt = torch.rand(2, 2048, 3, generator=g).to(DEV)
+    partial = gt[:, torch.randperm(2048, generator=g)[:2048]].transpose(2, 1).contiguous()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    net.train()
+    losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        fine, loss_fine, total = net(partial, gt, alpha=0.5)
+        total.backward()
+        opt.step()
+        losses.append(total.item())
+    assert all(math.isfinite(v) for v in losses)
+    expect_b = 4 if name == "vrcnet" else 2          # VRCNet doubles the batch in training
+    assert fine.shape == (expect_b, 2048, 3) and loss_fine.shape == (expect_b,)
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(gr).all() for gr in grads)
+    net.eval()
+    with torch.no_grad():
+        r = net(partial, gt, prefix="val")
+        t = net(partial, prefix="test")
+    assert t['result'].shape == (2, 2048, 3)
+    for k in ('cd_p', 'cd_t', 'f1', 'emd'):
+        assert r[k].shape == (2,) and torch.isfinite(r[k]).all(), k

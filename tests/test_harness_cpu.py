@@ -209,3 +209,31 @@ def test_two_rank_gloo_val_and_ddp_step(tmp_path):
     for a, b in zip(out[0][2], net.parameters()):
         assert torch.allclose(torch.tensor(a), b.detach(), rtol=1e-5, atol=1e-6)
     assert os.path.exists(os.path.join(str(tmp_path), "best_cd_t_network.pth"))   # rank 0 wrote it
+
+
+def test_models_state_dict_layout_matches_reference():
+    """Names and shapes of every parameter of PCN / ECG / VRCNet equal the
+    reference models' (tests/golden/model_state_keys.json, recorded from the
+    reference by tests/golden/make_model_keys.py) => checkpoints interchange."""
+    import json
+    import train
+    from models import ecg, pcn, vrcnet
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "model_state_keys.json")))
+    for name, mod, nparam in (("pcn", pcn, 6861059), ("ecg", ecg, 14195987), ("vrcnet", vrcnet, 17221879)):
+        net = mod.Model(train.load_config(os.path.join(COMPLETION, "cfgs", name + ".yaml")))
+        mine = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert mine == ref[name], name
+        assert sum(p.numel() for p in net.parameters()) == nparam
+
+
+def test_pcn_forward_matches_reference_golden():
+    """Same seed => same initial weights (identical construction order); the
+    forward pass reproduces the reference PCN's output on the golden input."""
+    import train
+    from models import pcn
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pcn_forward_golden.npz"))
+    torch.manual_seed(1234)
+    net = pcn.Model(train.load_config(os.path.join(COMPLETION, "cfgs", "pcn.yaml"))).eval()
+    with torch.no_grad():
+        res = net(torch.tensor(g["x"]), prefix="test")["result"]
+    np.testing.assert_allclose(res.numpy(), g["result"], rtol=1e-5, atol=1e-6)
