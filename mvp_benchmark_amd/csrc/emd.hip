@@ -572,7 +572,27 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #endif
         nlist = 0;
       };
-      for (int cb = 0; cb < nsub; cb += kWave) {
+      // When the search cube covers most of the grid (high prices everywhere,
+      // e.g. a clustered prediction against a spread target) the cell
+      // machinery only adds overhead: scan the cell-sorted objects linearly,
+      // 4 x 64 per step, with the same lossless filter.
+      const bool linear = 2 * nsub > ncell;
+      if (linear) {
+        for (int base = 0; base < n; base += 4 * kWave) {
+          float4 o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = sc.obj[base + r * kWave + lane];  // n % 1024 == 0
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
+            const float tq = st.tm - o[r].w;
+            const bool ps = tq >= 0.f && sd <= tq * tq;
+            const unsigned long long m = __ballot(ps);
+            if (m) emd_fold(st, m, emd_value(sd, o[r].w), base + r * kWave + lane, n, tpu, sc.perm);
+          }
+        }
+      }
+      for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
         const int i = cb + lane;
         bool cpass = false;
         int c = 0;

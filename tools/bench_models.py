@@ -1,0 +1,46 @@
+"""End-to-end model steps at the BASELINE configs (single GPU):
+   cfg 2: PCN eval 2048 -> 16384 pts, batch 32 (CD + F1 + EMD)
+   cfg 3: VRCNet train step, per-rank batch 32 (2048 pts), CD loss
+   (+ ECG train step).  Synthetic data, random-init weights."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "completion"))
+import torch
+import train
+
+dev = "cuda:0"
+g = torch.Generator().manual_seed(0)
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+# cfg 2
+args = train.load_config(os.path.join(ROOT, "completion", "cfgs", "pcn_eval16k.yaml"))
+net = importlib.import_module("models.pcn").Model(args).to(dev).eval()
+partial = torch.rand(32, 3, 2048, generator=g).to(dev); gt = torch.rand(32, 16384, 3, generator=g).to(dev)
+with torch.no_grad():
+    ms = timed(lambda: net(partial, gt, prefix="val"))
+    args.eval_emd = False; net.eval_emd = False
+    ms_noemd = timed(lambda: net(partial, gt, prefix="val"))
+print("cfg2 PCN eval (32, 2048->16384) CD+F1+EMD: %.1f ms/step (%.1f clouds/s); without EMD %.1f ms" % (ms, 32e3 / ms, ms_noemd), flush=True)
+
+for name in ("vrcnet", "ecg"):
+    args = train.load_config(os.path.join(ROOT, "completion", "cfgs", name + ".yaml"))
+    args.load_model = None
+    net = importlib.import_module("models." + name).Model(args).to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    gt = torch.rand(32, 2048, 3, generator=g).to(dev)
+    partial = gt.transpose(2, 1).contiguous()
+    def step():
+        opt.zero_grad()
+        _, _, loss = net(partial, gt, alpha=0.5)
+        loss.backward()
+        opt.step()
+    ms = timed(step)
+    print("%s train step (batch 32, 2048 pts): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
+        name, ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
