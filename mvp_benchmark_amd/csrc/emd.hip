@@ -37,6 +37,8 @@
 //   * GetMax's last-writer race (emd_cuda.cu:188-191) is made deterministic:
 //     the highest qualifying bidder index wins, via a round-tagged 64-bit
 //     atomic max -- the result of executing the reference kernel sequentially.
+#include <type_traits>
+
 #include "common.h"
 
 namespace mvp {
@@ -52,7 +54,11 @@ constexpr int kMaxG = 12;
 constexpr int kMaxCells = kMaxG * kMaxG * kMaxG;  // 1728
 constexpr int kBidCache = 1024;  // list positions whose bid is cached in LDS
 constexpr int kRecCap = 512;     // list positions whose person record is cached in LDS
-constexpr int kListCap = 512;    // per-wave surviving-cell list (flushed when full)
+#ifndef MVP_EMD_ROWMIN
+#define MVP_EMD_ROWMIN 96
+#endif
+constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 bidders share a wave
+constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
 
 // Filter slack.  An object is skipped only if
 //   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ float c_pmin[kMaxCells];
   __shared__ int c_start[kMaxCells + 1];
   __shared__ int s_tmp[kMaxCells];  // counts / fill cursors during the build
-  __shared__ unsigned short w_list[kEmdWaves][kListCap];  // per-wave surviving cells
+  __shared__ unsigned short w_list[kEmdWaves][4 * kRowListCap];  // surviving cells, per 16-lane row
   __shared__ float s_red[6][kEmdWaves];
   __shared__ int s_wsum[kEmdWaves];
   __shared__ int s_cnt[2];
@@ -406,8 +412,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   long long n_rounds = 0, n_bids = 0;
 #ifdef MVP_EMD_PROFILE
   long long cyc_bid = 0, cyc_getmax = 0, cyc_assign = 0;
-  long long cb_seed = 0, cb_cells = 0, cb_visit = 0, cb_write = 0, cb_n = 0;
-  long long cn_sub = 0, cn_list = 0, cn_fold = 0, cn_over = 0;
 #endif
   for (int it = 0; it < iters; ++it) {
     const int U = s_cnt[cur];
@@ -425,6 +429,244 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
     const long long tp0 = __builtin_readcyclecounter();
 #endif
+    // Two Bid paths: many bidders -> four bidders per wave (throughput);
+    // few bidders -> one bidder per wave (shortest dependent chain).
+    if (U > kRowModeMin) {
+    // ---------------- Bid (emd_cuda.cu:95-179): one 16-lane ROW per bidder
+    // A bid touches ~16 cells and ~60 objects, so a 64-lane wave per bidder
+    // mostly waits on its own dependent instruction stream.  Four bidders per
+    // wave (one per 16-lane DPP row) run those streams side by side: row-wide
+    // reductions are 4 DPP steps, every lane keeps the exact top-2 of the
+    // candidates it evaluated, and the rows are merged once per bid.
+    {
+      const int row = lane >> 4, l16 = lane & 15;
+      const int rsh = row * 16;
+      unsigned short *wl = w_list[wave] + row * kRowListCap;
+      for (int ub = 0; ub < U; ub += kEmdWaves * 4) {
+        const int u = ub + wave * 4 + row;
+        const bool act = u < U;  // row-uniform
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
+        int4 rb = make_int4(0, -1, -1, 0);
+        if (act) {
+          if (u < kRecCap) {
+            ra = s_rq[cur][u];
+            rb = s_ri[cur][u];
+          } else {
+            const int jj = L[u];
+            ra = *reinterpret_cast<const float4 *>(&sc.person[jj]);
+            const int4 g = *(reinterpret_cast<const int4 *>(&sc.person[jj]) + 1);
+            rb = make_int4(jj, g.y, g.z, 0);
+          }
+        }
+        const int j = rb.x;
+        const float qx = ra.x, qy = ra.y, qz = ra.z;
+        const int p1 = rb.y, p2 = rb.z;
+        const int c0 = emd_cell(gg, qx, qy, qz);
+
+        // (1) seed: second-largest exact value among DISTINCT real objects --
+        // the home cell's members plus the previous best / second best when
+        // they live elsewhere (a valid lower bound of the final second best).
+        float tm;
+        {
+          float a1 = -1e9f, a2 = -1e9f;
+          const int s0 = c_start[c0], s1 = act ? c_start[c0 + 1] : s0;
+          for (int s = s0 + l16; __any(s < s1); s += 16) {
+            if (s < s1) {
+              const float4 o = sc.obj[s];
+              top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
+            }
+          }
+          bool extra = false;
+          if (act && ((l16 == 0 && p1 >= 0) || (l16 == 1 && p2 >= 0))) {
+            const float4 o = sc.obj[l16 == 0 ? p1 : p2];
+            if (emd_cell(gg, o.x, o.y, o.z) != c0) {
+              extra = true;
+              top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
+            }
+          }
+          const int have = (s1 - s0) + __builtin_popcountll((__ballot(extra) >> rsh) & 0xFFFFull);
+          if (act && have < 2) {  // row-uniform; rare: the first 16 slots (distinct objects)
+            const float4 o = sc.obj[l16];
+            a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
+            a2 = -1e9f;
+          }
+          top2_dpp_step<0xB1, 0xF>(a1, a2);   // butterfly inside the row:
+          top2_dpp_step<0x4E, 0xF>(a1, a2);   // every lane ends with the row's
+          top2_dpp_step<0x141, 0xF>(a1, a2);  // (largest, second largest)
+          top2_dpp_step<0x140, 0xF>(a1, a2);
+          tm = (3.0f - a2) + kMargin;
+        }
+
+        // exact top-2 of the candidates THIS LANE evaluates
+        float lb1 = -1e9f, lb2 = -1e9f;
+        int lbk = -1, lb2k = -1;
+        auto consider = [&](bool in_range, const float4 &o, int slot) {
+          const float sd = sqdist3(o.x - qx, o.y - qy, o.z - qz);
+          const float tq = tm - o.w;
+          const bool ps = in_range && tq >= 0.f && sd <= tq * tq;
+          if (__any(ps)) {
+            if (ps) {
+              const float v = emd_value(sd, o.w);
+              if (v > lb1) {
+                lb2 = lb1; lb2k = lbk; lb1 = v; lbk = slot;
+              } else if (v == lb1) {   // rare: reference order on ORIGINAL indices
+                lb2 = v;
+                if (emd_precedes(sc.perm[slot], sc.perm[lbk], n, tpu)) {
+                  lb2k = lbk; lbk = slot;
+                } else {
+                  lb2k = slot;
+                }
+              } else if (v > lb2) {
+                lb2 = v; lb2k = slot;
+              }
+            }
+          }
+        };
+
+        // (2) cells intersecting the cube |o - q|_inf <= tm (prices >= 0)
+        int ix0, iy0, iz0, nx, ny, nz;
+        {
+          const float r = tm * gg.invh + 1e-3f;  // slack covers index rounding
+          const float fx = (qx - gg.lox) * gg.invh;
+          const float fy = (qy - gg.loy) * gg.invh;
+          const float fz = (qz - gg.loz) * gg.invh;
+          const float gm = (float)(gg.g - 1);
+          ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
+          iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
+          iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
+          nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
+          ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
+          nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
+        }
+        const int nxy = nx * ny;
+        const int nsub_all = act ? nxy * nz : 0;
+        // approximate reciprocals suffice: (i + 0.5) / m is >= 0.5/144 away
+        // from an integer, far above the 1 ulp error of v_rcp_f32
+        const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
+        // search cube covers most of the grid (clustered prediction against a
+        // spread target): scan the cell-sorted objects linearly instead
+        const bool linear = act && 2 * nsub_all > ncell;
+        if (__any(linear)) {
+          for (int base = 0; base < n; base += 64) {   // n % 1024 == 0
+            float4 o[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              o[r4] = linear ? sc.obj[base + r4 * 16 + l16] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) consider(linear, o[r4], base + r4 * 16 + l16);
+          }
+        }
+        const int nsub = linear ? 0 : nsub_all;
+
+        // (3) visit the listed cells of this row, 4 per step (16 lanes each)
+        int nlist = 0;
+        auto visit = [&]() {
+          for (int k0 = 0; __any(k0 < nlist); k0 += 4) {
+            int s[4], s1[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int k = k0 + r4;
+              s[r4] = 0;
+              s1[r4] = 0;
+              if (k < nlist) {
+                const int cc = wl[k];
+                s[r4] = c_start[cc] + l16;
+                s1[r4] = c_start[cc + 1];
+              }
+            }
+            bool more = true;
+            while (more) {
+              float4 o[4];
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4)
+                o[r4] = s[r4] < s1[r4] ? sc.obj[s[r4]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) consider(s[r4] < s1[r4], o[r4], s[r4]);
+              bool mine = false;   // cells with more than 16 members: next 16
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                s[r4] += 16;
+                mine |= s[r4] < s1[r4];
+              }
+              more = __any(mine);
+            }
+          }
+          nlist = 0;
+        };
+        for (int cb = 0; __any(cb < nsub); cb += 16) {
+          const int i = cb + l16;
+          bool cpass = false;
+          int c = 0;
+          if (i < nsub) {
+            // exact small-integer division via float (i < 1728, divisors <= 144)
+            const int kz = (int)(((float)i + 0.5f) * inv_nxy);
+            const int rem = i - kz * nxy;
+            const int ky = (int)(((float)rem + 0.5f) * inv_nx);
+            const int kx = rem - ky * nx;
+            c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
+            const float dx = __builtin_fmaxf(__builtin_fmaxf(c_minx[c] - qx, qx - c_maxx[c]), 0.f);
+            const float dy = __builtin_fmaxf(__builtin_fmaxf(c_miny[c] - qy, qy - c_maxy[c]), 0.f);
+            const float dz = __builtin_fmaxf(__builtin_fmaxf(c_minz[c] - qz, qz - c_maxz[c]), 0.f);
+            const float tq = tm - c_pmin[c];
+            cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
+          }
+          const unsigned rmask = (unsigned)((__ballot(cpass) >> rsh) & 0xFFFFull);
+          if (cpass) wl[nlist + __builtin_popcount(rmask & ((1u << l16) - 1u))] = (unsigned short)c;
+          nlist += __builtin_popcount(rmask);
+          if (__any(nlist > kRowListCap - 16)) visit();  // keep room for the next 16
+        }
+        visit();
+
+        // (4) merge the 16 lanes of the row: exact best / second best with the
+        // reference's tie order (original object indices ride along)
+        int lo1 = lbk >= 0 ? sc.perm[lbk] : 0;
+        auto merge_step = [&](auto ctrl_tag) {
+          constexpr int CTRL = decltype(ctrl_tag)::value;
+          const float ob1 = dpp_f32<CTRL, 0xF>(-1e9f, lb1);
+          const float ob2 = dpp_f32<CTRL, 0xF>(-1e9f, lb2);
+          const int obk = __builtin_amdgcn_update_dpp(-1, lbk, CTRL, 0xF, 0xF, false);
+          const int ob2k = __builtin_amdgcn_update_dpp(-1, lb2k, CTRL, 0xF, 0xF, false);
+          const int oo1 = __builtin_amdgcn_update_dpp(0, lo1, CTRL, 0xF, 0xF, false);
+          const bool tie = ob1 == lb1 && obk >= 0 && lbk >= 0;
+          bool other_first = false;
+          if (__any(tie)) other_first = tie && emd_precedes(oo1, lo1, n, tpu);
+          const bool other_wins = ob1 > lb1 || other_first;
+          if (other_wins) {
+            const bool from_b1 = lb1 >= ob2;
+            lb2 = from_b1 ? lb1 : ob2;
+            lb2k = from_b1 ? lbk : ob2k;
+            lb1 = ob1; lbk = obk; lo1 = oo1;
+          } else {
+            const bool from_ob1 = ob1 >= lb2;
+            lb2k = from_ob1 ? obk : lb2k;
+            lb2 = from_ob1 ? ob1 : lb2;
+          }
+        };
+        merge_step(std::integral_constant<int, 0xB1>{});
+        merge_step(std::integral_constant<int, 0x4E>{});
+        merge_step(std::integral_constant<int, 0x141>{});
+        merge_step(std::integral_constant<int, 0x140>{});
+
+        if (act && lbk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
+          if (l16 == 0) s_err = 1;
+          lbk = 0;
+          lb2k = -1;
+        }
+        if (act && l16 == 0) {
+          const float inc = lb1 - lb2 + eps;
+          sc.person[j].bidinc = inc;
+          *(reinterpret_cast<int4 *>(&sc.person[j]) + 1) = make_int4(lbk, lbk, lb2k, 0);
+          if (u < kBidCache) {
+            s_bj[u] = j;
+            s_bo[u] = lbk;
+            s_b2k[u] = lb2k;
+            s_binc[u] = inc;
+          }
+          atomic_max_float(&sc.ostate[lbk].maxinc, inc);
+        }
+      }
+    }
+    } else {
     // ---------------- Bid (emd_cuda.cu:95-179): one wave per bidder
     // A bidder's record comes from the LDS cache (list position < kRecCap)
     // or, in the heavy early rounds, from global memory with the next
@@ -448,9 +690,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       const float qx = ra.x, qy = ra.y, qz = ra.z;
       const int p1 = rb.y, p2 = rb.z;
       load_rec(u + kEmdWaves);  // prefetch (consumed next iteration)
-#ifdef MVP_EMD_PROFILE
-      const long long q0 = __builtin_readcyclecounter();
-#endif
       const int c0 = emd_cell(gg, qx, qy, qz);
 
       // (1) seed: second-largest exact value among DISTINCT real objects --
@@ -487,9 +726,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         st.tm = (3.0f - seed_b2) + kMargin;
       }
 
-#ifdef MVP_EMD_PROFILE
-      const long long q1 = __builtin_readcyclecounter();
-#endif
       // (2) Only cells that intersect the cube |o - q|_inf <= tm can hold a
       // relevant object (prices are >= 0).  Enumerate that sub-box of the
       // grid 64 cells at a time and test each cell's exact bounding box and
@@ -553,9 +789,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               const bool ps = s[r] < s1[r] && tq >= 0.f && sd <= tq * tq;
               const unsigned long long m = __ballot(ps);
               if (m) emd_fold(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm);
-#ifdef MVP_EMD_PROFILE
-              cn_fold += __builtin_popcountll(m);
-#endif
             }
             // cells with more than 32 members (rare): next 32
             bool mine = false;
@@ -567,9 +800,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             more = __any(mine);
           }
         }
-#ifdef MVP_EMD_PROFILE
-        cn_list += nlist;
-#endif
         nlist = 0;
       };
       // When the search cube covers most of the grid (high prices everywhere,
@@ -613,16 +843,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         if (cpass)
           wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
         nlist += __builtin_popcountll(cmask);
-        if (nlist > kListCap - kWave) visit();  // keep room for the next 64
+        if (nlist > (4 * kRowListCap) - kWave) visit();  // keep room for the next 64
       }
-#ifdef MVP_EMD_PROFILE
-      cn_sub += nsub;
-      const long long q2 = __builtin_readcyclecounter();
-#endif
       visit();
-#ifdef MVP_EMD_PROFILE
-      const long long q3 = __builtin_readcyclecounter();
-#endif
       if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
         if (lane == 0) s_err = 1;
         st.bk = 0;
@@ -640,9 +863,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         }
         atomic_max_float(&sc.ostate[st.bk].maxinc, inc);
       }
-#ifdef MVP_EMD_PROFILE
-      { const long long q4 = __builtin_readcyclecounter(); cb_seed += q1 - q0; cb_cells += q2 - q1; cb_visit += q3 - q2; cb_write += q4 - q3; cb_n += 1; }
-#endif
+    }
     }
     if (t == 0) s_cnt[cur ^ 1] = 0;
     __syncthreads();
@@ -742,7 +963,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
     stats[0] = cyc_bid;
     stats[1] = (cyc_getmax << 32) | (cyc_assign & 0xffffffffll);
-    if (cloud == 0) printf("wave0 bids %lld: seed %lld cells %lld visit %lld write %lld cycles/bid | per bid: cells tested %.1f visited %.1f folds %.2f overflow-steps %.2f\n", cb_n, cb_seed / (cb_n ? cb_n : 1), cb_cells / (cb_n ? cb_n : 1), cb_visit / (cb_n ? cb_n : 1), cb_write / (cb_n ? cb_n : 1), (double)cn_sub / (cb_n ? cb_n : 1), (double)cn_list / (cb_n ? cb_n : 1), (double)cn_fold / (cb_n ? cb_n : 1), (double)cn_over / (cb_n ? cb_n : 1));
 #endif
   }
   // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
