@@ -912,7 +912,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           // the evicted owner bids again next round
           ass[prev] = -1;
           const int pos = atomicAdd(&s_cnt[nxt], 1);
-          Lnext[pos] = prev;
+          if (pos >= kRecCap) Lnext[pos] = prev;   // entries below kRecCap live in LDS only
           if (pos < kRecCap) {
             const float4 pa = *reinterpret_cast<const float4 *>(&sc.person[prev]);
             const int4 pb = *(reinterpret_cast<const int4 *>(&sc.person[prev]) + 1);
@@ -924,19 +924,23 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         sc.ostate[o].maxinc = __float_as_int(-1e9f);
         ass[j] = o;
         sc.obj[o].w = oo.w + bi;
-        // refresh the cell's price lower bound (racing refreshes of the same
-        // cell may leave a slightly stale -- still valid -- bound)
+        // The cell's price lower bound only needs a refresh when the object
+        // that just got dearer was (one of) the cheapest of its cell; then the
+        // members are re-scanned (racing refreshes of one cell may leave a
+        // slightly stale -- still valid -- bound).
         const int c = emd_cell(gg, oo.x, oo.y, oo.z);
-        float pm = oo.w + bi;
-        const int e1 = c_start[c + 1];
+        if (oo.w <= c_pmin[c]) {
+          float pm = oo.w + bi;
+          const int e1 = c_start[c + 1];
 #pragma unroll 8
-        for (int s = c_start[c]; s < e1; ++s)
-          pm = __builtin_fminf(pm, s == o ? pm : sc.obj[s].w);
-        c_pmin[c] = pm;
+          for (int s = c_start[c]; s < e1; ++s)
+            pm = __builtin_fminf(pm, s == o ? pm : sc.obj[s].w);
+          c_pmin[c] = pm;
+        }
       } else {
         // lost: stays in the list, record carried over through LDS
         const int pos = atomicAdd(&s_cnt[nxt], 1);
-        Lnext[pos] = j;
+        if (pos >= kRecCap) Lnext[pos] = j;
         if (pos < kRecCap) {
           float4 pa;
           if (u < kRecCap)
