@@ -18,18 +18,23 @@
 //     stored cell-sorted as float4 {x, y, z, price}.  Per cell the workgroup
 //     keeps in LDS the exact bounding box of its members and a lower bound of
 //     their prices (prices only rise, so a stale bound stays valid);
-//   * Bid = one wave per bidder.  A bid needs the best and
-//     second-best of  v_k = float(3.0 - (double)sqrtf(|q-o_k|^2) - price_k)
-//     (emd_cuda.cu:146) over all k.  Instead of evaluating all n objects the
-//     wave (1) seeds a lower bound B2 of the second-best value from the
-//     bidder's home cell and its previous two best objects, (2) tests all
-//     cells 64 at a time against  dist(q, box) + price_lb <= 3 - B2  and
-//     (3) visits only surviving cells, where each object first passes the
-//     same conservative test on its squared distance (no sqrt, no double);
-//     only objects that can still change {best, second best, best index} get
-//     the exact double-precision value and are folded into wave-uniform state.
-//     Every skip is provably lossless (kMargin below), so bids are
-//     bit-identical to the exhaustive scan;
+//   * Bid.  A bid needs the best and second-best of
+//         v_k = float(3.0 - (double)sqrtf(|q-o_k|^2) - price_k)     (emd_cuda.cu:146)
+//     over all k.  Instead of evaluating all n objects the bidder (1) seeds a
+//     lower bound B2 of the second-best value from its home cell and its
+//     previous two best objects, (2) tests only the cells intersecting the
+//     cube |o-q|_inf <= 3-B2 against  dist(q, box) + price_lb <= 3 - B2  and
+//     (3) visits only surviving cells, where each object first passes the same
+//     conservative test on its squared distance (no sqrt, no double); only
+//     objects that can still change {best, second best, best index} get the
+//     exact double-precision value.  Every skip is provably lossless (kMargin
+//     below), so bids are bit-identical to the exhaustive scan.  Two
+//     schedules share that logic: rounds with many bidders run FOUR bidders
+//     per wave (one per 16-lane DPP row; lane-local exact top-2, merged per
+//     row with DPP) for throughput; rounds with few bidders run one bidder
+//     per wave (wave-uniform state, scalar folds) for the shortest dependent
+//     chain.  A search cube that covers most of the grid falls back to a
+//     linear scan of the cell-sorted objects;
 //   * ties are resolved by the reference's own order, reconstructed from its
 //     thread partition (emd_cuda.cu:108-118,139-142,163-171): candidates are
 //     ordered by (chunk thread, 2048-tile, index in tile) of their ORIGINAL
@@ -42,11 +47,6 @@
 #include "common.h"
 
 namespace mvp {
-
-#ifndef MVP_EMD_STOP
-#define MVP_EMD_STOP 99
-#endif
-#define MVP_STAGE(k) do { if (MVP_EMD_STOP == (k)) { if (threadIdx.x == 0) { stats[0] = 1000 + (k); stats[1] = 0; } return; } } while (0)
 
 constexpr int kEmdThreads = 1024;
 constexpr int kEmdWaves = kEmdThreads / kWave;
@@ -317,7 +317,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     gg.invh = (float)g / ext;
   }
   const int ncell = gg.g * gg.g * gg.g;
-  MVP_STAGE(1);
 
   // (b) histogram
   for (int c = t; c < kMaxCells; c += kEmdThreads) s_tmp[c] = 0;
@@ -325,7 +324,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   for (int k = t; k < n; k += kEmdThreads)
     atomicAdd(&s_tmp[emd_cell(gg, xyz2[k * 3 + 0], xyz2[k * 3 + 1], xyz2[k * 3 + 2])], 1);
   __syncthreads();
-  MVP_STAGE(2);
   // (c) exclusive prefix sum over <= 1728 cells: 2 cells per thread
   {
     const int c0 = 2 * t, c1 = 2 * t + 1;
@@ -349,7 +347,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     if (c1 < kMaxCells) s_tmp[c1] = 0;
     __syncthreads();
   }
-  MVP_STAGE(3);
   // (d) scatter into cell-sorted order; initial state of emd_module.py:54-65
   for (int k = t; k < n; k += kEmdThreads) {
     const float x = xyz2[k * 3 + 0], y = xyz2[k * 3 + 1], z = xyz2[k * 3 + 2];
@@ -385,7 +382,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     s_err = 0;
   }
   __syncthreads();
-  MVP_STAGE(4);
   // (e) exact bounding box per cell; price lower bound 0
   for (int c = t; c < ncell; c += kEmdThreads) {
     float bx0 = __builtin_inff(), by0 = __builtin_inff(), bz0 = __builtin_inff();
@@ -405,7 +401,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   }
   __syncthreads();
 
-  MVP_STAGE(5);
   // ------------------------------------------------------------ the auction
   const int block_cnt = n / 1024;
   int cur = 0;
@@ -867,7 +862,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     }
     if (t == 0) s_cnt[cur ^ 1] = 0;
     __syncthreads();
-    MVP_STAGE(6);
 #ifdef MVP_EMD_PROFILE
     const long long tp1 = __builtin_readcyclecounter();
 #endif
@@ -887,7 +881,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         atomicMax(&sc.ostate[o].maxidx, tag | (unsigned long long)(unsigned)j);
     }
     __syncthreads();
-    MVP_STAGE(7);
 #ifdef MVP_EMD_PROFILE
     const long long tp2 = __builtin_readcyclecounter();
 #endif
@@ -953,7 +946,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       }
     }
     __syncthreads();
-    MVP_STAGE(8);
 #ifdef MVP_EMD_PROFILE
     const long long tp3 = __builtin_readcyclecounter();
     cyc_bid += tp1 - tp0; cyc_getmax += tp2 - tp1; cyc_assign += tp3 - tp2;
