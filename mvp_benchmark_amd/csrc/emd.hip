@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   int cur = 0;
   long long n_rounds = 0, n_bids = 0;
 #ifdef MVP_EMD_PROFILE
-  long long cyc_bid = 0, cyc_getmax = 0, cyc_assign = 0;
+  long long cyc_bid = 0, cyc_getmax = 0, cyc_assign = 0, cyc_bid_row = 0, n_row_rounds = 0, n_row_bids = 0;
 #endif
   for (int it = 0; it < iters; ++it) {
     const int U = s_cnt[cur];
@@ -949,6 +949,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
     const long long tp3 = __builtin_readcyclecounter();
     cyc_bid += tp1 - tp0; cyc_getmax += tp2 - tp1; cyc_assign += tp3 - tp2;
+    if (U > kRowModeMin) { cyc_bid_row += tp1 - tp0; n_row_rounds += 1; n_row_bids += U; }
 #endif
     cur ^= 1;
   }
@@ -959,6 +960,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
     stats[0] = cyc_bid;
     stats[1] = (cyc_getmax << 32) | (cyc_assign & 0xffffffffll);
+    if (cloud < 4) printf("cloud %d: rounds %lld bids %lld | row-mode rounds %lld bids %lld bid-cycles %lld | all bid-cycles %lld getmax %lld assign %lld\n", cloud, n_rounds, n_bids, n_row_rounds, n_row_bids, cyc_bid_row, cyc_bid, cyc_getmax, cyc_assign);
 #endif
   }
   // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
