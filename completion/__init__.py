@@ -1,0 +1,1 @@
+"""Completion harness (train.py / test.py entry points, models, cfgs)."""

@@ -1,0 +1,1 @@
+"""YAML configurations of the completion entry points."""

@@ -1,0 +1,1 @@
+"""Completion networks: pcn, ecg, vrcnet (train.py imports `models.<model_name>`)."""

@@ -1,0 +1,37 @@
+"""Pieces shared by the three completion networks: layer factories and the
+loss / metric tail of Model.forward (identical in the reference's pcn.py
+:93-112, ecg.py:233-253 and vrcnet.py:519-526, restated once here)."""
+import torch.nn as nn
+
+from model_utils import calc_cd, calc_emd
+
+
+def pointwise1d(c_in, c_out, bias=True):
+    """Per-point linear map on (B, C, N) features."""
+    return nn.Conv1d(c_in, c_out, kernel_size=1, bias=bias)
+
+
+def pointwise2d(c_in, c_out, bias=True):
+    """Per-edge linear map on (B, C, N, k) / (B, C, 1, N) features."""
+    return nn.Conv2d(c_in, c_out, kernel_size=1, bias=bias)
+
+
+dense = nn.Linear
+
+
+def shape_loss(kind, pred, gt):
+    """Per-cloud training loss (B,): 'cd' -> cd_p of calc_cd, 'emd' -> calc_emd
+    at the training setting (eps 0.005, 50 iterations)."""
+    if kind == 'cd':
+        return calc_cd(pred, gt)[0]
+    if kind == 'emd':
+        return calc_emd(pred, gt)
+    raise NotImplementedError('Train loss is either CD or EMD!')
+
+
+def eval_outputs(coarse, fine, gt, eval_emd):
+    """prefix == "val": the metric dictionary train.py / test.py consume.  EMD
+    runs at the evaluation setting (eps 0.004, 3000 iterations) when enabled."""
+    emd = calc_emd(fine, gt, eps=0.004, iterations=3000) if eval_emd else 0
+    cd_p, cd_t, f1 = calc_cd(fine, gt, calc_f1=True)
+    return {'out1': coarse, 'out2': fine, 'emd': emd, 'cd_p': cd_p, 'cd_t': cd_t, 'f1': f1}

@@ -1,0 +1,129 @@
+"""Edge-feature encoder of ECG: dense edge convolutions (Stack_conv,
+Dense_conv) and the 4-level U-Net built from them (EF_encoder).  Counterparts:
+reference completion/models/ecg.py:21-33, :36-65, :68-158; sub-module names
+are kept so checkpoints interchange.  Split out of ecg.py, which keeps the
+decoder and the Model.
+
+Op-layer calls per encoder forward: kNN graphs inside get_graph_feature, FPS +
+gather + group inside edge_preserve_sampling (3072 -> 1024 -> 256 -> 64 points
+at the default cfg), three_nn + three_interpolate back up.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from model_utils import edge_preserve_sampling, get_graph_feature, three_nn_upsampling
+from mm3d_pn2 import three_interpolate
+from models._common import dense, pointwise1d, pointwise2d
+
+
+class Stack_conv(nn.Module):
+    """1x1 conv whose output is concatenated BEHIND its input (dense growth)."""
+
+    def __init__(self, input_size, output_size, act=None):
+        super().__init__()
+        self.model = nn.Sequential()
+        self.model.add_module('conv', pointwise2d(input_size, output_size))
+        if act is not None:
+            self.model.add_module('act', act)
+
+    def forward(self, x):
+        return torch.cat((x, self.model(x)), 1)
+
+
+class Dense_conv(nn.Module):
+    """DenseNet-style edge convolution: kNN edge features -> first_conv ->
+    (dense_n - 1) Stack_conv layers -> max over the k neighbours.
+    Output channels: input_size + growth_rate * dense_n."""
+
+    def __init__(self, input_size, growth_rate=64, dense_n=3, k=16):
+        super().__init__()
+        self.growth_rate = growth_rate
+        self.dense_n = dense_n
+        self.k = k
+        self.comp = growth_rate * 2
+        self.input_size = input_size
+
+        self.first_conv = pointwise2d(input_size * 2, growth_rate)
+        width = input_size + growth_rate
+        self.model = nn.Sequential()
+        for i in range(1, dense_n):
+            last = i == dense_n - 1
+            self.model.add_module('stack_conv_%d' % i,
+                                  Stack_conv(width, growth_rate, None if last else nn.ReLU()))
+            width += growth_rate
+        self.input_size = width - growth_rate if dense_n > 1 else width
+
+    def forward(self, x):
+        edge = F.relu(self.first_conv(get_graph_feature(x, k=self.k)))        # (B, g, N, k)
+        edge = torch.cat((edge, x.unsqueeze(3).expand(-1, -1, -1, self.k)), 1)
+        return self.model(edge).max(dim=3)[0]
+
+
+class EF_encoder(nn.Module):
+    """4-level edge-feature U-Net over the point cloud: dense edge convs on
+    the way down (edge-preserved FPS pooling), three_nn interpolation on the
+    way up, skip connections at every level."""
+
+    def __init__(self, growth_rate=24, dense_n=3, k=16, hierarchy=[1024, 256, 64], input_size=3, output_size=256):
+        super().__init__()
+        self.growth_rate = growth_rate
+        self.comp = growth_rate * 2
+        self.dense_n = dense_n
+        self.k = k
+        self.hierarchy = hierarchy
+        self.init_channel = 24
+        grow = growth_rate * dense_n
+
+        self.conv1 = pointwise1d(input_size, self.init_channel)
+        self.dense_conv1 = Dense_conv(self.init_channel, growth_rate, dense_n, k)
+        c1 = self.init_channel * 2 + grow                      # 120
+
+        self.conv2 = pointwise1d(c1 * 2, self.comp)
+        self.dense_conv2 = Dense_conv(self.comp, growth_rate, dense_n, k)
+        c2 = c1 * 2 + self.comp + grow                         # 360
+
+        self.conv3 = pointwise1d(c2 * 2, self.comp)
+        self.dense_conv3 = Dense_conv(self.comp, growth_rate, dense_n, k)
+        c3 = c2 * 2 + self.comp + grow                         # 840
+
+        self.conv4 = pointwise1d(c3 * 2, self.comp)
+        self.dense_conv4 = Dense_conv(self.comp, growth_rate, dense_n, k)
+        c4 = c3 * 2 + self.comp + grow                         # 1800
+
+        self.gf_conv = pointwise1d(c4, 1024)
+        self.fc1 = dense(1024, 512)
+        self.fc2 = dense(512, 1024)
+
+        self.conv5 = pointwise1d(c4 + 1024, 1024)
+        self.conv6 = pointwise1d(c3 + 1024, 768)
+        self.conv7 = pointwise1d(c2 + 768, 512)
+        self.conv8 = pointwise1d(c1 + 512, output_size)
+
+    def forward(self, x):
+        pts = [x[:, 0:3, :].transpose(1, 2).contiguous()]       # level-0 coordinates (B,N,3)
+
+        # ---- down: level features f[l] (before pooling), pooled inputs
+        x0 = F.relu(self.conv1(x))
+        f = [torch.cat((F.relu(self.dense_conv1(x0)), x0), 1)]  # 120 channels
+        squeeze = [self.conv2, self.conv3, self.conv4]
+        dense = [self.dense_conv2, self.dense_conv3, self.dense_conv4]
+        for level in range(3):
+            pooled, _, _, p_next = edge_preserve_sampling(f[level], pts[level], self.hierarchy[level], self.k)
+            pts.append(p_next)
+            y = F.relu(dense[level](F.relu(squeeze[level](pooled))))
+            f.append(torch.cat((y, pooled), 1))
+
+        # ---- bottleneck: global feature broadcast back onto the coarsest level
+        g = self.gf_conv(f[3]).max(dim=-1)[0]
+        g = F.relu(self.fc2(F.relu(self.fc1(g)))).unsqueeze(2).expand(-1, -1, self.hierarchy[2])
+        up = F.relu(self.conv5(torch.cat((g, f[3]), 1)))
+
+        # ---- up: interpolate to the finer level, fuse with its skip features
+        for level, conv in ((2, self.conv6), (1, self.conv7)):
+            idx, weight = three_nn_upsampling(pts[level], pts[level + 1])
+            up = three_interpolate(up.contiguous(), idx, weight)
+            up = F.relu(conv(torch.cat((f[level], up), 1)))
+        idx, weight = three_nn_upsampling(pts[0], pts[1])
+        up = three_interpolate(up.contiguous(), idx, weight)
+        return self.conv8(torch.cat((f[0], up), 1))

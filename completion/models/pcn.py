@@ -14,7 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from model_utils import gen_grid_up, calc_emd, calc_cd
+from model_utils import gen_grid_up
+from models._common import dense, eval_outputs, pointwise1d, shape_loss
 
 
 class PCN_encoder(nn.Module):
@@ -22,11 +23,11 @@ class PCN_encoder(nn.Module):
     per-point MLP -> global max."""
 
     def __init__(self, output_size=1024):
-        super(PCN_encoder, self).__init__()
-        self.conv1 = nn.Conv1d(3, 128, 1)
-        self.conv2 = nn.Conv1d(128, 256, 1)
-        self.conv3 = nn.Conv1d(512, 512, 1)
-        self.conv4 = nn.Conv1d(512, output_size, 1)
+        super().__init__()
+        self.conv1 = pointwise1d(3, 128)
+        self.conv2 = pointwise1d(128, 256)
+        self.conv3 = pointwise1d(512, 512)
+        self.conv4 = pointwise1d(512, output_size)
 
     def forward(self, x):
         num_points = x.size(2)
@@ -41,20 +42,20 @@ class PCN_decoder(nn.Module):
     grid around every coarse point."""
 
     def __init__(self, num_coarse, num_fine, scale, cat_feature_num):
-        super(PCN_decoder, self).__init__()
+        super().__init__()
         self.num_coarse = num_coarse
         self.num_fine = num_fine
         self.scale = scale
-        self.fc1 = nn.Linear(1024, 1024)
-        self.fc2 = nn.Linear(1024, 1024)
-        self.fc3 = nn.Linear(1024, num_coarse * 3)
+        self.fc1 = dense(1024, 1024)
+        self.fc2 = dense(1024, 1024)
+        self.fc3 = dense(1024, num_coarse * 3)
         # (2, scale) folding grid; not part of the checkpoint (the reference
         # keeps it as a plain attribute)
         self.register_buffer("grid", gen_grid_up(2 ** (int(math.log2(scale))), 0.05).contiguous(),
                              persistent=False)
-        self.conv1 = nn.Conv1d(cat_feature_num, 512, 1)
-        self.conv2 = nn.Conv1d(512, 512, 1)
-        self.conv3 = nn.Conv1d(512, 3, 1)
+        self.conv1 = pointwise1d(cat_feature_num, 512)
+        self.conv2 = pointwise1d(512, 512)
+        self.conv3 = pointwise1d(512, 3)
 
     def forward(self, x):
         batch_size = x.size(0)
@@ -72,7 +73,7 @@ class PCN_decoder(nn.Module):
 
 class Model(nn.Module):
     def __init__(self, args, num_coarse=1024):
-        super(Model, self).__init__()
+        super().__init__()
         self.num_coarse = num_coarse
         self.num_points = args.num_points
         self.train_loss = args.loss
@@ -89,18 +90,9 @@ class Model(nn.Module):
         out2 = out2.transpose(1, 2).contiguous()
 
         if prefix == "train":
-            if self.train_loss == 'emd':
-                loss1 = calc_emd(out1, gt)
-                loss2 = calc_emd(out2, gt)
-            elif self.train_loss == 'cd':
-                loss1, _ = calc_cd(out1, gt)
-                loss2, _ = calc_cd(out2, gt)
-            else:
-                raise NotImplementedError('Train loss is either CD or EMD!')
-            total_train_loss = loss1.mean() + loss2.mean() * alpha
-            return out2, loss2, total_train_loss
+            loss_coarse = shape_loss(self.train_loss, out1, gt)
+            loss_fine = shape_loss(self.train_loss, out2, gt)
+            return out2, loss_fine, loss_coarse.mean() + loss_fine.mean() * alpha
         if prefix == "val":
-            emd = calc_emd(out2, gt, eps=0.004, iterations=3000) if self.eval_emd else 0
-            cd_p, cd_t, f1 = calc_cd(out2, gt, calc_f1=True)
-            return {'out1': out1, 'out2': out2, 'emd': emd, 'cd_p': cd_p, 'cd_t': cd_t, 'f1': f1}
+            return eval_outputs(out1, out2, gt, self.eval_emd)
         return {'result': out2}

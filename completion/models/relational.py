@@ -1,0 +1,167 @@
+"""Relational encoder of VRCNet: point self-attention (SA_module), its
+selective-kernel fusion over several neighbourhood sizes (SK_SA_module), the
+residual unit built from them (SKN_Res_unit) and the 4-level U-Net that stacks
+the units between edge-preserved pooling and three_nn un-pooling
+(SA_SKN_Res_encoder).  Counterparts: reference completion/models/vrcnet.py
+:21-57, :107-152, :155-173, :176-298; sub-module names are kept so checkpoints
+interchange.  Split out of vrcnet.py, which keeps the decoder and the
+variational Model.
+
+Op-layer calls per encoder forward: kNN graphs (model_utils.knn) at the four
+resolutions, FPS + gather + group inside edge_preserve_sampling on the way
+down, three_nn + three_interpolate on the way up.
+"""
+import torch
+import torch.nn as nn
+
+from model_utils import edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling
+from mm3d_pn2 import three_interpolate
+from models._common import dense, pointwise2d
+
+
+class SA_module(nn.Module):
+    """Point self-attention over a fixed kNN graph: relation features of the
+    centre and its k neighbours produce per-neighbour weights (shared across
+    `share_planes` channel groups) that aggregate the neighbours' values."""
+
+    def __init__(self, in_planes, rel_planes, mid_planes, out_planes, share_planes=8, k=16):
+        super().__init__()
+        self.share_planes = share_planes
+        self.k = k
+        self.conv1 = pointwise2d(in_planes, rel_planes)
+        self.conv2 = pointwise2d(in_planes, rel_planes)
+        self.conv3 = pointwise2d(in_planes, mid_planes)
+        self.conv_w = nn.Sequential(
+            nn.ReLU(inplace=False),
+            pointwise2d(rel_planes * (k + 1), mid_planes // share_planes, bias=False),
+            nn.ReLU(inplace=False),
+            pointwise2d(mid_planes // share_planes, k * mid_planes // share_planes))
+        self.activation_fn = nn.ReLU(inplace=False)
+        self.conv_out = pointwise2d(mid_planes, out_planes)
+
+    def forward(self, input):
+        x, idx = input                                   # x: (B, C, 1, N), idx: (B, N, k)
+        batch_size, _, _, num_points = x.size()
+        act = self.activation_fn(x)
+        nbr = get_edge_features(act, idx)                # (B, C, k, N)
+        query = self.conv1(act)                          # (B, r, 1, N)
+        keys = self.conv2(nbr).reshape(batch_size, -1, 1, num_points)    # (B, k*r, 1, N)
+        values = self.conv3(nbr)                         # (B, mid, k, N)
+
+        w = self.conv_w(torch.cat([query, keys], 1)).view(batch_size, -1, self.k, num_points)
+        w = w.repeat(1, self.share_planes, 1, 1)         # (B, mid, k, N)
+        out = (w * values).sum(dim=2, keepdim=True)
+        out = self.conv_out(self.activation_fn(out))     # (B, C_out, 1, N)
+        return [out + x, idx]
+
+
+class SK_SA_module(nn.Module):
+    """Selective-kernel fusion of several SA_modules with different k."""
+
+    def __init__(self, in_planes, rel_planes, mid_planes, out_planes, share_planes=8, k=[10, 20], r=2, L=32):
+        super().__init__()
+        self.num_kernels = len(k)
+        d = max(int(out_planes / r), L)
+        self.sams = nn.ModuleList(
+            [SA_module(in_planes, rel_planes, mid_planes, out_planes, share_planes, kk) for kk in k])
+        self.fc = dense(out_planes, d)
+        self.fcs = nn.ModuleList([dense(d, out_planes) for _ in k])
+        self.softmax = nn.Softmax(dim=1)
+        self.af = nn.ReLU(inplace=False)
+
+    def forward(self, input):
+        x, idxs = input
+        assert self.num_kernels == len(idxs)
+        feas = torch.stack([self.af(sam([x, idx])[0]) for sam, idx in zip(self.sams, idxs)], dim=1)
+        fea_z = self.fc(feas.sum(dim=1).mean(-1).mean(-1))                       # (B, d)
+        attention = self.softmax(torch.stack([fc(fea_z) for fc in self.fcs], dim=1))   # (B, K, C)
+        fea_v = (feas * attention.unsqueeze(-1).unsqueeze(-1)).sum(dim=1)
+        return [fea_v, idxs]
+
+
+class SKN_Res_unit(nn.Module):
+    def __init__(self, input_size, output_size, k=[10, 20], layers=1):
+        super().__init__()
+        self.conv1 = pointwise2d(input_size, output_size, bias=False)
+        self.sam = self._make_layer(output_size, output_size // 16, output_size // 4, output_size, int(layers), 8, k=k)
+        self.conv2 = pointwise2d(output_size, output_size, bias=False)
+        self.conv_res = pointwise2d(input_size, output_size, bias=False)
+        self.af = nn.ReLU(inplace=False)
+
+    def _make_layer(self, in_planes, rel_planes, mid_planes, out_planes, blocks, share_planes=8, k=16):
+        return nn.Sequential(*[SK_SA_module(in_planes, rel_planes, mid_planes, out_planes, share_planes, k)
+                               for _ in range(blocks)])
+
+    def forward(self, feat, idx):
+        x, _ = self.sam([self.conv1(feat), idx])
+        return self.conv2(self.af(x)) + self.conv_res(feat)
+
+
+class SA_SKN_Res_encoder(nn.Module):
+    """4-level relational U-Net: SKN residual units on kNN graphs, edge-preserved
+    FPS pooling down, three_nn interpolation up."""
+
+    def __init__(self, input_size=3, k=[10, 20], pk=16, output_size=64, layers=[2, 2, 2, 2],
+                 pts_num=[3072, 1536, 768, 384]):
+        super().__init__()
+        self.init_channel = 64
+        c1 = self.init_channel
+        c2, c3, c4 = c1 * 2, c1 * 4, c1 * 8
+        self.sam_res1 = SKN_Res_unit(input_size, c1, k, int(layers[0]))
+        self.sam_res2 = SKN_Res_unit(c2, c2, k, int(layers[1]))
+        self.sam_res3 = SKN_Res_unit(c3, c3, k, int(layers[2]))
+        self.sam_res4 = SKN_Res_unit(c4, c4, k, int(layers[3]))
+
+        self.conv5 = pointwise2d(c4, 1024)
+        self.fc1 = dense(1024, 512)
+        self.fc2 = dense(512, 1024)
+
+        self.conv6 = pointwise2d(c4 + 1024, c4)
+        self.conv7 = pointwise2d(c3 + c4, c3)
+        self.conv8 = pointwise2d(c2 + c3, c2)
+        self.conv9 = pointwise2d(c1 + c2, c1)
+
+        self.conv_out = pointwise2d(c1, output_size)
+        self.dropout = nn.Dropout()
+        self.af = nn.ReLU(inplace=False)
+        self.k = k
+        self.pk = pk
+        self.rate = 2
+        self.pts_num = pts_num
+
+    def _graphs(self, pts_bcn):
+        """kNN index lists (one per k) of a (B, 3, N) cloud."""
+        return [knn(pts_bcn, kk) for kk in self.k]
+
+    def _edge_pooling(self, features, points, rate=2, k=16, sample_num=None):
+        features = features.squeeze(2)
+        if sample_num is None:
+            sample_num = int(features.size(2)) // rate
+        ds_features, p_idx, pn_idx, ds_points = edge_preserve_sampling(features.contiguous(), points, sample_num, k)
+        return ds_features.unsqueeze(2), p_idx, pn_idx, ds_points
+
+    def _edge_unpooling(self, features, src_pts, tgt_pts):
+        idx, weight = three_nn_upsampling(tgt_pts, src_pts)
+        return three_interpolate(features.squeeze(2).contiguous(), idx, weight).unsqueeze(2)
+
+    def forward(self, features):
+        batch_size = features.size(0)
+        xyz = features[:, 0:3, :]
+        pts = [xyz.transpose(1, 2).contiguous()]                   # (B, N, 3) per level
+        units = [self.sam_res1, self.sam_res2, self.sam_res3, self.sam_res4]
+
+        skips = [self.af(units[0](features.unsqueeze(2), self._graphs(xyz)))]
+        for level in range(1, 4):
+            x, _, _, p = self._edge_pooling(skips[-1], pts[-1], self.rate, self.pk, self.pts_num[level])
+            pts.append(p)
+            skips.append(self.af(units[level](x, self._graphs(p.transpose(1, 2).contiguous()))))
+
+        g = self.conv5(skips[3]).max(dim=-1)[0].view(batch_size, -1)
+        g = self.dropout(self.af(self.fc2(self.dropout(self.af(self.fc1(g))))))
+        g = g.unsqueeze(2).expand(-1, -1, self.pts_num[3]).unsqueeze(2)
+
+        x = self.af(self.conv6(torch.cat([g, skips[3]], 1)))
+        for level, conv in ((2, self.conv7), (1, self.conv8), (0, self.conv9)):
+            x = self._edge_unpooling(x, pts[level + 1], pts[level])
+            x = self.af(conv(torch.cat([x, skips[level]], 1)))
+        return self.conv_out(x).squeeze(2)

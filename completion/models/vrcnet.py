@@ -16,47 +16,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from model_utils import (EF_expansion, calc_cd, calc_emd, edge_preserve_sampling,
-                         furthest_point_sample, gather_points, gen_grid_up, get_edge_features, knn,
-                         three_nn_upsampling)
-from mm3d_pn2 import three_interpolate
+from model_utils import EF_expansion, calc_cd, furthest_point_sample, gather_points, gen_grid_up
+from models._common import dense, eval_outputs, pointwise1d
 from models.pcn import PCN_encoder
-
-
-class SA_module(nn.Module):
-    """Point self-attention over a fixed kNN graph: relation features of the
-    centre and its k neighbours produce per-neighbour weights (shared across
-    `share_planes` channel groups) that aggregate the neighbours' values."""
-
-    def __init__(self, in_planes, rel_planes, mid_planes, out_planes, share_planes=8, k=16):
-        super(SA_module, self).__init__()
-        self.share_planes = share_planes
-        self.k = k
-        self.conv1 = nn.Conv2d(in_planes, rel_planes, kernel_size=1)
-        self.conv2 = nn.Conv2d(in_planes, rel_planes, kernel_size=1)
-        self.conv3 = nn.Conv2d(in_planes, mid_planes, kernel_size=1)
-        self.conv_w = nn.Sequential(
-            nn.ReLU(inplace=False),
-            nn.Conv2d(rel_planes * (k + 1), mid_planes // share_planes, kernel_size=1, bias=False),
-            nn.ReLU(inplace=False),
-            nn.Conv2d(mid_planes // share_planes, k * mid_planes // share_planes, kernel_size=1))
-        self.activation_fn = nn.ReLU(inplace=False)
-        self.conv_out = nn.Conv2d(mid_planes, out_planes, kernel_size=1)
-
-    def forward(self, input):
-        x, idx = input                                   # x: (B, C, 1, N), idx: (B, N, k)
-        batch_size, _, _, num_points = x.size()
-        act = self.activation_fn(x)
-        nbr = get_edge_features(act, idx)                # (B, C, k, N)
-        query = self.conv1(act)                          # (B, r, 1, N)
-        keys = self.conv2(nbr).reshape(batch_size, -1, 1, num_points)    # (B, k*r, 1, N)
-        values = self.conv3(nbr)                         # (B, mid, k, N)
-
-        w = self.conv_w(torch.cat([query, keys], 1)).view(batch_size, -1, self.k, num_points)
-        w = w.repeat(1, self.share_planes, 1, 1)         # (B, mid, k, N)
-        out = (w * values).sum(dim=2, keepdim=True)
-        out = self.conv_out(self.activation_fn(out))     # (B, C_out, 1, N)
-        return [out + x, idx]
+from models.relational import SA_module, SA_SKN_Res_encoder, SK_SA_module, SKN_Res_unit  # noqa: F401
 
 
 class Folding(nn.Module):
@@ -64,12 +27,12 @@ class Folding(nn.Module):
     concatenated with the global feature and a small 2-D grid."""
 
     def __init__(self, input_size, output_size, step_ratio, global_feature_size=1024, num_models=1):
-        super(Folding, self).__init__()
+        super().__init__()
         self.input_size = input_size
         self.output_size = output_size
         self.step_ratio = step_ratio
         self.num_models = num_models
-        self.conv = nn.Conv1d(input_size + global_feature_size + 2, output_size, 1, bias=True)
+        self.conv = pointwise1d(input_size + global_feature_size + 2, output_size, bias=True)
         # (step_ratio, 2) grid over [-0.2, 0.2]^2; plain attribute as in the
         # reference (not part of the checkpoint)
         self.grid = gen_grid_up(step_ratio, 0.2).transpose(0, 1).contiguous()
@@ -86,126 +49,14 @@ class Folding(nn.Module):
 
 class Linear_ResBlock(nn.Module):
     def __init__(self, input_size=1024, output_size=256):
-        super(Linear_ResBlock, self).__init__()
-        self.conv1 = nn.Linear(input_size, input_size)
-        self.conv2 = nn.Linear(input_size, output_size)
-        self.conv_res = nn.Linear(input_size, output_size)
+        super().__init__()
+        self.conv1 = dense(input_size, input_size)
+        self.conv2 = dense(input_size, output_size)
+        self.conv_res = dense(input_size, output_size)
         self.af = nn.ReLU(inplace=False)
 
     def forward(self, feature):
         return self.conv2(self.af(self.conv1(self.af(feature)))) + self.conv_res(feature)
-
-
-class SK_SA_module(nn.Module):
-    """Selective-kernel fusion of several SA_modules with different k."""
-
-    def __init__(self, in_planes, rel_planes, mid_planes, out_planes, share_planes=8, k=[10, 20], r=2, L=32):
-        super(SK_SA_module, self).__init__()
-        self.num_kernels = len(k)
-        d = max(int(out_planes / r), L)
-        self.sams = nn.ModuleList(
-            [SA_module(in_planes, rel_planes, mid_planes, out_planes, share_planes, kk) for kk in k])
-        self.fc = nn.Linear(out_planes, d)
-        self.fcs = nn.ModuleList([nn.Linear(d, out_planes) for _ in k])
-        self.softmax = nn.Softmax(dim=1)
-        self.af = nn.ReLU(inplace=False)
-
-    def forward(self, input):
-        x, idxs = input
-        assert self.num_kernels == len(idxs)
-        feas = torch.stack([self.af(sam([x, idx])[0]) for sam, idx in zip(self.sams, idxs)], dim=1)
-        fea_z = self.fc(feas.sum(dim=1).mean(-1).mean(-1))                       # (B, d)
-        attention = self.softmax(torch.stack([fc(fea_z) for fc in self.fcs], dim=1))   # (B, K, C)
-        fea_v = (feas * attention.unsqueeze(-1).unsqueeze(-1)).sum(dim=1)
-        return [fea_v, idxs]
-
-
-class SKN_Res_unit(nn.Module):
-    def __init__(self, input_size, output_size, k=[10, 20], layers=1):
-        super(SKN_Res_unit, self).__init__()
-        self.conv1 = nn.Conv2d(input_size, output_size, 1, bias=False)
-        self.sam = self._make_layer(output_size, output_size // 16, output_size // 4, output_size, int(layers), 8, k=k)
-        self.conv2 = nn.Conv2d(output_size, output_size, 1, bias=False)
-        self.conv_res = nn.Conv2d(input_size, output_size, 1, bias=False)
-        self.af = nn.ReLU(inplace=False)
-
-    def _make_layer(self, in_planes, rel_planes, mid_planes, out_planes, blocks, share_planes=8, k=16):
-        return nn.Sequential(*[SK_SA_module(in_planes, rel_planes, mid_planes, out_planes, share_planes, k)
-                               for _ in range(blocks)])
-
-    def forward(self, feat, idx):
-        x, _ = self.sam([self.conv1(feat), idx])
-        return self.conv2(self.af(x)) + self.conv_res(feat)
-
-
-class SA_SKN_Res_encoder(nn.Module):
-    """4-level relational U-Net: SKN residual units on kNN graphs, edge-preserved
-    FPS pooling down, three_nn interpolation up."""
-
-    def __init__(self, input_size=3, k=[10, 20], pk=16, output_size=64, layers=[2, 2, 2, 2],
-                 pts_num=[3072, 1536, 768, 384]):
-        super(SA_SKN_Res_encoder, self).__init__()
-        self.init_channel = 64
-        c1 = self.init_channel
-        c2, c3, c4 = c1 * 2, c1 * 4, c1 * 8
-        self.sam_res1 = SKN_Res_unit(input_size, c1, k, int(layers[0]))
-        self.sam_res2 = SKN_Res_unit(c2, c2, k, int(layers[1]))
-        self.sam_res3 = SKN_Res_unit(c3, c3, k, int(layers[2]))
-        self.sam_res4 = SKN_Res_unit(c4, c4, k, int(layers[3]))
-
-        self.conv5 = nn.Conv2d(c4, 1024, 1)
-        self.fc1 = nn.Linear(1024, 512)
-        self.fc2 = nn.Linear(512, 1024)
-
-        self.conv6 = nn.Conv2d(c4 + 1024, c4, 1)
-        self.conv7 = nn.Conv2d(c3 + c4, c3, 1)
-        self.conv8 = nn.Conv2d(c2 + c3, c2, 1)
-        self.conv9 = nn.Conv2d(c1 + c2, c1, 1)
-
-        self.conv_out = nn.Conv2d(c1, output_size, 1)
-        self.dropout = nn.Dropout()
-        self.af = nn.ReLU(inplace=False)
-        self.k = k
-        self.pk = pk
-        self.rate = 2
-        self.pts_num = pts_num
-
-    def _graphs(self, pts_bcn):
-        """kNN index lists (one per k) of a (B, 3, N) cloud."""
-        return [knn(pts_bcn, kk) for kk in self.k]
-
-    def _edge_pooling(self, features, points, rate=2, k=16, sample_num=None):
-        features = features.squeeze(2)
-        if sample_num is None:
-            sample_num = int(features.size(2)) // rate
-        ds_features, p_idx, pn_idx, ds_points = edge_preserve_sampling(features.contiguous(), points, sample_num, k)
-        return ds_features.unsqueeze(2), p_idx, pn_idx, ds_points
-
-    def _edge_unpooling(self, features, src_pts, tgt_pts):
-        idx, weight = three_nn_upsampling(tgt_pts, src_pts)
-        return three_interpolate(features.squeeze(2).contiguous(), idx, weight).unsqueeze(2)
-
-    def forward(self, features):
-        batch_size = features.size(0)
-        xyz = features[:, 0:3, :]
-        pts = [xyz.transpose(1, 2).contiguous()]                   # (B, N, 3) per level
-        units = [self.sam_res1, self.sam_res2, self.sam_res3, self.sam_res4]
-
-        skips = [self.af(units[0](features.unsqueeze(2), self._graphs(xyz)))]
-        for level in range(1, 4):
-            x, _, _, p = self._edge_pooling(skips[-1], pts[-1], self.rate, self.pk, self.pts_num[level])
-            pts.append(p)
-            skips.append(self.af(units[level](x, self._graphs(p.transpose(1, 2).contiguous()))))
-
-        g = self.conv5(skips[3]).max(dim=-1)[0].view(batch_size, -1)
-        g = self.dropout(self.af(self.fc2(self.dropout(self.af(self.fc1(g))))))
-        g = g.unsqueeze(2).expand(-1, -1, self.pts_num[3]).unsqueeze(2)
-
-        x = self.af(self.conv6(torch.cat([g, skips[3]], 1)))
-        for level, conv in ((2, self.conv7), (1, self.conv8), (0, self.conv9)):
-            x = self._edge_unpooling(x, pts[level + 1], pts[level])
-            x = self.af(conv(torch.cat([x, skips[level]], 1)))
-        return self.conv_out(x).squeeze(2)
 
 
 class MSAP_SKN_decoder(nn.Module):
@@ -215,7 +66,7 @@ class MSAP_SKN_decoder(nn.Module):
 
     def __init__(self, num_coarse_raw, num_fps, num_coarse, num_fine, layers=[2, 2, 2, 2], knn_list=[10, 20], pk=10,
                  points_label=False, local_folding=False):
-        super(MSAP_SKN_decoder, self).__init__()
+        super().__init__()
         self.num_coarse_raw = num_coarse_raw
         self.num_fps = num_fps
         self.num_coarse = num_coarse
@@ -223,9 +74,9 @@ class MSAP_SKN_decoder(nn.Module):
         self.points_label = points_label
         self.local_folding = local_folding
 
-        self.fc1 = nn.Linear(1024, 1024)
-        self.fc2 = nn.Linear(1024, 1024)
-        self.fc3 = nn.Linear(1024, num_coarse_raw * 3)
+        self.fc1 = dense(1024, 1024)
+        self.fc2 = dense(1024, 1024)
+        self.fc3 = dense(1024, num_coarse_raw * 3)
 
         self.dense_feature_size = 256
         self.expand_feature_size = 64
@@ -238,15 +89,15 @@ class MSAP_SKN_decoder(nn.Module):
         if self.up_scale >= 2:
             self.expansion1 = EF_expansion(input_size=self.dense_feature_size, output_size=self.expand_feature_size,
                                            step_ratio=self.up_scale, k=4)
-            self.conv_cup1 = nn.Conv1d(self.expand_feature_size, self.expand_feature_size, 1)
+            self.conv_cup1 = pointwise1d(self.expand_feature_size, self.expand_feature_size)
         else:
             self.expansion1 = None
-            self.conv_cup1 = nn.Conv1d(self.dense_feature_size, self.expand_feature_size, 1)
-        self.conv_cup2 = nn.Conv1d(self.expand_feature_size, 3, 1, bias=True)
+            self.conv_cup1 = pointwise1d(self.dense_feature_size, self.expand_feature_size)
+        self.conv_cup2 = pointwise1d(self.expand_feature_size, 3, bias=True)
 
-        self.conv_s1 = nn.Conv1d(self.expand_feature_size, 16, 1, bias=True)
-        self.conv_s2 = nn.Conv1d(16, 8, 1, bias=True)
-        self.conv_s3 = nn.Conv1d(8, 1, 1, bias=True)
+        self.conv_s1 = pointwise1d(self.expand_feature_size, 16, bias=True)
+        self.conv_s2 = pointwise1d(16, 8, bias=True)
+        self.conv_s3 = pointwise1d(8, 1, bias=True)
 
         ratio = num_fine // num_coarse
         if self.local_folding:
@@ -255,8 +106,8 @@ class MSAP_SKN_decoder(nn.Module):
         else:
             self.expansion2 = EF_expansion(input_size=self.expand_feature_size, output_size=self.dense_feature_size,
                                            step_ratio=ratio, k=4)
-        self.conv_f1 = nn.Conv1d(self.dense_feature_size, self.expand_feature_size, 1)
-        self.conv_f2 = nn.Conv1d(self.expand_feature_size, 3, 1)
+        self.conv_f1 = pointwise1d(self.dense_feature_size, self.expand_feature_size)
+        self.conv_f2 = pointwise1d(self.expand_feature_size, 3)
         self.af = nn.ReLU(inplace=False)
 
     def forward(self, global_feat, point_input):
@@ -308,7 +159,7 @@ class MSAP_SKN_decoder(nn.Module):
 
 class Model(nn.Module):
     def __init__(self, args, size_z=128, global_feature_size=1024):
-        super(Model, self).__init__()
+        super().__init__()
         layers = [int(i) for i in str(args.layers).split(',')]
         knn_list = [int(i) for i in str(args.knn_list).split(',')]
 
@@ -388,7 +239,5 @@ class Model(nn.Module):
             total_train_loss = total_train_loss + (dl_rec.mean() + dl_g.mean()) * 20
             return fine, loss4, total_train_loss
         if prefix == "val":
-            emd = calc_emd(fine, gt, eps=0.004, iterations=3000) if self.eval_emd else 0
-            cd_p, cd_t, f1 = calc_cd(fine, gt, calc_f1=True)
-            return {'out1': coarse_raw, 'out2': fine, 'emd': emd, 'cd_p': cd_p, 'cd_t': cd_t, 'f1': f1}
+            return eval_outputs(coarse_raw, fine, gt, self.eval_emd)
         return {'result': fine}

@@ -1,0 +1,1 @@
+"""Chamfer distance operator (dist_chamfer_3D.chamfer_3DDist)."""

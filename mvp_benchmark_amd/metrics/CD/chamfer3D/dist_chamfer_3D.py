@@ -16,47 +16,39 @@ from torch.autograd import Function
 from ...._lib import call
 
 
+def _as_cloud(t):
+    return t.contiguous().float()
+
+
 class chamfer_3DFunction(Function):
+    """(xyz1 (B,N,3), xyz2 (B,M,3)) -> dist1 (B,N), dist2 (B,M) squared NN
+    distances and idx1, idx2 int32 arg-mins (lowest index on ties).
+    Differentiable w.r.t. both clouds through the distances."""
+
     @staticmethod
     def forward(ctx, xyz1, xyz2):
-        batchsize, n, _ = xyz1.size()
-        _, m, _ = xyz2.size()
-        device = xyz1.device
-        xyz1 = xyz1.contiguous().float()
-        xyz2 = xyz2.contiguous().float()
-
-        dist1 = torch.zeros(batchsize, n, device=device)
-        dist2 = torch.zeros(batchsize, m, device=device)
-        idx1 = torch.zeros(batchsize, n, dtype=torch.int32, device=device)
-        idx2 = torch.zeros(batchsize, m, dtype=torch.int32, device=device)
-
-        call("mvp_chamfer_forward", device, batchsize, n, m, xyz1, xyz2,
-             dist1, dist2, idx1, idx2)
-        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
-        ctx.mark_non_differentiable(idx1, idx2)
-        return dist1, dist2, idx1, idx2
+        xyz1, xyz2 = _as_cloud(xyz1), _as_cloud(xyz2)
+        B, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+        dev = xyz1.device
+        dist = [torch.zeros(B, k, device=dev) for k in (n, m)]
+        idx = [torch.zeros(B, k, dtype=torch.int32, device=dev) for k in (n, m)]
+        call("mvp_chamfer_forward", dev, B, n, m, xyz1, xyz2, dist[0], dist[1], idx[0], idx[1])
+        ctx.save_for_backward(xyz1, xyz2, *idx)
+        ctx.mark_non_differentiable(*idx)
+        return dist[0], dist[1], idx[0], idx[1]
 
     @staticmethod
     def backward(ctx, graddist1, graddist2, gradidx1, gradidx2):
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
-        graddist1 = graddist1.contiguous()
-        graddist2 = graddist2.contiguous()
-        device = graddist1.device
-        batchsize, n, _ = xyz1.size()
-        m = xyz2.size(1)
-
-        gradxyz1 = torch.zeros(xyz1.size(), device=device)
-        gradxyz2 = torch.zeros(xyz2.size(), device=device)
-        call("mvp_chamfer_backward", device, batchsize, n, m, xyz1, xyz2,
-             gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
-        return gradxyz1, gradxyz2
+        dev = graddist1.device
+        grads = [torch.zeros(x.shape, device=dev) for x in (xyz1, xyz2)]
+        call("mvp_chamfer_backward", dev, xyz1.shape[0], xyz1.shape[1], xyz2.shape[1], xyz1, xyz2,
+             grads[0], grads[1], graddist1.contiguous(), graddist2.contiguous(), idx1, idx2)
+        return grads[0], grads[1]
 
 
 class chamfer_3DDist(nn.Module):
-    def __init__(self):
-        super(chamfer_3DDist, self).__init__()
+    """Module face of chamfer_3DFunction (what `metrics.cd` names)."""
 
     def forward(self, input1, input2):
-        input1 = input1.contiguous()
-        input2 = input2.contiguous()
-        return chamfer_3DFunction.apply(input1, input2)
+        return chamfer_3DFunction.apply(input1.contiguous(), input2.contiguous())

@@ -1,0 +1,227 @@
+"""autograd.Function front-ends of the PointNet++ set-abstraction operators.
+
+One module for the whole op family (the reference spreads them over
+`ops/<op>/<op>.py`, one pybind extension each; those import paths are kept as
+thin re-exports).  Each Function keeps the reference's class name, positional
+`apply` signature, output dtype/shape and autograd contract, allocates its
+outputs on the input's device and hands raw device pointers to libmvpops
+through `_lib.call` (C ABI: include/mvpops.h).
+
+Reference wrappers mirrored here (paths under utils/mm3d_pn2/ops/):
+  furthest_point_sample/furthest_point_sample.py:7-78
+  ball_query/ball_query.py:7-47        knn/knn.py:7-72
+  interpolate/three_nn.py:8-45         interpolate/three_interpolate.py:8-63
+  gather_points/gather_points.py:7-52  group_points/group_points.py:166-221
+"""
+import torch
+from torch.autograd import Function
+
+from .._lib import call
+
+
+def _need_contiguous(*tensors):
+    for t in tensors:
+        assert t.is_contiguous()
+
+
+def _new(ref, *shape, dtype=torch.float32, zero=False):
+    make = torch.zeros if zero else torch.empty
+    return make(*shape, dtype=dtype, device=ref.device)
+
+
+# ------------------------------------------------------------------ sampling
+class FurthestPointSampling(Function):
+    """D-FPS: start at point 0, repeatedly add the point farthest from the
+    chosen set.  (B, N, 3) float32, num_points -> (B, num_points) int32."""
+
+    @staticmethod
+    def forward(ctx, points_xyz, num_points):
+        _need_contiguous(points_xyz)
+        B, N = points_xyz.shape[:2]
+        out = _new(points_xyz, B, num_points, dtype=torch.int32, zero=True)
+        scratch = _new(points_xyz, B, N).fill_(1e10)      # running min-distances
+        call("mvp_furthest_point_sampling", points_xyz.device, B, N, num_points, points_xyz, scratch, out)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(xyz, a=None):
+        return None, None
+
+
+class FurthestPointSamplingWithDist(Function):
+    """F-FPS on a precomputed (B, N, N) distance matrix -> (B, num_points) int32."""
+
+    @staticmethod
+    def forward(ctx, points_dist, num_points):
+        _need_contiguous(points_dist)
+        B, N, _ = points_dist.shape
+        out = _new(points_dist, B, num_points, dtype=torch.int32, zero=True)
+        scratch = _new(points_dist, B, N).fill_(1e10)
+        call("mvp_furthest_point_sampling_with_dist", points_dist.device, B, N, num_points, points_dist,
+             scratch, out)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(xyz, a=None):
+        return None, None
+
+
+# ------------------------------------------------------------------- queries
+class BallQuery(Function):
+    """For every centre: the first `sample_num` points, in index order, with
+    d2 == 0 or min_radius^2 <= d2 < max_radius^2; spare slots repeat the first
+    hit, centres without a hit return zeros.
+    (min_radius, max_radius, sample_num, xyz (B,N,3), center_xyz (B,M,3)) ->
+    (B, M, sample_num) int32."""
+
+    @staticmethod
+    def forward(ctx, min_radius, max_radius, sample_num, xyz, center_xyz):
+        _need_contiguous(center_xyz, xyz)
+        assert min_radius < max_radius
+        B, N, _ = xyz.shape
+        M = center_xyz.shape[1]
+        idx = _new(xyz, B, M, sample_num, dtype=torch.int32, zero=True)
+        call("mvp_ball_query", xyz.device, B, N, M, min_radius, max_radius, sample_num, center_xyz, xyz, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None, None
+
+
+class KNN(Function):
+    """k nearest points of every centre (heap order of the reference: ascending
+    squared distance), k <= 100.
+    (k, xyz, center_xyz=None, transposed=False) -> (B, k, npoint) int32;
+    with transposed=True the inputs are (B, 3, N) / (B, 3, npoint)."""
+
+    @staticmethod
+    def forward(ctx, k, xyz, center_xyz=None, transposed=False):
+        assert k > 0
+        center_xyz = xyz if center_xyz is None else center_xyz
+        if transposed:
+            xyz = xyz.transpose(2, 1).contiguous()
+            center_xyz = center_xyz.transpose(2, 1).contiguous()
+        _need_contiguous(xyz, center_xyz)
+        assert center_xyz.device == xyz.device, 'center_xyz and xyz should be put on the same device'
+        B, npoint, _ = center_xyz.shape
+        idx = _new(xyz, B, npoint, k, dtype=torch.int32, zero=True)
+        dist2 = _new(xyz, B, npoint, k, zero=True)
+        call("mvp_knn", xyz.device, B, xyz.shape[1], npoint, k, xyz, center_xyz, idx, dist2)
+        idx = idx.transpose(2, 1).contiguous()            # (B, k, npoint)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+class ThreeNN(Function):
+    """Three nearest `source` points of every `target` point.
+    (target (B,N,3), source (B,M,3)) -> (L2 distance (B,N,3) -- NOT squared --,
+    indices (B,N,3) int32)."""
+
+    @staticmethod
+    def forward(ctx, target, source):
+        _need_contiguous(target, source)
+        B, N, _ = target.shape
+        dist2 = _new(target, B, N, 3)
+        idx = _new(target, B, N, 3, dtype=torch.int32)
+        call("mvp_three_nn", target.device, B, N, source.shape[1], target, source, dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+# ------------------------------------------------- interpolate / gather / group
+class ThreeInterpolate(Function):
+    """out[b,c,n] = sum_j weight[b,n,j] * features[b,c,indices[b,n,j]].
+    (features (B,C,M), indices (B,n,3) int32, weight (B,n,3)) -> (B,C,n);
+    differentiable w.r.t. features."""
+
+    @staticmethod
+    def forward(ctx, features, indices, weight):
+        _need_contiguous(features, indices, weight)
+        B, c, m = features.shape
+        n = indices.shape[1]
+        ctx.three_interpolate_for_backward = (indices, weight, m)
+        out = _new(features, B, c, n)
+        call("mvp_three_interpolate", features.device, B, c, m, n, features, indices, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.shape
+        grad_features = _new(grad_out, B, c, m, zero=True)
+        call("mvp_three_interpolate_grad", grad_out.device, B, c, n, m, grad_out.data.contiguous(), idx, weight,
+             grad_features)
+        return grad_features, None, None
+
+
+class GatherPoints(Function):
+    """out[b,c,m] = features[b,c,indices[b,m]].
+    (features (B,C,N), indices (B,M) int32) -> (B,C,M); differentiable w.r.t.
+    features (scatter-add)."""
+
+    @staticmethod
+    def forward(ctx, features, indices):
+        _need_contiguous(features, indices)
+        B, npoint = indices.shape
+        _, C, N = features.shape
+        out = _new(features, B, C, npoint)
+        call("mvp_gather_points", features.device, B, C, N, npoint, features, indices, out)
+        ctx.for_backwards = (indices, C, N)
+        ctx.mark_non_differentiable(indices)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.shape
+        grad_features = _new(grad_out, B, C, N, zero=True)
+        call("mvp_gather_points_grad", grad_out.device, B, C, N, npoint, grad_out.data.contiguous(), idx,
+             grad_features)
+        return grad_features, None
+
+
+class GroupingOperation(Function):
+    """out[b,c,p,s] = features[b,c,indices[b,p,s]].
+    (features (B,C,N), indices (B,npoint,nsample) int32) -> (B,C,npoint,nsample);
+    differentiable w.r.t. features (scatter-add)."""
+
+    @staticmethod
+    def forward(ctx, features, indices):
+        _need_contiguous(features, indices)
+        B, npoint, nsample = indices.shape
+        _, C, N = features.shape
+        out = _new(features, B, C, npoint, nsample)
+        call("mvp_group_points", features.device, B, C, N, npoint, nsample, features, indices, out)
+        ctx.for_backwards = (indices, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, N = ctx.for_backwards
+        B, C, npoint, nsample = grad_out.shape
+        grad_features = _new(grad_out, B, C, N, zero=True)
+        call("mvp_group_points_grad", grad_out.device, B, C, N, npoint, nsample, grad_out.data.contiguous(), idx,
+             grad_features)
+        return grad_features, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+furthest_point_sample_with_dist = FurthestPointSamplingWithDist.apply
+ball_query = BallQuery.apply
+knn = KNN.apply
+three_nn = ThreeNN.apply
+three_interpolate = ThreeInterpolate.apply
+gather_points = GatherPoints.apply
+grouping_operation = GroupingOperation.apply

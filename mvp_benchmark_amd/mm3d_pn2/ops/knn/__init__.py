@@ -1,3 +1,4 @@
-from .knn import knn
+"""knn operator (re-export)."""
+from .knn import knn  # noqa: F401
 
-__all__ = ['knn']
+__all__ = ["knn"]
