@@ -7,17 +7,25 @@
 // default stream (21 001 launches at the eval setting iters=3000), every
 // bidder scans all n objects every round (O(n^2 k)), and GetMax is racy.
 // MI355X-first design:
-//   * ONE persistent launch; a 1024-lane workgroup owns one cloud and runs the
-//     whole auction with workgroup barriers (3 per round) instead of launches;
-//     rounds stop as soon as nobody is unassigned (exact: such rounds are
+//   * ONE persistent launch.  A cloud is owned by a CLUSTER of W 1024-lane
+//     workgroups (W = 1, 2 or 4, chosen so that b*W workgroups fit the chip's
+//     CUs: at the headline batch of 64 clouds a single workgroup per cloud
+//     would leave 192 of 256 CUs idle).  Every workgroup keeps its own
+//     unassigned list and bids for it; the auction state (prices, owners,
+//     bid keys) is shared through write-through (sc1) stores and L1-bypassing
+//     (sc1) loads, and the round structure is kept by two all-gathers of
+//     8-byte tagged granules per round (the data is the flag; no fences in
+//     the loop).  W = 1 uses plain accesses and workgroup barriers only;
+//   * rounds stop as soon as nobody is unassigned (exact: such rounds are
 //     no-ops in the reference, emd_cuda.cu:105-106,185,199);
-//   * the unassigned list is maintained incrementally (losers stay, evicted
-//     owners are appended) instead of a count / prefix-sum / compaction pass
-//     over all n points per round;
+//   * the unassigned lists are maintained incrementally (losers stay, an
+//     evicted owner joins the list of the workgroup that evicted it) instead
+//     of a count / prefix-sum / compaction pass over all n points per round;
 //   * objects (xyz2) are bucketed once into a uniform grid (<= 12^3 cells) and
-//     stored cell-sorted as float4 {x, y, z, price}.  Per cell the workgroup
+//     stored cell-sorted as float4 {x, y, z, price}.  Per cell every workgroup
 //     keeps in LDS the exact bounding box of its members and a lower bound of
-//     their prices (prices only rise, so a stale bound stays valid);
+//     their prices (prices only rise, so a stale bound stays valid; refreshed
+//     bounds are broadcast to the other workgroups of the cluster each round);
 //   * Bid.  A bid needs the best and second-best of
 //         v_k = float(3.0 - (double)sqrtf(|q-o_k|^2) - price_k)     (emd_cuda.cu:146)
 //     over all k.  Instead of evaluating all n objects the bidder (1) seeds a
@@ -39,9 +47,18 @@
 //     thread partition (emd_cuda.cu:108-118,139-142,163-171): candidates are
 //     ordered by (chunk thread, 2048-tile, index in tile) of their ORIGINAL
 //     object index;
-//   * GetMax's last-writer race (emd_cuda.cu:188-191) is made deterministic:
-//     the highest qualifying bidder index wins, via a round-tagged 64-bit
-//     atomic max -- the result of executing the reference kernel sequentially.
+//   * GetMax (emd_cuda.cu:181-194) is folded into the bid: a bid is ONE 64-bit
+//     atomic max of {order-preserving bits of the increment, bidder} on the
+//     object, so after the round's barrier the key already names the winner
+//     -- the highest bidder index among the maximal increments, which is what
+//     executing the reference's racy kernel sequentially gives.  The
+//     reference lets every bidder within 1e-6 of the maximum compete
+//     (emd_cuda.cu:188); the atomic's return value tells a bidder whether a
+//     different increment within that band was bid on the same object, and
+//     only rounds where that happened (a few per 10^5 bids) run the explicit
+//     GetMax pass and its extra barrier.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -59,6 +76,9 @@ constexpr int kRecCap = 512;     // list positions whose person record is cached
 #endif
 constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 bidders share a wave
 constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
+constexpr int kMaxCluster = 4;   // workgroups per cloud (W)
+constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
+constexpr unsigned kSpinLimit = 1u << 22;  // bound of every cluster wait (a few seconds), then abort
 
 // Filter slack.  An object is skipped only if
 //   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
@@ -71,45 +91,65 @@ constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushe
 // is >= the cell's, so a skipped cell contains only skippable objects.
 constexpr float kMargin = 1e-5f;
 
-// Per-person record (32 B): everything a bid needs in one 2x16-byte fetch.
-struct __attribute__((aligned(16))) PersonRec {
-  float qx, qy, qz;  // the person's point (xyz1)
-  float bidinc;      // increment of its last bid
-  int bid;           // slot it last bid on
-  int prev1, prev2;  // best / second-best slot of its previous bid (seed hints)
-  int pad;
-};
-// Per-object auction state (16 B), next to the object's float4 {x,y,z,price}.
-struct __attribute__((aligned(16))) ObjState {
-  unsigned long long maxidx;  // (round+1)<<32 | winning bidder
-  int maxinc;                 // max bid increment this round, float bits
-  int ass_inv;                // owner (-1 = free)
-};
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
 
+// Per-person record (32 B): two 16-byte halves.
+//   lo = {qx, qy, qz, -}                         the person's point (xyz1)
+//   hi = {bid, prev1, prev2, bits(bidinc)}       slot it last bid on, best /
+//        second-best slot of that bid (seed hints), increment of that bid
+// Per-object auction state (16 B), next to the object's float4 {x,y,z,price}:
+//   {key lo, key hi, owner (-1 = free), -}
+//   key = ord(max bid increment this round) << 32 | (winning bidder + 1); 0 = no bid
 struct EmdScratch {
-  float4 *obj;        // (n) cell-sorted x, y, z, price of xyz2
-  ObjState *ostate;   // (n) per slot
-  PersonRec *person;  // (n) per person
-  int *perm;          // (n) slot -> original object index
-  int *ulist;         // (2n) ping-pong unassigned lists
+  float4 *obj;     // (n) cell-sorted x, y, z, price of xyz2
+  int4 *ostate;    // (n) per slot
+  float4 *person;  // (2n) per person: lo, hi
+  int *perm;       // (n) slot -> original object index
+  int *ulist;      // (W x 2n) ping-pong unassigned lists, one pair per workgroup
+  u64 *chg;        // (W x kChgCap) {cell, bits(price bound)} broadcast per round
 };
 
 __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
-  return (size_t)n * 76;  // 16 + 16 + 32 + 4 + 8
+  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg
+  return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8;
 }
+// After the per-cloud areas: 256 B of barrier granules per cloud, then the
+// per-cloud statistics {rounds, bids}.  Zeroed by the host before the launch.
+constexpr size_t kEmdTailPerCloud = 256 + 16;
 
 __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
   EmdScratch s;
   s.obj = reinterpret_cast<float4 *>(base);
-  base += (size_t)n * 16;
-  s.ostate = reinterpret_cast<ObjState *>(base);
-  base += (size_t)n * 16;
-  s.person = reinterpret_cast<PersonRec *>(base);
-  base += (size_t)n * 32;
-  s.perm = reinterpret_cast<int *>(base);
-  base += (size_t)n * 4;
-  s.ulist = reinterpret_cast<int *>(base);
+  s.ostate = reinterpret_cast<int4 *>(base + (size_t)n * 16);
+  s.person = reinterpret_cast<float4 *>(base + (size_t)n * 32);
+  s.perm = reinterpret_cast<int *>(base + (size_t)n * 64);
+  s.ulist = reinterpret_cast<int *>(base + (size_t)n * 68);
+  s.chg = reinterpret_cast<u64 *>(base + (size_t)n * (68 + 8 * kMaxCluster));
   return s;
+}
+
+// Order-preserving map float -> unsigned (and back); never 0 for a non-NaN.
+__device__ __forceinline__ unsigned emd_f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float emd_ord2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+// A bidder with increment bi competes for an object whose maximal increment
+// is mi (emd_cuda.cu:188).
+__device__ __forceinline__ bool emd_in_band(float bi, float mi) {
+  return (double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6;
+}
+// `old` = the object's key before this bidder's atomic max.  True if a
+// DIFFERENT increment close enough to compete was already bid (the test is
+// wider than the band: false alarms only cost the explicit GetMax pass).
+__device__ __forceinline__ bool emd_band_alarm(u64 old, float inc) {
+  if (old == 0ull) return false;
+  const float mo = emd_ord2f((unsigned)(old >> 32));
+  const double d = (double)mo - (double)inc;
+  return mo != inc && d <= 2e-6 && d >= -2e-6;
 }
 
 // Reference merge order between two candidates (ORIGINAL object indices) of
@@ -124,13 +164,6 @@ __device__ __forceinline__ bool emd_precedes(int ka, int kb, int n, int tpu) {
   if (ta != tb) return ta < tb;
   if (tile_a != tile_b) return tile_a < tile_b;
   return kka < kkb;
-}
-
-__device__ __forceinline__ void atomic_max_float(int *addr, float val) {
-  if (val >= 0.f)
-    atomicMax(addr, __float_as_int(val));
-  else
-    atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(val));
 }
 
 __device__ __forceinline__ float emd_value(float s, float p) {
@@ -226,16 +259,59 @@ __device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
   return (iz * gg.g + iy) * gg.g + ix;
 }
 
+// All-gather of two 32-bit payloads among the W workgroups of a cluster; also
+// the cluster's barrier.  Every global store the workgroup issued before the
+// call is complete (acknowledged write-through) before its granules are
+// published.  Granule = one aligned 8-byte {epoch, payload} written by ONE
+// sc1 store and polled with sc1 loads: the data is the flag.  Slots are
+// double-buffered by epoch parity (a workgroup can be at most one epoch ahead
+// of the slowest reader).  Returns false when the wait was abandoned.
+template <int W>
+__device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned epoch,
+                                                   const int *p0, const int *p1,
+                                                   unsigned *s_gout, int *s_abort) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < kWave) {
+    const int lane = threadIdx.x;
+    u64 *base = slots + (size_t)(epoch & 1u) * (2 * W);
+    if (lane < 2) {
+      const unsigned pv = (unsigned)(lane == 0 ? *p0 : *p1);
+      __hip_atomic_store(base + 2 * wg + lane, ((u64)epoch << 32) | pv, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    u64 x = (u64)epoch << 32;
+    bool done = false;
+    for (unsigned spins = 0; spins < kSpinLimit; ++spins) {
+      if (lane < 2 * W)
+        x = __hip_atomic_load(base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      done = __all((unsigned)(x >> 32) == epoch);
+      if (done) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane < 2 * W) s_gout[lane] = (unsigned)x;
+    if (!done && lane == 0) *s_abort = 1;
+  }
+  __syncthreads();
+  return *s_abort == 0;
+}
+
+template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
-    int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    float *__restrict__ dist, int *__restrict__ assignment, float eps,
-    int iters, char *__restrict__ scratch) {
-  const int cloud = blockIdx.x;
-  // per-cloud auction statistics {rounds executed, bids made}, after the
-  // per-cloud state areas (read by bench.py; not part of the op's result)
-  long long *stats = reinterpret_cast<long long *>(
-                         scratch + (size_t)gridDim.x * emd_scratch_per_cloud(n)) +
-                     2 * (size_t)cloud;
+    int b, int bpad, int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    float *__restrict__ dist, int *assignment, float eps, int iters, char *scratch) {
+  // Block -> (cloud, member): members of a cluster are bpad (a multiple of 8)
+  // blocks apart, so they share an XCD under the round-robin dispatch (faster
+  // L2 sharing only; nothing below depends on placement).
+  const int cloud = W == 1 ? (int)blockIdx.x : (int)blockIdx.x % bpad;
+  const int wg = W == 1 ? 0 : (int)blockIdx.x / bpad;
+  if (cloud >= b) return;
+  char *cbase = scratch + (size_t)cloud * emd_scratch_per_cloud(n);
+  char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
+  u64 *slots = reinterpret_cast<u64 *>(tail + (size_t)cloud * 256);
+  // per-cloud auction statistics {rounds executed, bids made} (read by
+  // bench.py; not part of the op's result)
+  long long *stats = reinterpret_cast<long long *>(tail + (size_t)b * 256) + 2 * (size_t)cloud;
   const int t = threadIdx.x;
   const int lane = t & (kWave - 1);
   const int wave = t >> 6;
@@ -243,8 +319,68 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   xyz2 += (size_t)cloud * n * 3;
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
-  const EmdScratch sc =
-      emd_carve(scratch + (size_t)cloud * emd_scratch_per_cloud(n), n);
+  const EmdScratch sc = emd_carve(cbase, n);
+
+  // ---- accessors of the shared auction state.  W == 1: plain.  W > 1: loads
+  // bypass this CU's L1 (sc1), stores are written through (sc1), so data is
+  // visible to the other workgroups once the store is acknowledged.
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, (int)emd_scratch_per_cloud(n), 0x00020000);
+  auto ld_obj = [&](int s) -> float4 {
+    if constexpr (W == 1) {
+      return sc.obj[s];
+    } else {
+      const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)s * 16u, 0, 16);
+      return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  auto ld_ostate = [&](int s) -> int4 {
+    if constexpr (W == 1) {
+      return sc.ostate[s];
+    } else {
+      const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((unsigned)n + (unsigned)s) * 16u, 0, 16);
+      return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+    }
+  };
+  auto ld_person = [&](int j, int half) -> float4 {  // half 0 = lo, 1 = hi
+    if constexpr (W == 1) {
+      return sc.person[2 * j + half];
+    } else {
+      const v4u v =
+          __builtin_amdgcn_raw_buffer_load_b128(rs, (2u * (unsigned)n + 2u * (unsigned)j + (unsigned)half) * 16u, 0, 16);
+      return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  auto st_person_hi = [&](int j, int bid, int p1, int p2, float inc) {
+    if constexpr (W == 1) {
+      sc.person[2 * j + 1] = make_float4(__int_as_float(bid), __int_as_float(p1), __int_as_float(p2), inc);
+    } else {
+      v4u v;
+      v.x = (unsigned)bid; v.y = (unsigned)p1; v.z = (unsigned)p2; v.w = __float_as_uint(inc);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, (2u * (unsigned)n + 2u * (unsigned)j + 1u) * 16u, 0, 16);
+    }
+  };
+  auto st_ostate = [&](int s, int owner) {  // key = 0 (no bid), new owner
+    if constexpr (W == 1) {
+      sc.ostate[s] = make_int4(0, 0, owner, 0);
+    } else {
+      v4u v;
+      v.x = 0u; v.y = 0u; v.z = (unsigned)owner; v.w = 0u;
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((unsigned)n + (unsigned)s) * 16u, 0, 16);
+    }
+  };
+  auto st_i32 = [&](int *p, int v) {
+    if constexpr (W == 1) *p = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto st_f32 = [&](float *p, float v) {
+    if constexpr (W == 1) *p = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto ld_key = [&](int s) -> u64 {
+    u64 *p = reinterpret_cast<u64 *>(&sc.ostate[s]);
+    if constexpr (W == 1) return *p;
+    else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
 
   // Per-cell metadata (SoA, conflict-free lane-per-cell reads).
   __shared__ float c_minx[kMaxCells], c_miny[kMaxCells], c_minz[kMaxCells];
@@ -256,9 +392,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ float s_red[6][kEmdWaves];
   __shared__ int s_wsum[kEmdWaves];
   __shared__ int s_cnt[2];
-  __shared__ int s_err;
+  __shared__ int s_err, s_abort, s_nchg;
+  __shared__ int s_alarm[2];  // by round parity: set in Bid, read after the barrier, cleared a round later
+  __shared__ unsigned s_gout[2 * kMaxCluster];
   // this round's bids for the first kBidCache list positions (skips two
-  // dependent global round trips in GetMax / Assign)
+  // dependent global round trips in Assign)
   __shared__ int s_bj[kBidCache], s_bo[kBidCache], s_b2k[kBidCache];
   __shared__ float s_binc[kBidCache];
   // person records {qx,qy,qz,-} / {j, prev1, prev2, -} of the first kRecCap
@@ -268,6 +406,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ int4 s_ri[2][kRecCap];
 
   // ------------------------------------------------------------ grid build
+  // Every workgroup of the cluster derives the same grid geometry and cell
+  // offsets (deterministic reductions); member 0 alone writes the shared
+  // cell-sorted arrays and the initial state.
   // (a) bounding box of both clouds
   float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -290,6 +431,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       s_red[a][wave] = mn[a];
       s_red[3 + a][wave] = mx[a];
     }
+  }
+  if (t == 0) {
+    s_err = 0;
+    s_abort = 0;
+    s_alarm[0] = 0;
+    s_alarm[1] = 0;
+    s_nchg = 0;
   }
   __syncthreads();
   GridGeom gg;
@@ -347,41 +495,52 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     if (c1 < kMaxCells) s_tmp[c1] = 0;
     __syncthreads();
   }
-  // (d) scatter into cell-sorted order; initial state of emd_module.py:54-65
-  for (int k = t; k < n; k += kEmdThreads) {
-    const float x = xyz2[k * 3 + 0], y = xyz2[k * 3 + 1], z = xyz2[k * 3 + 2];
-    const int c = emd_cell(gg, x, y, z);
-    const int s = c_start[c] + atomicAdd(&s_tmp[c], 1);
-    sc.obj[s] = make_float4(x, y, z, 0.f);
-    sc.perm[s] = k;
-    ass[k] = -1;
-    ObjState os;
-    os.maxidx = 0ull;
-    os.maxinc = 0;  // 0.0f
-    os.ass_inv = -1;
-    sc.ostate[k] = os;
-    PersonRec pr;
-    pr.qx = xyz1[k * 3 + 0];
-    pr.qy = xyz1[k * 3 + 1];
-    pr.qz = xyz1[k * 3 + 2];
-    pr.bidinc = 0.f;
-    pr.bid = -1;
-    pr.prev1 = -1;
-    pr.prev2 = -1;
-    pr.pad = 0;
-    sc.person[k] = pr;
-    sc.ulist[k] = k;
+  // (d) member 0: scatter into cell-sorted order; initial state of
+  // emd_module.py:54-65
+  if (wg == 0) {
+    for (int k = t; k < n; k += kEmdThreads) {
+      const float x = xyz2[k * 3 + 0], y = xyz2[k * 3 + 1], z = xyz2[k * 3 + 2];
+      const int c = emd_cell(gg, x, y, z);
+      const int s = c_start[c] + atomicAdd(&s_tmp[c], 1);
+      sc.obj[s] = make_float4(x, y, z, 0.f);
+      sc.perm[s] = k;
+      ass[k] = -1;
+      sc.ostate[k] = make_int4(0, 0, -1, 0);
+      sc.person[2 * k] = make_float4(xyz1[k * 3 + 0], xyz1[k * 3 + 1], xyz1[k * 3 + 2], 0.f);
+      sc.person[2 * k + 1] = make_float4(__int_as_float(-1), __int_as_float(-1), __int_as_float(-1), 0.f);
+    }
   }
-  if (t < kRecCap) {  // round 0: list position u holds person u
-    s_rq[0][t] = make_float4(xyz1[t * 3 + 0], xyz1[t * 3 + 1], xyz1[t * 3 + 2], 0.f);
-    s_ri[0][t] = make_int4(t, -1, -1, 0);
+  // every member: its own share of the persons is its first unassigned list
+  const int share = n / W;  // n % 1024 == 0
+  const int first = wg * share;
+  int *my_ulist = sc.ulist + (size_t)wg * 2 * n;
+  for (int k = t; k < share; k += kEmdThreads) my_ulist[k] = first + k;
+  if (t < kRecCap && t < share) {  // round 0: list position u holds person first + u
+    const int k = first + t;
+    s_rq[0][t] = make_float4(xyz1[k * 3 + 0], xyz1[k * 3 + 1], xyz1[k * 3 + 2], 0.f);
+    s_ri[0][t] = make_int4(k, -1, -1, 0);
   }
   if (t == 0) {
-    s_cnt[0] = n;
+    s_cnt[0] = share;
     s_cnt[1] = 0;
-    s_err = 0;
   }
-  __syncthreads();
+  unsigned epoch = 0;
+  if constexpr (W > 1) {
+    // hand the shared arrays to the other members: release (write back this
+    // XCD's L2) -> barrier -> acquire (drop this CU's L1) -> plain loads
+    __syncthreads();
+    if (wg == 0 && t == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool ok = emd_cluster_gather<W>(slots, wg, ++epoch, &s_cnt[1], &s_cnt[1], s_gout, &s_abort);
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    if (!ok) {
+      if (wg == 0 && t == 0) stats[0] = -2;
+      return;
+    }
+  } else {
+    __syncthreads();
+  }
   // (e) exact bounding box per cell; price lower bound 0
   for (int c = t; c < ncell; c += kEmdThreads) {
     float bx0 = __builtin_inff(), by0 = __builtin_inff(), bz0 = __builtin_inff();
@@ -404,26 +563,34 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   // ------------------------------------------------------------ the auction
   const int block_cnt = n / 1024;
   int cur = 0;
+  int Utot = n;  // unassigned persons of the whole cloud
   long long n_rounds = 0, n_bids = 0;
+  bool aborted = false;
 #ifdef MVP_EMD_PROFILE
-  long long cyc_bid = 0, cyc_getmax = 0, cyc_assign = 0, cyc_bid_row = 0, n_row_rounds = 0, n_row_bids = 0;
+  long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0;
 #endif
   for (int it = 0; it < iters; ++it) {
-    const int U = s_cnt[cur];
-    if (U == 0) break;
+    if (Utot == 0) break;
+    const int U = s_cnt[cur];  // this workgroup's bidders
     n_rounds += 1;
     n_bids += U;
     const bool last = it == iters - 1;
-    const int *L = sc.ulist + (size_t)cur * n;
-    int *Lnext = sc.ulist + (size_t)(cur ^ 1) * n;
+    const int *L = my_ulist + (size_t)cur * n;
+    int *Lnext = my_ulist + (size_t)(cur ^ 1) * n;
     // thread_per_unass of the reference (emd_cuda.cu:107-109): fixes the tie
     // order only.
-    const int upb = (U + block_cnt - 1) / block_cnt;
+    const int upb = (Utot + block_cnt - 1) / block_cnt;
     const int tpu = 1024 / upb;
 
 #ifdef MVP_EMD_PROFILE
     const long long tp0 = __builtin_readcyclecounter();
 #endif
+    // A bid = one returning 64-bit atomic max on the object's key; the value
+    // it returns is examined one bid later (or after the loop), so the wave
+    // never waits for it.
+    u64 pend_old = 0ull;
+    float pend_inc = 0.f;
+    bool alarm = false;
     // Two Bid paths: many bidders -> four bidders per wave (throughput);
     // few bidders -> one bidder per wave (shortest dependent chain).
     if (U > kRowModeMin) {
@@ -448,9 +615,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             rb = s_ri[cur][u];
           } else {
             const int jj = L[u];
-            ra = *reinterpret_cast<const float4 *>(&sc.person[jj]);
-            const int4 g = *(reinterpret_cast<const int4 *>(&sc.person[jj]) + 1);
-            rb = make_int4(jj, g.y, g.z, 0);
+            ra = ld_person(jj, 0);
+            const float4 g = ld_person(jj, 1);
+            rb = make_int4(jj, __float_as_int(g.y), __float_as_int(g.z), 0);
           }
         }
         const int j = rb.x;
@@ -467,13 +634,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const int s0 = c_start[c0], s1 = act ? c_start[c0 + 1] : s0;
           for (int s = s0 + l16; __any(s < s1); s += 16) {
             if (s < s1) {
-              const float4 o = sc.obj[s];
+              const float4 o = ld_obj(s);
               top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
             }
           }
           bool extra = false;
           if (act && ((l16 == 0 && p1 >= 0) || (l16 == 1 && p2 >= 0))) {
-            const float4 o = sc.obj[l16 == 0 ? p1 : p2];
+            const float4 o = ld_obj(l16 == 0 ? p1 : p2);
             if (emd_cell(gg, o.x, o.y, o.z) != c0) {
               extra = true;
               top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
@@ -481,7 +648,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           }
           const int have = (s1 - s0) + __builtin_popcountll((__ballot(extra) >> rsh) & 0xFFFFull);
           if (act && have < 2) {  // row-uniform; rare: the first 16 slots (distinct objects)
-            const float4 o = sc.obj[l16];
+            const float4 o = ld_obj(l16);
             a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
             a2 = -1e9f;
           }
@@ -546,7 +713,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             float4 o[4];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4)
-              o[r4] = linear ? sc.obj[base + r4 * 16 + l16] : make_float4(0.f, 0.f, 0.f, 0.f);
+              o[r4] = linear ? ld_obj(base + r4 * 16 + l16) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) consider(linear, o[r4], base + r4 * 16 + l16);
           }
@@ -574,7 +741,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               float4 o[4];
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4)
-                o[r4] = s[r4] < s1[r4] ? sc.obj[s[r4]] : make_float4(0.f, 0.f, 0.f, 0.f);
+                o[r4] = s[r4] < s1[r4] ? ld_obj(s[r4]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) consider(s[r4] < s1[r4], o[r4], s[r4]);
               bool mine = false;   // cells with more than 16 members: next 16
@@ -649,15 +816,17 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         }
         if (act && l16 == 0) {
           const float inc = lb1 - lb2 + eps;
-          sc.person[j].bidinc = inc;
-          *(reinterpret_cast<int4 *>(&sc.person[j]) + 1) = make_int4(lbk, lbk, lb2k, 0);
+          st_person_hi(j, lbk, lbk, lb2k, inc);
           if (u < kBidCache) {
             s_bj[u] = j;
             s_bo[u] = lbk;
             s_b2k[u] = lb2k;
             s_binc[u] = inc;
           }
-          atomic_max_float(&sc.ostate[lbk].maxinc, inc);
+          alarm |= emd_band_alarm(pend_old, pend_inc);
+          pend_old = atomicMax(reinterpret_cast<u64 *>(&sc.ostate[lbk]),
+                               ((u64)emd_f2ord(inc) << 32) | (u64)((unsigned)j + 1u));
+          pend_inc = inc;
         }
       }
     }
@@ -674,9 +843,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         rb = s_ri[cur][u];
       } else if (u < U) {
         const int jj = L[u];
-        ra = *reinterpret_cast<const float4 *>(&sc.person[jj]);
-        const int4 g = *(reinterpret_cast<const int4 *>(&sc.person[jj]) + 1);
-        rb = make_int4(jj, g.y, g.z, 0);
+        ra = ld_person(jj, 0);
+        const float4 g = ld_person(jj, 1);
+        rb = make_int4(jj, __float_as_int(g.y), __float_as_int(g.z), 0);
       }
     };
     load_rec(wave);
@@ -696,12 +865,12 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         float a1 = -1e9f, a2 = -1e9f;
         const int s0 = c_start[c0], s1 = c_start[c0 + 1];
         for (int s = s0 + lane; s < s1; s += kWave) {
-          const float4 o = sc.obj[s];
+          const float4 o = ld_obj(s);
           top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
         }
         bool extra = false;
         if ((lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0)) {
-          const float4 o = sc.obj[lane == 0 ? p1 : p2];
+          const float4 o = ld_obj(lane == 0 ? p1 : p2);
           if (emd_cell(gg, o.x, o.y, o.z) != c0) {
             extra = true;
             top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
@@ -709,7 +878,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         }
         const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
         if (have < 2) {  // wave-uniform; rare: fall back to the first 64 slots
-          const float4 o = sc.obj[lane];
+          const float4 o = ld_obj(lane);
           a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
           a2 = -1e9f;
         }
@@ -776,7 +945,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             float4 o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              o[r] = s[r] < s1[r] ? sc.obj[s[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
+              o[r] = s[r] < s1[r] ? ld_obj(s[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
@@ -806,7 +975,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         for (int base = 0; base < n; base += 4 * kWave) {
           float4 o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = sc.obj[base + r * kWave + lane];  // n % 1024 == 0
+          for (int r = 0; r < 4; ++r) o[r] = ld_obj(base + r * kWave + lane);  // n % 1024 == 0
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
@@ -848,45 +1017,81 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       }
       if (lane == 0) {
         const float inc = st.b1 - st.b2 + eps;
-        sc.person[j].bidinc = inc;
-        *(reinterpret_cast<int4 *>(&sc.person[j]) + 1) = make_int4(st.bk, st.bk, st.b2k, 0);
+        st_person_hi(j, st.bk, st.bk, st.b2k, inc);
         if (u < kBidCache) {
           s_bj[u] = j;
           s_bo[u] = st.bk;
           s_b2k[u] = st.b2k;
           s_binc[u] = inc;
         }
-        atomic_max_float(&sc.ostate[st.bk].maxinc, inc);
+        alarm |= emd_band_alarm(pend_old, pend_inc);
+        pend_old = atomicMax(reinterpret_cast<u64 *>(&sc.ostate[st.bk]),
+                             ((u64)emd_f2ord(inc) << 32) | (u64)((unsigned)j + 1u));
+        pend_inc = inc;
       }
     }
     }
+    alarm |= emd_band_alarm(pend_old, pend_inc);
+    int *my_alarm = &s_alarm[it & 1];
+    if (alarm) *my_alarm = 1;
     if (t == 0) s_cnt[cur ^ 1] = 0;
-    __syncthreads();
 #ifdef MVP_EMD_PROFILE
     const long long tp1 = __builtin_readcyclecounter();
 #endif
-
-    // ---------------- GetMax (emd_cuda.cu:181-194), deterministic
-    const unsigned long long tag = (unsigned long long)(it + 1) << 32;
-    for (int u = t; u < U; u += kEmdThreads) {
-      int j, o;
-      float bi;
-      if (u < kBidCache) {
-        j = s_bj[u]; o = s_bo[u]; bi = s_binc[u];
-      } else {
-        j = L[u]; o = sc.person[j].bid; bi = sc.person[j].bidinc;
+    // ---------------- all bids of the round are placed
+    bool any_alarm;
+    if constexpr (W > 1) {
+      if (!emd_cluster_gather<W>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort)) {
+        aborted = true;
+        break;
       }
-      const float mi = __int_as_float(sc.ostate[o].maxinc);
-      if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
-        atomicMax(&sc.ostate[o].maxidx, tag | (unsigned long long)(unsigned)j);
+      any_alarm = false;
+#pragma unroll
+      for (int w = 0; w < W; ++w) any_alarm |= s_gout[2 * w] != 0u;
+    } else {
+      __syncthreads();
+      any_alarm = *my_alarm != 0;
     }
-    __syncthreads();
+
+    // ---------------- GetMax (emd_cuda.cu:181-194): only when two different
+    // increments within the 1e-6 band met on one object this round.  Every
+    // bidder inside the band of the object's maximal increment raises the
+    // key's bidder field; the increment field stays.
+    if (any_alarm) {
+#ifdef MVP_EMD_PROFILE
+      n_alarm += 1;
+#endif
+      for (int u = t; u < U; u += kEmdThreads) {
+        int j, o;
+        float bi;
+        if (u < kBidCache) {
+          j = s_bj[u]; o = s_bo[u]; bi = s_binc[u];
+        } else {
+          j = L[u];
+          const float4 g = ld_person(j, 1);
+          o = __float_as_int(g.x); bi = g.w;
+        }
+        const u64 key = ld_key(o);
+        if (emd_in_band(bi, emd_ord2f((unsigned)(key >> 32))))
+          atomicMax(reinterpret_cast<u64 *>(&sc.ostate[o]), (key & 0xFFFFFFFF00000000ull) | (u64)((unsigned)j + 1u));
+      }
+      if constexpr (W > 1) {
+        if (!emd_cluster_gather<W>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort)) {
+          aborted = true;
+          break;
+        }
+      } else {
+        __syncthreads();
+      }
+    }
+    if (t == 0) s_alarm[(it + 1) & 1] = 0;  // next round's flag; its writers are a barrier away
 #ifdef MVP_EMD_PROFILE
     const long long tp2 = __builtin_readcyclecounter();
 #endif
 
     // ---------------- Assign (emd_cuda.cu:196-215)
     const int nxt = cur ^ 1;
+    u64 *my_chg = sc.chg + (size_t)wg * kChgCap;
     for (int u = t; u < U; u += kEmdThreads) {
       int j, o, b2k;
       float bi;
@@ -894,41 +1099,47 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         j = s_bj[u]; o = s_bo[u]; bi = s_binc[u]; b2k = s_b2k[u];
       } else {
         j = L[u];
-        const int4 g = *(reinterpret_cast<const int4 *>(&sc.person[j]) + 1);
-        o = g.x; b2k = g.z; bi = sc.person[j].bidinc;
+        const float4 g = ld_person(j, 1);
+        o = __float_as_int(g.x); b2k = __float_as_int(g.z); bi = g.w;
       }
-      const ObjState os = sc.ostate[o];
-      const float4 oo = sc.obj[o];  // independent of `os`: same round trip
-      if (last || os.maxidx == (tag | (unsigned long long)(unsigned)j)) {
-        const int prev = os.ass_inv;
+      const int4 os = ld_ostate(o);
+      const float4 oo = ld_obj(o);  // independent of `os`: same round trip
+      if (last || (unsigned)os.x == (unsigned)j + 1u) {  // a loser may read after the winner reset the key to 0
+        const int prev = os.z;
         if (!last && prev != -1) {
-          // the evicted owner bids again next round
-          ass[prev] = -1;
+          // the evicted owner bids again next round, in this workgroup's list
+          st_i32(&ass[prev], -1);
           const int pos = atomicAdd(&s_cnt[nxt], 1);
           if (pos >= kRecCap) Lnext[pos] = prev;   // entries below kRecCap live in LDS only
           if (pos < kRecCap) {
-            const float4 pa = *reinterpret_cast<const float4 *>(&sc.person[prev]);
-            const int4 pb = *(reinterpret_cast<const int4 *>(&sc.person[prev]) + 1);
+            const float4 pa = ld_person(prev, 0);
+            const float4 pb = ld_person(prev, 1);
             s_rq[nxt][pos] = pa;
-            s_ri[nxt][pos] = make_int4(prev, pb.y, pb.z, 0);
+            s_ri[nxt][pos] = make_int4(prev, __float_as_int(pb.y), __float_as_int(pb.z), 0);
           }
         }
-        sc.ostate[o].ass_inv = j;
-        sc.ostate[o].maxinc = __float_as_int(-1e9f);
-        ass[j] = o;
-        sc.obj[o].w = oo.w + bi;
+        st_ostate(o, j);
+        st_i32(&ass[j], o);
+        st_f32(&sc.obj[o].w, oo.w + bi);
         // The cell's price lower bound only needs a refresh when the object
         // that just got dearer was (one of) the cheapest of its cell; then the
-        // members are re-scanned (racing refreshes of one cell may leave a
-        // slightly stale -- still valid -- bound).
+        // members are re-scanned (prices read while other winners raise them
+        // are old or new -- either way a valid bound) and the new bound is
+        // broadcast to the other workgroups of the cluster.
         const int c = emd_cell(gg, oo.x, oo.y, oo.z);
         if (oo.w <= c_pmin[c]) {
           float pm = oo.w + bi;
           const int e1 = c_start[c + 1];
 #pragma unroll 8
           for (int s = c_start[c]; s < e1; ++s)
-            pm = __builtin_fminf(pm, s == o ? pm : sc.obj[s].w);
+            pm = __builtin_fminf(pm, s == o ? pm : ld_obj(s).w);
           c_pmin[c] = pm;
+          if constexpr (W > 1) {
+            const int q = atomicAdd(&s_nchg, 1);
+            if (q < kChgCap)
+              __hip_atomic_store(my_chg + q, ((u64)(unsigned)c << 32) | (u64)__float_as_uint(pm),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       } else {
         // lost: stays in the list, record carried over through LDS
@@ -939,35 +1150,84 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           if (u < kRecCap)
             pa = s_rq[cur][u];
           else
-            pa = *reinterpret_cast<const float4 *>(&sc.person[j]);
+            pa = ld_person(j, 0);
           s_rq[nxt][pos] = pa;
           s_ri[nxt][pos] = make_int4(j, o, b2k, 0);
         }
       }
     }
-    __syncthreads();
 #ifdef MVP_EMD_PROFILE
     const long long tp3 = __builtin_readcyclecounter();
-    cyc_bid += tp1 - tp0; cyc_getmax += tp2 - tp1; cyc_assign += tp3 - tp2;
-    if (U > kRowModeMin) { cyc_bid_row += tp1 - tp0; n_row_rounds += 1; n_row_bids += U; }
+#endif
+    // ---------------- end of round: next list sizes + refreshed price bounds
+    if constexpr (W > 1) {
+      if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort)) {
+        aborted = true;
+        break;
+      }
+      Utot = 0;
+      bool overflow = false;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        Utot += (int)s_gout[2 * w];
+        if (w != wg) overflow |= (int)s_gout[2 * w + 1] > kChgCap;
+      }
+      if (overflow) {
+        // too many refreshes to broadcast (the first, heavy rounds): recompute
+        // every bound from the prices themselves (stable between barriers)
+        for (int c = t; c < ncell; c += kEmdThreads) {
+          float pm = __builtin_inff();
+          for (int s = c_start[c]; s < c_start[c + 1]; ++s) pm = __builtin_fminf(pm, ld_obj(s).w);
+          if (pm >= c_pmin[c]) c_pmin[c] = pm;
+        }
+      } else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          if (w == wg) continue;
+          const int cnt = (int)s_gout[2 * w + 1];
+          const u64 *src = sc.chg + (size_t)w * kChgCap;
+          for (int i = t; i < cnt; i += kEmdThreads) {
+            const u64 e = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int pmb = (int)(unsigned)e;
+            if (pmb >= 0)  // bits of a non-negative float order like ints
+              atomicMax(reinterpret_cast<int *>(&c_pmin[(int)(e >> 32)]), pmb);
+          }
+        }
+      }
+      if (t == 0) s_nchg = 0;
+      __syncthreads();
+    } else {
+      __syncthreads();
+      Utot = s_cnt[nxt];
+    }
+#ifdef MVP_EMD_PROFILE
+    const long long tp4 = __builtin_readcyclecounter();
+    cyc_bid += tp1 - tp0; cyc_sync1 += tp2 - tp1; cyc_assign += tp3 - tp2; cyc_sync2 += tp4 - tp3;
 #endif
     cur ^= 1;
   }
 
+  if (aborted) {
+    if (t == 0) stats[0] = -2;
+    return;
+  }
   if (t == 0) {
-    stats[0] = s_err ? -1 : n_rounds;
-    stats[1] = n_bids;
+    if (wg == 0) stats[0] = s_err ? -1 : n_rounds;
+    if (s_err) stats[0] = -1;
+    atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
 #ifdef MVP_EMD_PROFILE
-    stats[0] = cyc_bid;
-    stats[1] = (cyc_getmax << 32) | (cyc_assign & 0xffffffffll);
-    if (cloud < 4) printf("cloud %d: rounds %lld bids %lld | row-mode rounds %lld bids %lld bid-cycles %lld | all bid-cycles %lld getmax %lld assign %lld\n", cloud, n_rounds, n_bids, n_row_rounds, n_row_bids, cyc_bid_row, cyc_bid, cyc_getmax, cyc_assign);
+    if (cloud < 2)
+      printf("cloud %d wg %d: rounds %lld bids %lld alarms %lld | cycles bid %lld sync1 %lld assign %lld sync2 %lld\n",
+             cloud, wg, n_rounds, n_bids, n_alarm, cyc_bid, cyc_sync1, cyc_assign, cyc_sync2);
 #endif
   }
   // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
   __syncthreads();
-  for (int j = t; j < n; j += kEmdThreads) {
-    const int s = ass[j];
-    const float4 o = sc.obj[s];
+  for (int j = first + t; j < first + share; j += kEmdThreads) {
+    int s;
+    if constexpr (W == 1) s = ass[j];
+    else s = __hip_atomic_load(&ass[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float4 o = sc.obj[s];  // coordinates never change
     const float dx = xyz1[j * 3 + 0] - o.x;
     const float dy = xyz1[j * 3 + 1] - o.y;
     const float dz = xyz1[j * 3 + 2] - o.z;
@@ -994,13 +1254,44 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
   grad_xyz[a + 2] += g * (xyz1[a + 2] - xyz2[c + 2]);
 }
 
+// Workgroups per cloud: as many (1, 2, 4) as keep b*W workgroups co-resident,
+// one per CU.  MVP_EMD_CLUSTER=1|2|4 overrides (still capped by the CU count).
+static int emd_cluster_width(int b) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 1;
+  int want = kMaxCluster;
+  if (const char *e = getenv("MVP_EMD_CLUSTER")) want = atoi(e);
+  int w = 1;
+  while (w * 2 <= want && w * 2 <= kMaxCluster && (long long)b * w * 2 <= cus) w *= 2;
+  return w;
+}
+
+template <int W>
+static hipError_t emd_launch(int b, int n, const float *xyz1, const float *xyz2, float *dist,
+                             int *assignment, float eps, int iters, char *scratch,
+                             hipStream_t stream) {
+  int bpad = W == 1 ? b : (b + 7) / 8 * 8;
+  if (W == 1) {
+    hipLaunchKernelGGL(emd_auction_kernel<1>, dim3(b), dim3(kEmdThreads), 0, stream, b, bpad, n,
+                       xyz1, xyz2, dist, assignment, eps, iters, scratch);
+    return hipSuccess;
+  }
+  // cluster members wait for each other: the launch must be checked against
+  // the device's residency (cooperative launch does exactly that)
+  void *args[] = {&b, &bpad, &n, &xyz1, &xyz2, &dist, &assignment, &eps, &iters, &scratch};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_auction_kernel<W>),
+                                    dim3(W * bpad), dim3(kEmdThreads), args, 0, stream);
+}
+
 }  // namespace mvp
 
 using namespace mvp;
 
 extern "C" long long mvp_emd_scratch_bytes(int b, int n) {
   if (b < 0 || n < 0) return -1;
-  return (long long)b * ((long long)emd_scratch_per_cloud(n) + 16);
+  return (long long)b * ((long long)emd_scratch_per_cloud(n) + (long long)kEmdTailPerCloud);
 }
 
 extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
@@ -1014,9 +1305,19 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
   if (!xyz1 || !xyz2 || !dist || !assignment || !scratch) return MVP_EBADARG;
   if (scratch_bytes < mvp_emd_scratch_bytes(b, n)) return MVP_EBADARG;
   if ((reinterpret_cast<uintptr_t>(scratch) & 15) != 0) return MVP_EBADARG;
-  hipLaunchKernelGGL(emd_auction_kernel, dim3(b), dim3(kEmdThreads), 0,
-                     as_stream(stream), n, xyz1, xyz2, dist, assignment, eps,
-                     iters, reinterpret_cast<char *>(scratch));
+  char *sbase = reinterpret_cast<char *>(scratch);
+  hipStream_t st = as_stream(stream);
+  // barrier granules and statistics start from zero on every call
+  if (hipMemsetAsync(sbase + (size_t)b * emd_scratch_per_cloud(n), 0, (size_t)b * kEmdTailPerCloud, st) != hipSuccess)
+    return check_launch("mvp_emd_forward");
+  const int w = emd_cluster_width(b);
+  hipError_t err = hipErrorUnknown;
+  if (w == 4) err = emd_launch<4>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
+  else if (w == 2) err = emd_launch<2>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
+  if (err != hipSuccess) {  // w == 1, or the cluster does not fit this device
+    (void)hipGetLastError();
+    (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
+  }
   return check_launch("mvp_emd_forward");
 }
 

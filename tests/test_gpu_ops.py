@@ -115,6 +115,51 @@ def test_emd_matches_oracle_bit_exact(oracle, b, n, eps, iters):
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
+@pytest.fixture
+def cluster_width(monkeypatch):
+    """Pins how many workgroups own one cloud (MVP_EMD_CLUSTER, read per call)."""
+    def pin(w):
+        monkeypatch.setenv("MVP_EMD_CLUSTER", str(w))
+    return pin
+
+
+@pytest.mark.parametrize("width", [1, 2, 4])
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "duplicates"])
+def test_emd_every_cluster_width_matches_oracle(oracle, cluster_width, width, kind):
+    """Same bits whether one, two or four workgroups share a cloud.  The
+    clustered case keeps thousands of bidders on a handful of objects (bid
+    increments within the reference's 1e-6 GetMax band, more bidders per
+    workgroup than the LDS bid cache holds); duplicates force value ties."""
+    from mvp_benchmark_amd.metrics import emd
+    cluster_width(width)
+    if kind == "uniform":
+        x1, x2, eps, iters = rand_clouds(11, 3, 4096, 3), rand_clouds(12, 3, 4096, 3), 0.004, 3000
+    elif kind == "clustered":
+        x1 = (0.5 + 0.01 * rand_clouds(13, 2, 8192, 3)).astype(np.float32)
+        x2, eps, iters = rand_clouds(14, 2, 8192, 3), 0.004, 40
+    else:
+        x1 = np.tile(rand_clouds(15, 1, 512, 3), (1, 4, 1))
+        x2, eps, iters = np.tile(rand_clouds(16, 1, 256, 3), (1, 8, 1)), 0.005, 300
+    dist, ass = emd()(dev(x1), dev(x2), eps, iters)
+    od, oa = oracle.emd_forward(x1, x2, eps, iters)
+    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
+def test_emd_cluster_widths_agree_at_full_size(cluster_width):
+    """16384 points, eval setting: 1 and 4 workgroups per cloud give identical
+    assignments (the oracle needs minutes at this size)."""
+    from mvp_benchmark_amd.metrics import emd
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.rand(8, 16384, 3, generator=g).to(DEV)
+    x2 = torch.rand(8, 16384, 3, generator=g).to(DEV)
+    out = {}
+    for w in (1, 4):
+        cluster_width(w)
+        out[w] = emd()(x1, x2, 0.004, 3000)
+    assert torch.equal(out[1][1], out[4][1]) and torch.equal(out[1][0], out[4][0])
+
+
 def test_emd_clustered_input_with_ties(oracle):
     """Duplicated points force equal values, i.e. the tie order."""
     from mvp_benchmark_amd.metrics import emd
