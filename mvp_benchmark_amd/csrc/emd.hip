@@ -266,11 +266,13 @@ __device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
 // sc1 store and polled with sc1 loads: the data is the flag.  Slots are
 // double-buffered by epoch parity (a workgroup can be at most one epoch ahead
 // of the slowest reader).  Returns false when the wait was abandoned.
-template <int W>
+template <int W, bool DRAIN = true>
 __device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned epoch,
                                                    const int *p0, const int *p1,
                                                    unsigned *s_gout, int *s_abort) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // DRAIN = false: nothing stored since the last gather has to be visible to
+  // the other workgroups before the NEXT draining gather
+  if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x < kWave) {
     const int lane = threadIdx.x;
@@ -566,6 +568,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   int Utot = n;  // unassigned persons of the whole cloud
   long long n_rounds = 0, n_bids = 0;
   bool aborted = false;
+  u64 chg_pend = 0ull;    // a bound broadcast by another workgroup, not yet folded in
+  bool chg_have = false;
 #ifdef MVP_EMD_PROFILE
   long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0;
 #endif
@@ -1032,6 +1036,14 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     }
     }
     alarm |= emd_band_alarm(pend_old, pend_inc);
+    if constexpr (W > 1) {
+      if (chg_have) {
+        const int pmb = (int)(unsigned)chg_pend;
+        if (pmb >= 0)  // bits of a non-negative float order like ints
+          atomicMax(reinterpret_cast<int *>(&c_pmin[(int)(chg_pend >> 32)]), pmb);
+        chg_have = false;
+      }
+    }
     int *my_alarm = &s_alarm[it & 1];
     if (alarm) *my_alarm = 1;
     if (t == 0) s_cnt[cur ^ 1] = 0;
@@ -1041,7 +1053,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     // ---------------- all bids of the round are placed
     bool any_alarm;
     if constexpr (W > 1) {
-      if (!emd_cluster_gather<W>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort)) {
+      // The bids themselves are complete (their atomics have returned); the
+      // bidders' hint records are only read after the next draining gather.
+      if (!emd_cluster_gather<W, false>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort)) {
         aborted = true;
         break;
       }
@@ -1181,21 +1195,44 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           if (pm >= c_pmin[c]) c_pmin[c] = pm;
         }
       } else {
+        // Fetch the other workgroups' refreshed bounds now, fold them in after
+        // this workgroup's next bids (a bound that arrives a round late is
+        // still a bound): the load latency hides behind the Bid phase.  The
+        // producer rewrites its buffer only after the next gather, which this
+        // workgroup enters after consuming the value.
+        int idx = t, total = 0;
+        bool over = false;   // more entries than threads: take them synchronously
 #pragma unroll
         for (int w = 0; w < W; ++w) {
           if (w == wg) continue;
           const int cnt = (int)s_gout[2 * w + 1];
-          const u64 *src = sc.chg + (size_t)w * kChgCap;
-          for (int i = t; i < cnt; i += kEmdThreads) {
-            const u64 e = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int pmb = (int)(unsigned)e;
-            if (pmb >= 0)  // bits of a non-negative float order like ints
-              atomicMax(reinterpret_cast<int *>(&c_pmin[(int)(e >> 32)]), pmb);
+          if (!chg_have && idx >= 0 && idx < cnt) {
+            chg_pend = __hip_atomic_load(sc.chg + (size_t)w * kChgCap + idx, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+            chg_have = true;
           }
+          idx -= cnt;   // negative once this thread's entry has been found
+          total += cnt;
+        }
+        over = total > kEmdThreads;
+        if (over) {
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            if (w == wg) continue;
+            const int cnt = (int)s_gout[2 * w + 1];
+            const u64 *src = sc.chg + (size_t)w * kChgCap;
+            for (int i = t; i < cnt; i += kEmdThreads) {
+              const u64 e = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const int pmb = (int)(unsigned)e;
+              if (pmb >= 0)  // bits of a non-negative float order like ints
+                atomicMax(reinterpret_cast<int *>(&c_pmin[(int)(e >> 32)]), pmb);
+            }
+          }
+          chg_have = false;
+          __syncthreads();
         }
       }
       if (t == 0) s_nchg = 0;
-      __syncthreads();
     } else {
       __syncthreads();
       Utot = s_cnt[nxt];

@@ -24,11 +24,8 @@ for (b, n, eps, iters) in [(64, 1024, 0.004, 3000), (64, 2048, 0.004, 3000), (64
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
     st = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu()
-    if prof:
-        bid = st[:, 0].double().mean().item(); gm = (st[:, 1] >> 32).double().mean().item(); asg = (st[:, 1] & 0xffffffff).double().mean().item()
-        tot = bid + gm + asg
-        print("b=%d n=%d eps=%g iters=%d: %.2f ms | cycles(100MHz ticks?) bid %.3g (%.0f%%) getmax %.3g (%.0f%%) assign %.3g (%.0f%%)" % (
-            b, n, eps, iters, best, bid, 100 * bid / tot, gm, 100 * gm / tot, asg, 100 * asg / tot), flush=True)
+    if prof:   # the profiling build prints its per-phase cycle counters itself (clouds 0 and 1)
+        print("b=%d n=%d eps=%g iters=%d: %.2f ms" % (b, n, eps, iters, best), flush=True)
     else:
         print("b=%d n=%d eps=%g iters=%d: %.2f ms  rounds %d bids/cloud %.0f  -> %.3g ref-pair-evals/s" % (
             b, n, eps, iters, best, int(st[:, 0].max()), st[:, 1].double().mean().item(),
