@@ -78,6 +78,7 @@ constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 
 constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
 constexpr int kMaxCluster = 4;   // workgroups per cloud (W)
 constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
+constexpr int kSoloMax = 16;     // unassigned persons below which one workgroup finishes the auction alone
 constexpr unsigned kSpinLimit = 1u << 22;  // bound of every cluster wait (a few seconds), then abort
 
 // Filter slack.  An object is skipped only if
@@ -513,8 +514,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     }
   }
   // every member: its own share of the persons is its first unassigned list
-  const int share = n / W;  // n % 1024 == 0
-  const int first = wg * share;
+  int share = n / W;  // n % 1024 == 0
+  int first = wg * share;
   int *my_ulist = sc.ulist + (size_t)wg * 2 * n;
   for (int k = t; k < share; k += kEmdThreads) my_ulist[k] = first + k;
   if (t < kRecCap && t < share) {  // round 0: list position u holds person first + u
@@ -570,6 +571,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   bool aborted = false;
   u64 chg_pend = 0ull;    // a bound broadcast by another workgroup, not yet folded in
   bool chg_have = false;
+  // Once at most kSoloMax persons are left (their number never grows) one
+  // workgroup bids for all of them in a single pass and the cluster's barriers
+  // would only add latency: member 0 adopts the others' lists and carries on
+  // alone (same code, workgroup barriers), the others leave.
+  bool clustered = W > 1;
 #ifdef MVP_EMD_PROFILE
   long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0;
 #endif
@@ -1052,7 +1058,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #endif
     // ---------------- all bids of the round are placed
     bool any_alarm;
-    if constexpr (W > 1) {
+    if (clustered) {
       // The bids themselves are complete (their atomics have returned); the
       // bidders' hint records are only read after the next draining gather.
       if (!emd_cluster_gather<W, false>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort)) {
@@ -1089,7 +1095,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         if (emd_in_band(bi, emd_ord2f((unsigned)(key >> 32))))
           atomicMax(reinterpret_cast<u64 *>(&sc.ostate[o]), (key & 0xFFFFFFFF00000000ull) | (u64)((unsigned)j + 1u));
       }
-      if constexpr (W > 1) {
+      if (clustered) {
         if (!emd_cluster_gather<W>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort)) {
           aborted = true;
           break;
@@ -1148,7 +1154,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           for (int s = c_start[c]; s < e1; ++s)
             pm = __builtin_fminf(pm, s == o ? pm : ld_obj(s).w);
           c_pmin[c] = pm;
-          if constexpr (W > 1) {
+          if (clustered) {
             const int q = atomicAdd(&s_nchg, 1);
             if (q < kChgCap)
               __hip_atomic_store(my_chg + q, ((u64)(unsigned)c << 32) | (u64)__float_as_uint(pm),
@@ -1174,19 +1180,52 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     const long long tp3 = __builtin_readcyclecounter();
 #endif
     // ---------------- end of round: next list sizes + refreshed price bounds
-    if constexpr (W > 1) {
+    if (clustered) {
       if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort)) {
         aborted = true;
         break;
       }
       Utot = 0;
       bool overflow = false;
+      int cntw[W];
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        Utot += (int)s_gout[2 * w];
+        cntw[w] = (int)s_gout[2 * w];
+        Utot += cntw[w];
         if (w != wg) overflow |= (int)s_gout[2 * w + 1] > kChgCap;
       }
-      if (overflow) {
+      if (Utot > 0 && Utot <= kSoloMax && it + 1 < iters) {
+        // ---- hand everything to member 0 (lists of <= kSoloMax persons live
+        // in LDS only: publish the person ids; their records are in memory)
+        if (wg != 0 && t < cntw[wg]) st_i32(my_ulist + t, s_ri[nxt][t].x);
+        if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort)) {
+          aborted = true;
+          break;
+        }
+        if (wg != 0) {
+          if (t == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
+          return;
+        }
+        int idx = t;
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+          if (idx >= 0 && idx < cntw[w]) {
+            const int jj = __hip_atomic_load(sc.ulist + (size_t)w * 2 * n + idx, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            const float4 pa = ld_person(jj, 0);
+            const float4 pb = ld_person(jj, 1);
+            const int pos = atomicAdd(&s_cnt[nxt], 1);
+            s_rq[nxt][pos] = pa;
+            s_ri[nxt][pos] = make_int4(jj, __float_as_int(pb.y), __float_as_int(pb.z), 0);
+          }
+          idx -= cntw[w];
+        }
+        clustered = false;
+        first = 0;
+        share = n;
+        if (t == 0) s_nchg = 0;
+        __syncthreads();
+      } else if (overflow) {
         // too many refreshes to broadcast (the first, heavy rounds): recompute
         // every bound from the prices themselves (stable between barriers)
         for (int c = t; c < ncell; c += kEmdThreads) {
