@@ -398,6 +398,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ int s_err, s_abort, s_nchg;
   __shared__ int s_alarm[2];  // by round parity: set in Bid, read after the barrier, cleared a round later
   __shared__ unsigned s_gout[2 * kMaxCluster];
+#ifdef MVP_EMD_PROFILE
+  __shared__ unsigned long long s_hist[16];  // wave-mode bids: [0..7] duration buckets, [8] sum nsub, [9] sum cells visited, [10] count, [11] linear scans, [12] sum cycles
+  if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+#endif
   // this round's bids for the first kBidCache list positions (skips two
   // dependent global round trips in Assign)
   __shared__ int s_bj[kBidCache], s_bo[kBidCache], s_b2k[kBidCache];
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   // alone (same code, workgroup barriers), the others leave.
   bool clustered = W > 1;
 #ifdef MVP_EMD_PROFILE
-  long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0;
+  long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0;
 #endif
   for (int it = 0; it < iters; ++it) {
     if (Utot == 0) break;
@@ -864,6 +868,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       const float qx = ra.x, qy = ra.y, qz = ra.z;
       const int p1 = rb.y, p2 = rb.z;
       load_rec(u + kEmdWaves);  // prefetch (consumed next iteration)
+#ifdef MVP_EMD_PROFILE
+      const long long tb0 = __builtin_readcyclecounter();
+      int prof_cells = 0;
+#endif
       const int c0 = emd_cell(gg, qx, qy, qz);
 
       // (1) seed: second-largest exact value among DISTINCT real objects --
@@ -1017,9 +1025,25 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         if (cpass)
           wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
         nlist += __builtin_popcountll(cmask);
+#ifdef MVP_EMD_PROFILE
+        prof_cells += __builtin_popcountll(cmask);
+#endif
         if (nlist > (4 * kRowListCap) - kWave) visit();  // keep room for the next 64
       }
       visit();
+#ifdef MVP_EMD_PROFILE
+      if (lane == 0 && it >= 100) {
+        const long long d = __builtin_readcyclecounter() - tb0;
+        int bkt = 0;
+        while (bkt < 7 && d >= (2000ll << bkt)) ++bkt;
+        atomicAdd(&s_hist[bkt], 1ull);
+        atomicAdd(&s_hist[8], (unsigned long long)nsub);
+        atomicAdd(&s_hist[9], (unsigned long long)prof_cells);
+        atomicAdd(&s_hist[10], 1ull);
+        if (linear) atomicAdd(&s_hist[11], 1ull);
+        atomicAdd(&s_hist[12], (unsigned long long)d);
+      }
+#endif
       if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
         if (lane == 0) s_err = 1;
         st.bk = 0;
@@ -1225,6 +1249,69 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         share = n;
         if (t == 0) s_nchg = 0;
         __syncthreads();
+      } else {
+        // ---- rebalance: the round lasts as long as the fullest workgroup's
+        // bid passes (16 bidders per pass, 64 in row mode).  When an even
+        // split would need fewer passes than the fullest list does, lists
+        // above their even share hand the surplus (their last entries) to the
+        // lists below it.  Everybody derives the same plan from the gathered
+        // counts; the ids travel through the donors' dead current lists.
+        int maxc = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) maxc = max(maxc, cntw[w]);
+        const int even = (Utot + W - 1) / W;
+        const int cap = even > kRowModeMin ? (even + 63) / 64 * 64 : (even + 15) / 16 * 16;
+        if (maxc > cap && it + 1 < iters) {
+          const int base = Utot / W, rem = Utot % W;
+          int exc[W], dfc[W], exoff = 0, dfoff = 0, my_exoff = 0, my_dfoff = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            const int tgt = base + (w < rem ? 1 : 0);
+            exc[w] = max(0, cntw[w] - tgt);
+            dfc[w] = max(0, tgt - cntw[w]);
+            if (w == wg) { my_exoff = exoff; my_dfoff = dfoff; }
+            exoff += exc[w];
+            dfoff += dfc[w];
+          }
+          (void)my_exoff;
+          const int my_exc = exc[wg], my_dfc = dfc[wg], my_cnt = cntw[wg];
+          int *dead = my_ulist + (size_t)cur * n;   // this round's list: no longer read
+          for (int i = t; i < my_exc; i += kEmdThreads) {
+            const int pos = my_cnt - my_exc + i;
+            st_i32(dead + i, pos < kRecCap ? s_ri[nxt][pos].x : Lnext[pos]);
+          }
+          if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort)) {
+            aborted = true;
+            break;
+          }
+          for (int i = t; i < my_dfc; i += kEmdThreads) {
+            int p = my_dfoff + i, jj = -1;   // p-th entry of the pool = donors' surpluses in order
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              if (p >= 0 && p < exc[w])
+                jj = __hip_atomic_load(sc.ulist + (size_t)w * 2 * n + (size_t)cur * n + p, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+              p -= exc[w];
+            }
+            const int pos = my_cnt + i;
+            if (pos < kRecCap) {
+              const float4 pa = ld_person(jj, 0);
+              const float4 pb = ld_person(jj, 1);
+              s_rq[nxt][pos] = pa;
+              s_ri[nxt][pos] = make_int4(jj, __float_as_int(pb.y), __float_as_int(pb.z), 0);
+            } else {
+              Lnext[pos] = jj;
+            }
+          }
+          if (t == 0) s_cnt[nxt] = my_cnt - my_exc + my_dfc;
+          __syncthreads();
+#ifdef MVP_EMD_PROFILE
+          n_rebal += 1;
+#endif
+        }
+      }
+      if (!clustered) {
+        // (just collapsed: nothing to fetch)
       } else if (overflow) {
         // too many refreshes to broadcast (the first, heavy rounds): recompute
         // every bound from the prices themselves (stable between barriers)
@@ -1293,8 +1380,12 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
 #ifdef MVP_EMD_PROFILE
     if (cloud < 2)
-      printf("cloud %d wg %d: rounds %lld bids %lld alarms %lld | cycles bid %lld sync1 %lld assign %lld sync2 %lld\n",
-             cloud, wg, n_rounds, n_bids, n_alarm, cyc_bid, cyc_sync1, cyc_assign, cyc_sync2);
+      printf("cloud %d wg %d wave-mode bids after round 100: %llu, mean cycles %llu, mean sub-box cells %llu, mean cells visited %llu, linear %llu | <2k %llu <4k %llu <8k %llu <16k %llu <32k %llu <64k %llu <128k %llu more %llu\n",
+             cloud, wg, s_hist[10], s_hist[12] / (s_hist[10] + 1), s_hist[8] / (s_hist[10] + 1), s_hist[9] / (s_hist[10] + 1), s_hist[11],
+             s_hist[0], s_hist[1], s_hist[2], s_hist[3], s_hist[4], s_hist[5], s_hist[6], s_hist[7]);
+    if (cloud < 2)
+      printf("cloud %d wg %d: rounds %lld bids %lld alarms %lld rebalances %lld | cycles bid %lld sync1 %lld assign %lld sync2 %lld\n",
+             cloud, wg, n_rounds, n_bids, n_alarm, n_rebal, cyc_bid, cyc_sync1, cyc_assign, cyc_sync2);
 #endif
   }
   // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
