@@ -938,18 +938,19 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       // approximate reciprocals are enough: (i + 0.5) / m is >= 0.5/144 away
       // from an integer, far above the 1 ulp error of v_rcp_f32
       const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
-      const int sub = lane >> 5, sl = lane & 31;
+      const int sub = lane >> 4, sl = lane & 15;
       unsigned short *wl = w_list[wave];
       int nlist = 0;
-      // (3) visit listed cells, 8 per step: each 32-lane half-wave takes 4
-      // cells, so 4 independent 16-byte loads per lane are in flight at once
-      // (the auction is bound by dependent L2 round trips, not by issue).
+      // (3) visit listed cells, 16 per step: each 16-lane row takes 4 cells
+      // (a cell holds ~10 objects), so 4 independent 16-byte loads per lane are
+      // in flight at once and a typical bid (~10 surviving cells) needs ONE
+      // dependent memory round trip here.
       auto visit = [&]() {
-        for (int k0 = 0; k0 < nlist; k0 += 8) {
+        for (int k0 = 0; k0 < nlist; k0 += 16) {
           int s[4], s1[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int k = k0 + r * 2 + sub;
+            const int k = k0 + r * 4 + sub;
             s[r] = 0;
             s1[r] = 0;
             if (k < nlist) {
@@ -972,11 +973,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               const unsigned long long m = __ballot(ps);
               if (m) emd_fold(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm);
             }
-            // cells with more than 32 members (rare): next 32
+            // cells with more than 16 members (rare): next 16
             bool mine = false;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              s[r] += 32;
+              s[r] += 16;
               mine |= s[r] < s1[r];
             }
             more = __any(mine);
