@@ -8,7 +8,7 @@
 // bidder scans all n objects every round (O(n^2 k)), and GetMax is racy.
 // MI355X-first design:
 //   * ONE persistent launch.  A cloud is owned by a CLUSTER of W 1024-lane
-//     workgroups (W = 1, 2 or 4, chosen so that b*W workgroups fit the chip's
+//     workgroups (W = 1, 2, 4 or 8, chosen so that b*W workgroups fit the chip's
 //     CUs: at the headline batch of 64 clouds a single workgroup per cloud
 //     would leave 192 of 256 CUs idle).  Every workgroup keeps its own
 //     unassigned list and bids for it; the auction state (prices, owners,
@@ -76,7 +76,7 @@ constexpr int kRecCap = 512;     // list positions whose person record is cached
 #endif
 constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 bidders share a wave
 constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
-constexpr int kMaxCluster = 4;   // workgroups per cloud (W)
+constexpr int kMaxCluster = 8;   // workgroups per cloud (W)
 constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
 constexpr int kSoloMax = 16;     // unassigned persons below which one workgroup finishes the auction alone
 constexpr unsigned kSpinLimit = 1u << 22;  // bound of every cluster wait (a few seconds), then abort
@@ -1422,8 +1422,8 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
   grad_xyz[a + 2] += g * (xyz1[a + 2] - xyz2[c + 2]);
 }
 
-// Workgroups per cloud: as many (1, 2, 4) as keep b*W workgroups co-resident,
-// one per CU.  MVP_EMD_CLUSTER=1|2|4 overrides (still capped by the CU count).
+// Workgroups per cloud: as many (1, 2, 4, 8) as keep b*W workgroups co-resident,
+// one per CU.  MVP_EMD_CLUSTER=1|2|4|8 overrides (still capped by the CU count).
 static int emd_cluster_width(int b) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
@@ -1480,7 +1480,8 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
     return check_launch("mvp_emd_forward");
   const int w = emd_cluster_width(b);
   hipError_t err = hipErrorUnknown;
-  if (w == 4) err = emd_launch<4>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
+  if (w == 8) err = emd_launch<8>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
+  else if (w == 4) err = emd_launch<4>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
   else if (w == 2) err = emd_launch<2>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
   if (err != hipSuccess) {  // w == 1, or the cluster does not fit this device
     (void)hipGetLastError();

@@ -123,10 +123,10 @@ def cluster_width(monkeypatch):
     return pin
 
 
-@pytest.mark.parametrize("width", [1, 2, 4])
+@pytest.mark.parametrize("width", [1, 2, 4, 8])
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "duplicates"])
 def test_emd_every_cluster_width_matches_oracle(oracle, cluster_width, width, kind):
-    """Same bits whether one, two or four workgroups share a cloud.  The
+    """Same bits whether one, two, four or eight workgroups share a cloud.  The
     clustered case keeps thousands of bidders on a handful of objects (bid
     increments within the reference's 1e-6 GetMax band, more bidders per
     workgroup than the LDS bid cache holds); duplicates force value ties."""

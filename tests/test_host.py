@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.mvp_abi_version() == 1
-    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * 100 + 65536 + 272)
+    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * 132 + 8 * 2048 * 8 + 272)
 
 
 def test_argument_guards_need_no_gpu():
