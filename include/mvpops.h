@@ -88,7 +88,10 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * (may be non-injective after the forced last round).
  * Guards as emd_cuda.cu:236-249: n %% 1024 == 0, b <= 512 (-> MVP_EBADSHAPE);
  * iters >= 1.  Deterministic: GetMax's racy last-writer (emd_cuda.cu:188-191)
- * is pinned to the highest qualifying bidder index. */
+ * is pinned to the highest qualifying bidder index.
+ * One persistent (cooperative) launch; up to 8 workgroups share a cloud when
+ * b leaves CUs free (b*W <= CU count; MVP_EMD_CLUSTER=1|2|4|8 caps W).  The
+ * call enqueues one small memset (barrier words, statistics) ahead of it. */
 int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
                     float *dist, int *assignment, float eps, int iters,
                     void *scratch, long long scratch_bytes, void *stream);
