@@ -160,6 +160,30 @@ def test_emd_cluster_widths_agree_at_full_size(cluster_width):
     assert torch.equal(out[1][1], out[4][1]) and torch.equal(out[1][0], out[4][0])
 
 
+def test_emd_cluster_under_competing_load(oracle, cluster_width):
+    """The workgroups of a cluster exchange state inside one launch (write-through
+    stores, L1-bypassing loads, polled granules).  Run it while another stream
+    streams through HBM and occupies CUs, so that members start unevenly and
+    every hand-off happens under load; repeated calls also re-use a dirty
+    scratch buffer.  Results must not move by a bit."""
+    from mvp_benchmark_amd.metrics import emd
+    cluster_width(4)
+    x1, x2 = rand_clouds(21, 4, 4096, 3), rand_clouds(22, 4, 4096, 3)
+    od, oa = oracle.emd_forward(x1, x2, 0.004, 600)
+    t1, t2 = dev(x1), dev(x2)
+    side = torch.cuda.Stream()
+    big = torch.rand(64 * 1024 * 1024, device=DEV)
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            acc = big
+            for _ in range(40):
+                acc = acc * 1.0001 + 0.5      # ~0.5 GB of traffic per op, thousands of workgroups
+        dist, ass = emd()(t1, t2, 0.004, 600)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+        np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
 def test_emd_clustered_input_with_ties(oracle):
     """Duplicated points force equal values, i.e. the tie order."""
     from mvp_benchmark_amd.metrics import emd
