@@ -6,8 +6,10 @@ The operator imports are the reference's own (`model_utils.py:19-21`):
     sys.path.append("../utils"); from metrics import ...; from mm3d_pn2 import ...
 resolved here against this repo's `utils/` shims, i.e. the HIP kernels of
 libmvpops.so.  Nothing in this file falls back to a CPU implementation of an
-operator; the pure-PyTorch helpers (`knn`, `knn_point`, ...) are pure PyTorch in
-the reference too.
+operator.  `knn` / `knn_point` are pure PyTorch in the reference (matmul + topk
+over a materialised distance matrix); here coordinate (C = 3) neighbour
+searches on the GPU go through the fused knn operator,
+feature-space searches and CPU tensors keep the PyTorch formulation.
 """
 import math
 import os
@@ -23,6 +25,7 @@ if _UTILS not in sys.path:
 from metrics import cd, fscore, emd  # noqa: E402
 from mm3d_pn2 import (furthest_point_sample, gather_points, grouping_operation,  # noqa: E402
                       ball_query, three_nn)
+from mm3d_pn2 import knn as knn_op  # noqa: E402
 
 
 # --------------------------------------------------------------------------
@@ -55,9 +58,28 @@ def calc_emd(output, gt, eps=0.005, iterations=50):
 # --------------------------------------------------------------------------
 # pure-PyTorch neighbourhood helpers (model_utils.py:242-272, 230-239)
 # --------------------------------------------------------------------------
+def _knn_xyz(k, points, centers):
+    """k nearest `points` (B,N,3) of every centre (B,M,3) -> idx (B,M,k) int64,
+    ascending distance, through the knn operator (one fused scan per centre,
+    exact fp32 direct-difference distances) instead of a materialised (B,M,N)
+    matrix + topk.  Same neighbours as the matmul formulation except where two
+    candidates are closer to each other than that formulation's own rounding
+    error (tests/test_gpu_harness.py pins the tolerance)."""
+    idx = knn_op(k, points.contiguous(), centers.contiguous(), False)     # (B,k,M) int32
+    return idx.transpose(1, 2).contiguous().long()
+
+
+def _use_knn_op(t, k, channel_dim):
+    return t.is_cuda and t.dtype == torch.float32 and t.size(channel_dim) == 3 and 0 < k <= 100
+
+
 def knn(x, k):
     """x (B,C,N) -> idx (B,N,k) of the k nearest points (self included), by
-    top-k of the negative squared distance (model_utils.py:242-247)."""
+    top-k of the negative squared distance (model_utils.py:242-247).  For
+    coordinates (C = 3) the fused knn operator does the search."""
+    if _use_knn_op(x, k, 1):
+        pts = x.detach().transpose(2, 1)
+        return _knn_xyz(k, pts, pts)
     sq = (x * x).sum(dim=1, keepdim=True)                       # (B,1,N)
     inner = -2 * torch.matmul(x.transpose(2, 1), x)             # (B,N,N)
     neg_dist = -sq - inner - sq.transpose(2, 1)                 # -|xi|^2 + 2 xi.xj - |xj|^2
@@ -67,12 +89,19 @@ def knn(x, k):
 def knn_point(pk, point_input, point_output):
     """Top-pk neighbours of every point_output (B,M,C) among point_input
     (B,N,C): returns (negative squared distance (B,M,pk), idx (B,M,pk))
-    (model_utils.py:250-259)."""
+    (model_utils.py:250-259).  Differentiable through the distances."""
     inner = -2 * torch.matmul(point_output, point_input.transpose(2, 1))  # (B,M,N)
     out_sq = (point_output * point_output).sum(dim=2, keepdim=True)        # (B,M,1)
     in_sq = (point_input * point_input).sum(dim=2).unsqueeze(1)            # (B,1,N)
     pairwise = -out_sq - inner - in_sq
     return pairwise.topk(k=pk, dim=-1)
+
+
+def knn_point_idx(pk, point_input, point_output):
+    """The index half of knn_point; coordinates go through the knn operator."""
+    if _use_knn_op(point_input, pk, 2) and point_output.size(2) == 3:
+        return _knn_xyz(pk, point_input.detach(), point_output.detach())
+    return knn_point(pk, point_input, point_output)[1]
 
 
 def knn_point_all(pk, point_input, point_output):
@@ -135,7 +164,7 @@ def edge_preserve_sampling(feature_input, point_input, num_samples, k=10):
         .transpose(1, 2).contiguous()
 
     pk = int(min(k, num_points))
-    _, pn_idx = knn_point(pk, point_input, point_output)
+    pn_idx = knn_point_idx(pk, point_input, point_output)
     pn_idx = pn_idx.detach().int()
     neighbor_feature = gather_points(feature_input, pn_idx.view(batch_size, num_samples * pk))
     neighbor_feature = neighbor_feature.view(batch_size, feature_size, num_samples, pk).max(dim=3)[0]

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(
 }
 
 // -------------------------------------------------------------------- knn
-constexpr int kQTile = 1024;  // candidates per LDS tile
+constexpr int kQTile = 1024;  // candidates per LDS tile (a multiple of 32)
 
 // Max-heap in LDS, one column per thread: slot s of thread t at [s*T + t].
 template <int T>
@@ -112,19 +112,49 @@ __global__ __launch_bounds__(T) void knn_kernel(
   }
   float rootd = 1e10f;
 
+  // Candidates are screened 32 at a time against the heap root the sub-tile
+  // started with (branch-free, three wave-uniform ds_read_b128 per four
+  // candidates); the survivors -- a superset of what the reference admits,
+  // because the root only falls -- are then replayed in index order against
+  // the CURRENT root, so the sequence of heap operations is the reference's.
+  // A wave therefore runs the divergent heap update max-over-lanes(survivors)
+  // times per sub-tile instead of once per candidate that any lane admits.
   for (int k2 = 0; k2 < n; k2 += kQTile) {
     const int cnt = min(kQTile, n - k2);
+    const int padded = (cnt + 31) / 32 * 32;
     __syncthreads();
-    for (int q = t; q < cnt * 3; q += T) tile[q] = pts[(size_t)k2 * 3 + q];
+    for (int q = t; q < padded * 3; q += T)
+      tile[q] = q < cnt * 3 ? pts[(size_t)k2 * 3 + q] : __builtin_inff();  // d2 = +inf: never admitted
     __syncthreads();
-    for (int i = 0; i < cnt; ++i) {
-      const float d2 = sqdist3(nx - tile[i * 3 + 0], ny - tile[i * 3 + 1],
-                               nz - tile[i * 3 + 2]);
-      if (d2 < rootd) {
-        hd[t] = d2;
-        hi[t] = k2 + i;
-        knn_reheap<T>(hd, hi, t, nsample);
-        rootd = hd[t];
+    const float4 *__restrict__ t4 = reinterpret_cast<const float4 *>(tile);
+    for (int sub = 0; sub < padded; sub += 32) {
+      unsigned mask = 0u;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float4 a = t4[(sub / 4 + g) * 3 + 0];
+        const float4 b = t4[(sub / 4 + g) * 3 + 1];
+        const float4 c = t4[(sub / 4 + g) * 3 + 2];
+        const float d0 = sqdist3(nx - a.x, ny - a.y, nz - a.z);
+        const float d1 = sqdist3(nx - a.w, ny - b.x, nz - b.y);
+        const float d2 = sqdist3(nx - b.z, ny - b.w, nz - c.x);
+        const float d3 = sqdist3(nx - c.y, ny - c.z, nz - c.w);
+        mask |= (d0 < rootd ? 1u : 0u) << (4 * g + 0);
+        mask |= (d1 < rootd ? 1u : 0u) << (4 * g + 1);
+        mask |= (d2 < rootd ? 1u : 0u) << (4 * g + 2);
+        mask |= (d3 < rootd ? 1u : 0u) << (4 * g + 3);
+      }
+      while (__any(mask != 0u)) {
+        if (mask != 0u) {
+          const int i = sub + __builtin_ctz(mask);
+          mask &= mask - 1u;
+          const float d2 = sqdist3(nx - tile[i * 3 + 0], ny - tile[i * 3 + 1], nz - tile[i * 3 + 2]);
+          if (d2 < rootd) {
+            hd[t] = d2;
+            hi[t] = k2 + i;
+            knn_reheap<T>(hd, hi, t, nsample);
+            rootd = hd[t];
+          }
+        }
       }
     }
   }

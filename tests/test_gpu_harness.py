@@ -39,6 +39,36 @@ def test_calc_cd_and_calc_emd_formulas(oracle):
     np.testing.assert_allclose(e.cpu().numpy(), np.sqrt(od).mean(1), rtol=1e-6)
 
 
+def test_coordinate_knn_goes_through_the_op(oracle):
+    """model_utils.knn / knn_point_idx on coordinates use the
+    fused knn operator.  Pinned three ways: (1) bit-identical to the oracle's
+    knn (the operator's own contract), (2) the chosen neighbours are the true k
+    nearest in float64 up to 1e-6 relative on the k-th distance, (3) they agree
+    with the reference's matmul + topk formulation wherever consecutive
+    neighbour distances differ by more than that formulation's rounding
+    (2e-6 absolute for points in the unit cube)."""
+    import model_utils as mu
+    B, N, M, k = 3, 1536, 512, 16
+    pts, ctr = rand_clouds(5, B, N, 3), rand_clouds(6, B, M, 3)
+    idx = mu.knn(dev(np.ascontiguousarray(pts.transpose(0, 2, 1))), k)              # (B,N,k), self included
+    assert idx.dtype == torch.int64 and idx.shape == (B, N, k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oracle.knn(k, pts).transpose(0, 2, 1))
+    assert (idx[:, :, 0].cpu() == torch.arange(N)).all()
+    pn = mu.knn_point_idx(k, dev(pts), dev(ctr))                                    # (B,M,k)
+    np.testing.assert_array_equal(pn.cpu().numpy(), oracle.knn(k, pts, ctr).transpose(0, 2, 1))
+    d2 = ((ctr[:, :, None].astype(np.float64) - pts[:, None].astype(np.float64)) ** 2).sum(-1)
+    chosen = np.take_along_axis(d2, pn.cpu().numpy(), -1)
+    want = np.sort(d2, -1)[..., :k]
+    np.testing.assert_allclose(chosen, want, rtol=1e-6, atol=1e-12)                  # ascending, true k nearest
+    ref_idx = mu.knn_point(k, dev(pts), dev(ctr))[1].cpu().numpy()                   # matmul + topk
+    differ = ref_idx != pn.cpu().numpy()
+    gap = np.abs(np.take_along_axis(d2, ref_idx, -1) - chosen)
+    assert (gap[differ] < 2e-6).all() and differ.mean() < 1e-3
+    # feature-space searches keep the PyTorch formulation
+    feat = dev(rand_clouds(7, 2, 24, 256))
+    assert mu.knn(feat, 8).shape == (2, 256, 8)
+
+
 def test_edge_preserve_sampling_composition(oracle):
     import model_utils as mu
     B, C, N, S, k = 2, 16, 768, 384, 10
