@@ -117,12 +117,20 @@ def index_points(points, idx):
     return points[batch, idx, :]
 
 
+def _on_op_layer(t):
+    return t.is_cuda and t.dtype == torch.float32
+
+
 def get_edge_features(x, idx):
     """x (B,C,1,N) or (B,C,N), idx (B,N,k) -> neighbour features (B,C,k,N)
-    (model_utils.py:113-124)."""
+    (model_utils.py:113-124).  The gather (and its scatter-add gradient) is the
+    grouping operator instead of advanced indexing on a transposed copy."""
     batch_size, num_points, k = idx.size()
     if x.dim() == 4:
         x = x.squeeze(2)
+    if _on_op_layer(x):
+        # gather with the (small) index array transposed: the result is already (B,C,k,N) contiguous
+        return grouping_operation(x.contiguous(), idx.int().transpose(1, 2).contiguous())
     num_dims = x.size(1)
     flat = x.transpose(2, 1).reshape(batch_size * num_points, num_dims)
     base = torch.arange(batch_size, device=x.device).view(-1, 1, 1) * num_points
@@ -136,6 +144,11 @@ def get_graph_feature(x, k=20, minus_center=True):
     idx = knn(x, k=k)
     batch_size, num_points, _ = idx.size()
     num_dims = x.size(1)
+    if _on_op_layer(x):
+        x = x.contiguous()
+        nbr = grouping_operation(x, idx.int().contiguous())                 # (B,C,N,k)
+        ctr = x.unsqueeze(3).expand(-1, -1, -1, k)
+        return torch.cat((ctr, nbr - ctr if minus_center else nbr), dim=1)
     pts = x.transpose(2, 1).contiguous()                                   # (B,N,C)
     base = torch.arange(batch_size, device=x.device).view(-1, 1, 1) * num_points
     nbr = pts.view(batch_size * num_points, num_dims)[(idx + base).view(-1)]
