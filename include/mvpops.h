@@ -40,7 +40,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 1
+#define MVP_ABI_VERSION 2
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -59,6 +59,19 @@ const char *mvp_last_hip_error(void);
 int mvp_chamfer_forward(int b, int n, int m, const float *xyz1,
                         const float *xyz2, float *dist1, float *dist2,
                         int *idx1, int *idx2, void *stream);
+
+/* Same contract and bit-identical results as mvp_chamfer_forward, for large
+ * clouds: both sides are first bucketed into Morton-ordered cells inside the
+ * caller's scratch (mvp_chamfer_scratch_bytes(b,n,m) bytes, 16-byte aligned,
+ * contents irrelevant), then candidate tiles whose bounding box is farther
+ * than the current best of a whole wave of queries are skipped.  Falls back
+ * to the exhaustive kernel (scratch unused, may be NULL) when n or m < 2048
+ * or n*m < 2^24. */
+long long mvp_chamfer_scratch_bytes(int b, int n, int m);
+int mvp_chamfer_forward_sorted(int b, int n, int m, const float *xyz1,
+                               const float *xyz2, float *dist1, float *dist2,
+                               int *idx1, int *idx2, void *scratch,
+                               long long scratch_bytes, void *stream);
 
 /* Replaces chamfer_3D.backward = chamfer_backward (chamfer_cuda.cpp:22-27,32)
  * -> chamfer_cuda_backward (chamfer3D.cu:176-195) -> NmDistanceGradKernel x2

@@ -20,6 +20,7 @@ _ERR = {-1: "MVP_EBADSHAPE (bad shape / size guard)",
 # name -> argument kinds: p = device pointer, i = int, f = float, q = int64
 SIGNATURES = {
     "mvp_chamfer_forward": "iiipppppp",
+    "mvp_chamfer_forward_sorted": "iiipppppppq",
     "mvp_chamfer_backward": "iiipppppppp",
     "mvp_emd_forward": "iippppfipq",
     "mvp_emd_backward": "iippppp",
@@ -61,11 +62,13 @@ def load():
     lib.mvp_last_hip_error.restype = ctypes.c_char_p
     lib.mvp_emd_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_emd_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.mvp_chamfer_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_chamfer_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [_CT[k] for k in sig] + [ctypes.c_void_p]  # + stream
-    if lib.mvp_abi_version() != 1:
+    if lib.mvp_abi_version() != 2:
         raise MvpOpsError("libmvpops.so ABI version mismatch")
     _lib = lib
     return lib
@@ -109,7 +112,11 @@ def emd_scratch_bytes(b, n):
     return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
 
 
+def chamfer_scratch_bytes(b, n, m):
+    return int(load().mvp_chamfer_scratch_bytes(int(b), int(n), int(m)))
+
+
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
-    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes"] \
+    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_chamfer_scratch_bytes"] \
         + list(SIGNATURES)

@@ -122,6 +122,330 @@ __global__ __launch_bounds__(kCdThreads) void nm_distance_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Spatially sorted variant for large clouds: the same result with most of the
+// B*N*M pairs never evaluated.
+//
+// (1) chamfer_sort_kernel buckets each cloud side into 16^3 Morton-ordered
+//     cells (counting sort in LDS) and writes, into caller-provided scratch,
+//     the points in that order as float4 {x, y, z, bits(original index)}, the
+//     bounding box of every run of 16 sorted points (a "tile") and of every run
+//     of 1024 (a "batch").
+// (2) nm_distance_sorted_kernel keeps the brute-force skeleton -- a lane owns Q
+//     queries, candidates stream through LDS batches -- but both sides are in
+//     Morton order, so the 64*Q queries of a wave sit in a small box and a
+//     tile / batch is SKIPPED when the distance between that box and the
+//     tile's box already exceeds the worst current best of the wave.  Batches
+//     are visited outwards from the query block's own position in the order,
+//     so the bests are tight after the first batch or two.
+// Exactness: the box distance uses the same subtract / fma chain as sqdist3 on
+// per-axis gaps that are <= every member pair's |difference| (float subtract,
+// multiply and fma are monotone), so it never exceeds a member pair's computed
+// distance, and a tile is skipped only on strict `>`: a candidate that equals
+// the current best is still evaluated.  Ties go to the lowest ORIGINAL index
+// (chamfer3D.cu:36,46,126) by minimising the key {distance bits, original
+// index} -- the visiting order no longer is the index order.
+constexpr int kCsThreads = 1024;
+constexpr int kCsCells = 4096;  // 16^3
+constexpr int kCsTile = 16;
+constexpr int kCsBatch = 1024;
+constexpr int kCsPad = 0x7fffffff;  // original index of a padding entry
+
+__host__ __device__ inline long long cs_round_up(long long c) { return (c + kCsBatch - 1) / kCsBatch * kCsBatch; }
+// bytes of one sorted side holding c points: points + tile boxes + batch boxes
+__host__ __device__ inline long long cs_side_bytes(long long c) {
+  const long long cp = cs_round_up(c);
+  return cp * 16 + cp / kCsTile * 32 + cp / kCsBatch * 32;
+}
+
+struct CsSide {
+  float4 *pts;   // cp sorted points (padding: +inf coordinates, index kCsPad)
+  float4 *tbox;  // 2 per tile: lo, hi
+  float4 *bbox;  // 2 per batch: lo, hi
+};
+__host__ __device__ inline CsSide cs_carve(char *base, long long c) {
+  const long long cp = cs_round_up(c);
+  CsSide s;
+  s.pts = reinterpret_cast<float4 *>(base);
+  s.tbox = reinterpret_cast<float4 *>(base + cp * 16);
+  s.bbox = reinterpret_cast<float4 *>(base + cp * 16 + cp / kCsTile * 32);
+  return s;
+}
+
+__device__ __forceinline__ int cs_spread4(int v) {  // bit i -> bit 3i
+  v &= 0xF;
+  v = (v | (v << 4)) & 0xC3;
+  v = (v | (v << 2)) & 0x249;
+  return v;
+}
+
+__global__ __launch_bounds__(kCsThreads) void chamfer_sort_kernel(
+    int n1, int n2, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    char *__restrict__ scratch) {
+  const int side = blockIdx.x, cloud = blockIdx.y;
+  const int cnt = side == 0 ? n1 : n2;
+  const long long per_cloud = cs_side_bytes(n1) + cs_side_bytes(n2);
+  const CsSide out = cs_carve(scratch + (size_t)cloud * per_cloud + (side ? cs_side_bytes(n1) : 0), cnt);
+  const float *__restrict__ in = (side == 0 ? xyz1 : xyz2) + (size_t)cloud * cnt * 3;
+  const int cp = (int)cs_round_up(cnt);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  __shared__ int s_cnt[kCsCells];
+  __shared__ int s_start[kCsCells];
+  __shared__ float s_red[6][kCsThreads / 64];
+  __shared__ int s_wsum[kCsThreads / 64];
+
+  // bounding box
+  float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (int k = t; k < cnt; k += kCsThreads) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = in[k * 3 + a];
+      mn[a] = __builtin_fminf(mn[a], v);
+      mx[a] = __builtin_fmaxf(mx[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      mn[a] = __builtin_fminf(mn[a], __shfl_xor(mn[a], off, 64));
+      mx[a] = __builtin_fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+    }
+    if (lane == 0) {
+      s_red[a][wave] = mn[a];
+      s_red[3 + a][wave] = mx[a];
+    }
+  }
+  for (int c = t; c < kCsCells; c += kCsThreads) s_cnt[c] = 0;
+  __syncthreads();
+  float lo[3], ext = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l = s_red[a][0], h = s_red[3 + a][0];
+    for (int w = 1; w < kCsThreads / 64; ++w) {
+      l = __builtin_fminf(l, s_red[a][w]);
+      h = __builtin_fmaxf(h, s_red[3 + a][w]);
+    }
+    lo[a] = l;
+    ext = __builtin_fmaxf(ext, h - l);
+  }
+  if (!(ext > 0.f) || !(ext < 3.0e38f)) ext = 1.f;
+  const float invh = 16.f / ext;
+  auto cell_of = [&](float x, float y, float z) {
+    const int ix = min(15, max(0, (int)((x - lo[0]) * invh)));
+    const int iy = min(15, max(0, (int)((y - lo[1]) * invh)));
+    const int iz = min(15, max(0, (int)((z - lo[2]) * invh)));
+    return cs_spread4(ix) | (cs_spread4(iy) << 1) | (cs_spread4(iz) << 2);
+  };
+  for (int k = t; k < cnt; k += kCsThreads)
+    atomicAdd(&s_cnt[cell_of(in[k * 3 + 0], in[k * 3 + 1], in[k * 3 + 2])], 1);
+  __syncthreads();
+  {  // exclusive prefix sum over 4096 cells, 4 per thread
+    int v[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = s_cnt[4 * t + i];
+      sum += v[i];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s_start[4 * t + i] = base;
+      base += v[i];
+    }
+    __syncthreads();
+    for (int c = t; c < kCsCells; c += kCsThreads) s_cnt[c] = 0;
+    __syncthreads();
+  }
+  for (int k = t; k < cnt; k += kCsThreads) {
+    const float x = in[k * 3 + 0], y = in[k * 3 + 1], z = in[k * 3 + 2];
+    const int c = cell_of(x, y, z);
+    out.pts[s_start[c] + atomicAdd(&s_cnt[c], 1)] = make_float4(x, y, z, __int_as_float(k));
+  }
+  for (int k = cnt + t; k < cp; k += kCsThreads)
+    out.pts[k] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(kCsPad));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int tl = t; tl < cp / kCsTile; tl += kCsThreads) {
+    float bl[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float bh[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = 0; i < kCsTile; ++i) {
+      const float4 p = out.pts[tl * kCsTile + i];
+      if (__float_as_int(p.w) != kCsPad) {
+        bl[0] = __builtin_fminf(bl[0], p.x); bh[0] = __builtin_fmaxf(bh[0], p.x);
+        bl[1] = __builtin_fminf(bl[1], p.y); bh[1] = __builtin_fmaxf(bh[1], p.y);
+        bl[2] = __builtin_fminf(bl[2], p.z); bh[2] = __builtin_fmaxf(bh[2], p.z);
+      }
+    }
+    out.tbox[2 * tl + 0] = make_float4(bl[0], bl[1], bl[2], 0.f);
+    out.tbox[2 * tl + 1] = make_float4(bh[0], bh[1], bh[2], 0.f);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int bt = t; bt < cp / kCsBatch; bt += kCsThreads) {
+    float bl[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float bh[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = 0; i < kCsBatch / kCsTile; ++i) {
+      const float4 l = out.tbox[2 * (bt * (kCsBatch / kCsTile) + i) + 0];
+      const float4 h = out.tbox[2 * (bt * (kCsBatch / kCsTile) + i) + 1];
+      bl[0] = __builtin_fminf(bl[0], l.x); bh[0] = __builtin_fmaxf(bh[0], h.x);
+      bl[1] = __builtin_fminf(bl[1], l.y); bh[1] = __builtin_fmaxf(bh[1], h.y);
+      bl[2] = __builtin_fminf(bl[2], l.z); bh[2] = __builtin_fmaxf(bh[2], h.z);
+    }
+    out.bbox[2 * bt + 0] = make_float4(bl[0], bl[1], bl[2], 0.f);
+    out.bbox[2 * bt + 1] = make_float4(bh[0], bh[1], bh[2], 0.f);
+  }
+}
+
+// squared distance between two axis-aligned boxes (0 if they overlap), with
+// the rounding behaviour described above
+__device__ __forceinline__ float cs_box_dist(const float (&qlo)[3], const float (&qhi)[3],
+                                             const float4 &tlo, const float4 &thi) {
+  const float gx = __builtin_fmaxf(__builtin_fmaxf(tlo.x - qhi[0], qlo[0] - thi.x), 0.f);
+  const float gy = __builtin_fmaxf(__builtin_fmaxf(tlo.y - qhi[1], qlo[1] - thi.y), 0.f);
+  const float gz = __builtin_fmaxf(__builtin_fmaxf(tlo.z - qhi[2], qlo[2] - thi.z), 0.f);
+  return sqdist3(gx, gy, gz);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float cs_dpp_max(float v) {
+  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+  return __builtin_fmaxf(v, o);
+}
+// wave64 maximum with DPP row operations only; result taken from lane 63
+__device__ __forceinline__ float cs_wave_max(float v) {
+  v = cs_dpp_max<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = cs_dpp_max<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = cs_dpp_max<0x141, 0xF>(v);  // row_half_mirror
+  v = cs_dpp_max<0x140, 0xF>(v);  // row_mirror
+  v = cs_dpp_max<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
+  v = cs_dpp_max<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int Q>
+__global__ __launch_bounds__(kCdThreads) void nm_distance_sorted_kernel(
+    int n1, int n2, char *__restrict__ scratch, float *__restrict__ dist1,
+    float *__restrict__ dist2, int *__restrict__ idx1, int *__restrict__ idx2) {
+  const int dir = blockIdx.z;
+  const int nq = dir == 0 ? n1 : n2;
+  const int nc = dir == 0 ? n2 : n1;
+  if ((int)blockIdx.x * (kCdThreads * Q) >= nq) return;
+  const int cloud = blockIdx.y;
+  const long long per_cloud = cs_side_bytes(n1) + cs_side_bytes(n2);
+  char *cbase = scratch + (size_t)cloud * per_cloud;
+  const CsSide s1 = cs_carve(cbase, n1), s2 = cs_carve(cbase + cs_side_bytes(n1), n2);
+  const CsSide qs = dir == 0 ? s1 : s2, cs = dir == 0 ? s2 : s1;
+  float *__restrict__ result = (dir == 0 ? dist1 : dist2) + (size_t)cloud * nq;
+  int *__restrict__ result_i = (dir == 0 ? idx1 : idx2) + (size_t)cloud * nq;
+
+  __shared__ __attribute__((aligned(16))) float4 tile[kCsBatch];
+  __shared__ __attribute__((aligned(16))) float4 tbx[2 * kCsBatch / kCsTile];
+
+  const int tid = threadIdx.x;
+  float qx[Q], qy[Q], qz[Q];
+  int qorig[Q];
+  unsigned long long best[Q];
+  float qlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float qhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    // a wave's 64*Q queries are consecutive in the sorted order (a compact box)
+    int j = blockIdx.x * (kCdThreads * Q) + (tid >> 6) * (64 * Q) + q * 64 + (tid & 63);
+    const bool valid = j < nq;
+    j = valid ? j : nq - 1;
+    const float4 p = qs.pts[j];
+    qx[q] = p.x; qy[q] = p.y; qz[q] = p.z;
+    qorig[q] = valid ? __float_as_int(p.w) : -1;
+    best[q] = ~0ull;
+    qlo[0] = __builtin_fminf(qlo[0], p.x); qhi[0] = __builtin_fmaxf(qhi[0], p.x);
+    qlo[1] = __builtin_fminf(qlo[1], p.y); qhi[1] = __builtin_fmaxf(qhi[1], p.y);
+    qlo[2] = __builtin_fminf(qlo[2], p.z); qhi[2] = __builtin_fmaxf(qhi[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {  // the wave's query box
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      qlo[a] = __builtin_fminf(qlo[a], __shfl_xor(qlo[a], off, 64));
+      qhi[a] = __builtin_fmaxf(qhi[a], __shfl_xor(qhi[a], off, 64));
+    }
+  }
+  float wmax = __builtin_inff();  // worst current best distance in this wave
+
+  const int nb = (int)(cs_round_up(nc) / kCsBatch);
+  const int nblk = (nq + kCdThreads * Q - 1) / (kCdThreads * Q);
+  const int b0 = (int)((long long)blockIdx.x * nb / nblk);  // same relative position in the order
+  for (int k = 0; k < 2 * nb; ++k) {
+    const int bi = b0 + ((k & 1) ? (k + 1) / 2 : -(k / 2));  // b0, b0+1, b0-1, b0+2, ...
+    if (bi < 0 || bi >= nb) continue;                        // block-uniform
+    const bool need = !(cs_box_dist(qlo, qhi, cs.bbox[2 * bi], cs.bbox[2 * bi + 1]) > wmax);  // wave-uniform
+    if (!__syncthreads_or(need)) continue;
+    for (int i = tid; i < kCsBatch; i += kCdThreads) tile[i] = cs.pts[(size_t)bi * kCsBatch + i];
+    if (tid < 2 * kCsBatch / kCsTile) tbx[tid] = cs.tbox[(size_t)bi * (2 * kCsBatch / kCsTile) + tid];
+    __syncthreads();
+    if (need) {
+      // lane l tests tile l of the batch (64 tiles); the survivors are visited
+      // in order and re-tested against the bests as they tighten
+      const float lbl = cs_box_dist(qlo, qhi, tbx[2 * (tid & 63)], tbx[2 * (tid & 63) + 1]);
+      unsigned long long todo = __ballot(!(lbl > wmax));
+      while (todo) {
+        const int s = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbl), s)) > wmax) continue;
+        {
+          // precise test: does ANY query of the wave still need this tile?  (the
+          // same monotone arithmetic on the gaps between the query POINT and
+          // the tile's box, against that query's own best)
+          const float4 tlo = tbx[2 * s], thi = tbx[2 * s + 1];
+          bool mine = false;
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const float gx = __builtin_fmaxf(__builtin_fmaxf(tlo.x - qx[q], qx[q] - thi.x), 0.f);
+            const float gy = __builtin_fmaxf(__builtin_fmaxf(tlo.y - qy[q], qy[q] - thi.y), 0.f);
+            const float gz = __builtin_fmaxf(__builtin_fmaxf(tlo.z - qz[q], qz[q] - thi.z), 0.f);
+            mine |= !(sqdist3(gx, gy, gz) > __uint_as_float((unsigned)(best[q] >> 32)));
+          }
+          if (!__any(mine)) continue;
+        }
+#pragma unroll
+        for (int c = 0; c < kCsTile; ++c) {
+          const float4 p = tile[s * kCsTile + c];
+          const unsigned lo32 = __float_as_uint(p.w);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const float d = sqdist3(p.x - qx[q], p.y - qy[q], p.z - qz[q]);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | lo32;
+            best[q] = key < best[q] ? key : best[q];
+          }
+        }
+        float m = __uint_as_float((unsigned)(best[0] >> 32));
+#pragma unroll
+        for (int q = 1; q < Q; ++q) m = __builtin_fmaxf(m, __uint_as_float((unsigned)(best[q] >> 32)));
+        wmax = cs_wave_max(m);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (qorig[q] >= 0) {
+      result[qorig[q]] = __uint_as_float((unsigned)(best[q] >> 32));
+      result_i[qorig[q]] = (int)(unsigned)best[q];
+    }
+  }
+}
+
 // Gradient.  One thread per (cloud, point); both directions in one launch.
 // grad_xyzA[j] += 2 g (a_j - b_idx), grad_xyzB[idx] -= same (float atomics,
 // accumulation order unspecified as in the reference).
@@ -187,6 +511,35 @@ extern "C" int mvp_chamfer_forward(int b, int n, int m, const float *xyz1,
                        idx2);
   }
   return check_launch("mvp_chamfer_forward");
+}
+
+extern "C" long long mvp_chamfer_scratch_bytes(int b, int n, int m) {
+  if (b < 0 || n < 0 || m < 0) return -1;
+  return (long long)b * (cs_side_bytes(n) + cs_side_bytes(m));
+}
+
+extern "C" int mvp_chamfer_forward_sorted(int b, int n, int m, const float *xyz1,
+                                          const float *xyz2, float *dist1, float *dist2,
+                                          int *idx1, int *idx2, void *scratch,
+                                          long long scratch_bytes, void *stream) {
+  // small clouds: the exhaustive kernel is already cheaper than sorting
+  // (break-even measured at about 4096 x 4096 pairs per cloud)
+  if (b <= 0 || n < 2048 || m < 2048 || (long long)n * m < (1ll << 24) || (n > m ? n : m) > (1 << 30))
+    return mvp_chamfer_forward(b, n, m, xyz1, xyz2, dist1, dist2, idx1, idx2, stream);
+  if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2 || !scratch) return MVP_EBADARG;
+  if (scratch_bytes < mvp_chamfer_scratch_bytes(b, n, m)) return MVP_EBADARG;
+  if ((reinterpret_cast<uintptr_t>(scratch) & 15) != 0) return MVP_EBADARG;
+  if (b > 65535) return MVP_EBADSHAPE;
+  hipLaunchKernelGGL(chamfer_sort_kernel, dim3(2, b), dim3(kCsThreads), 0, as_stream(stream), n, m,
+                     xyz1, xyz2, reinterpret_cast<char *>(scratch));
+  // One query per lane: a wave's 64 consecutive sorted queries make the
+  // smallest box, so the most tiles are skipped (measured: Q = 1 / 2 / 4 ->
+  // 0.88 / 1.02 / 1.35 ms at (64, 16384, 16384); exhaustive 3.95 ms).
+  const int big = n > m ? n : m;
+  dim3 grid((big + kCdThreads - 1) / kCdThreads, b, 2);
+  hipLaunchKernelGGL(nm_distance_sorted_kernel<1>, grid, dim3(kCdThreads), 0, as_stream(stream), n, m,
+                     reinterpret_cast<char *>(scratch), dist1, dist2, idx1, idx2);
+  return check_launch("mvp_chamfer_forward_sorted");
 }
 
 extern "C" int mvp_chamfer_backward(int b, int n, int m, const float *xyz1,

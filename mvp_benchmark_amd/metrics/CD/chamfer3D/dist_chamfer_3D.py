@@ -13,7 +13,11 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
-from ...._lib import call
+from ...._lib import call, chamfer_scratch_bytes
+
+
+SORTED_MIN_POINTS = 2048   # both sides at least this large and
+SORTED_MIN_PAIRS = 1 << 24  # this many pairs per cloud -> spatially sorted kernel
 
 
 def _as_cloud(t):
@@ -32,7 +36,14 @@ class chamfer_3DFunction(Function):
         dev = xyz1.device
         dist = [torch.zeros(B, k, device=dev) for k in (n, m)]
         idx = [torch.zeros(B, k, dtype=torch.int32, device=dev) for k in (n, m)]
-        call("mvp_chamfer_forward", dev, B, n, m, xyz1, xyz2, dist[0], dist[1], idx[0], idx[1])
+        if n >= SORTED_MIN_POINTS and m >= SORTED_MIN_POINTS and n * m >= SORTED_MIN_PAIRS:
+            # large clouds: Morton-sorted sides + tile skipping (same bits, a fraction of the pairs)
+            nbytes = chamfer_scratch_bytes(B, n, m)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            call("mvp_chamfer_forward_sorted", dev, B, n, m, xyz1, xyz2, dist[0], dist[1], idx[0], idx[1],
+                 scratch, nbytes)
+        else:
+            call("mvp_chamfer_forward", dev, B, n, m, xyz1, xyz2, dist[0], dist[1], idx[0], idx[1])
         ctx.save_for_backward(xyz1, xyz2, *idx)
         ctx.mark_non_differentiable(*idx)
         return dist[0], dist[1], idx[0], idx[1]

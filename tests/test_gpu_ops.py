@@ -22,7 +22,7 @@ def dev(a, dtype=None):
 def test_extension_is_loaded_not_a_fallback():
     from mvp_benchmark_amd import _lib
     lib = _lib.load()
-    assert lib.mvp_abi_version() == 1
+    assert lib.mvp_abi_version() == 2
     assert "libmvpops.so" in open("/proc/self/maps").read()
     assert torch.cuda.is_available()
 
@@ -58,6 +58,52 @@ def test_chamfer_golden_vectors(oracle, chamfer_golden):
                                    (2, 16384, 2048), (70, 3072, 2048)])
 def test_chamfer_matches_oracle(oracle, b, n, m):
     _cd_check(oracle, rand_clouds(n, b, n, 3), rand_clouds(m + 1, b, m, 3))
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 4096, 4096), (3, 8192, 2500), (2, 3000, 6000), (1, 16384, 16384)])
+def test_chamfer_sorted_variant_is_bit_identical(oracle, b, n, m):
+    """Clouds of >= 2048 points per side and >= 2^24 pairs take the Morton-sorted, tile-skipping
+    kernel: distances AND indices equal the exhaustive kernel's / the oracle's."""
+    from mvp_benchmark_amd import _lib
+    a, c = rand_clouds(n + 3, b, n, 3), rand_clouds(m + 5, b, m, 3)
+    ta, tc = dev(a), dev(c)
+    outs = []
+    for name in ("mvp_chamfer_forward", "mvp_chamfer_forward_sorted"):
+        d1, d2 = torch.zeros(b, n, device=DEV), torch.zeros(b, m, device=DEV)
+        i1 = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+        i2 = torch.zeros(b, m, dtype=torch.int32, device=DEV)
+        if name.endswith("sorted"):
+            nbytes = _lib.chamfer_scratch_bytes(b, n, m)
+            scratch = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=DEV)   # contents are irrelevant
+            _lib.call(name, ta.device, b, n, m, ta, tc, d1, d2, i1, i2, scratch, nbytes)
+        else:
+            _lib.call(name, ta.device, b, n, m, ta, tc, d1, d2, i1, i2)
+        outs.append((d1, d2, i1, i2))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    if n * m <= 8192 * 2500:
+        o1, o2, j1, j2 = oracle.chamfer_forward(a, c)
+        np.testing.assert_array_equal(outs[1][0].cpu().numpy(), o1)
+        np.testing.assert_array_equal(outs[1][2].cpu().numpy(), j1)
+        np.testing.assert_array_equal(outs[1][3].cpu().numpy(), j2)
+
+
+def test_chamfer_sorted_variant_ties_and_clusters(oracle):
+    """Lattice points (exact distance ties -> lowest original index), duplicated
+    points and a tight cluster against a spread cloud (no tile can be skipped)."""
+    from mvp_benchmark_amd.metrics import cd
+    g = np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32) / 16
+    lattice = np.ascontiguousarray(g[:, np.random.default_rng(0).permutation(4096)])
+    shifted = np.ascontiguousarray((g + np.float32(1 / 32))[:, np.random.default_rng(1).permutation(4096)])
+    dup = np.tile(rand_clouds(2, 1, 1024, 3), (1, 4, 1))
+    tight = (0.5 + 0.001 * rand_clouds(3, 1, 4096, 3)).astype(np.float32)
+    for a, c in [(lattice, shifted), (dup, rand_clouds(4, 1, 4096, 3)), (tight, rand_clouds(5, 1, 4096, 3)), (lattice, lattice)]:
+        d1, d2, i1, i2 = cd()(dev(a), dev(c))
+        o1, o2, j1, j2 = oracle.chamfer_forward(a, c)
+        np.testing.assert_array_equal(d1.cpu().numpy(), o1)
+        np.testing.assert_array_equal(d2.cpu().numpy(), o2)
+        np.testing.assert_array_equal(i1.cpu().numpy(), j1)
+        np.testing.assert_array_equal(i2.cpu().numpy(), j2)
 
 
 def test_chamfer_exact_ties(oracle):
