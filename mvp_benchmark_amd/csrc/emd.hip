@@ -395,6 +395,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ float s_red[6][kEmdWaves];
   __shared__ int s_wsum[kEmdWaves];
   __shared__ int s_cnt[2];
+  __shared__ int s_next;             // next undrawn list position of the round (wave-mode bids)
   __shared__ int s_err, s_abort, s_nchg;
   __shared__ int s_alarm[2];  // by round parity: set in Bid, read after the barrier, cleared a round later
   __shared__ unsigned s_gout[2 * kMaxCluster];
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     s_abort = 0;
     s_alarm[0] = 0;
     s_alarm[1] = 0;
+    s_next = kEmdWaves;
     s_nchg = 0;
   }
   __syncthreads();
@@ -846,28 +848,21 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     }
     } else {
     // ---------------- Bid (emd_cuda.cu:95-179): one wave per bidder
-    // A bidder's record comes from the LDS cache (list position < kRecCap)
-    // or, in the heavy early rounds, from global memory with the next
-    // bidder's list entry and record prefetched one bid ahead.
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    int4 rb = make_int4(0, -1, -1, 0);
-    auto load_rec = [&](int u) {
-      if (u < kRecCap) {
-        ra = s_rq[cur][u];
-        rb = s_ri[cur][u];
-      } else if (u < U) {
-        const int jj = L[u];
-        ra = ld_person(jj, 0);
-        const float4 g = ld_person(jj, 1);
-        rb = make_int4(jj, __float_as_int(g.y), __float_as_int(g.z), 0);
-      }
-    };
-    load_rec(wave);
-    for (int u = wave; u < U; u += kEmdWaves) {
+    // Only rounds with at most kRowModeMin (< kRecCap) bidders come here, so
+    // every bidder's record is in the LDS cache.  Bids differ in length (4k to
+    // 16k cycles), so a wave that finishes draws the next list position from a
+    // shared counter instead of owning every 16th one: the phase lasts
+    // sum / 16 instead of the longest pair.  (The loop is bounded independently
+    // of the drawn position.)
+    static_assert(kRowModeMin < kRecCap, "wave-mode bidders must have their records in LDS");
+    int u = wave;
+    for (int guard = 0; guard <= kRowModeMin && u < U; ++guard) {
+      const float4 ra = s_rq[cur][u];
+      const int4 rb = s_ri[cur][u];
+      int drawn = 0;
       const int j = rb.x;
       const float qx = ra.x, qy = ra.y, qz = ra.z;
       const int p1 = rb.y, p2 = rb.z;
-      load_rec(u + kEmdWaves);  // prefetch (consumed next iteration)
 #ifdef MVP_EMD_PROFILE
       const long long tb0 = __builtin_readcyclecounter();
       int prof_cells = 0;
@@ -1063,7 +1058,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         pend_old = atomicMax(reinterpret_cast<u64 *>(&sc.ostate[st.bk]),
                              ((u64)emd_f2ord(inc) << 32) | (u64)((unsigned)j + 1u));
         pend_inc = inc;
+        drawn = atomicAdd(&s_next, 1);
       }
+      u = __builtin_amdgcn_readlane(drawn, 0);
     }
     }
     alarm |= emd_band_alarm(pend_old, pend_inc);
@@ -1129,7 +1126,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         __syncthreads();
       }
     }
-    if (t == 0) s_alarm[(it + 1) & 1] = 0;  // next round's flag; its writers are a barrier away
+    if (t == 0) {
+      s_alarm[(it + 1) & 1] = 0;  // next round's flag; its writers are a barrier away
+      s_next = kEmdWaves;         // list positions 0..15 belong to the waves, the rest are drawn
+    }
 #ifdef MVP_EMD_PROFILE
     const long long tp2 = __builtin_readcyclecounter();
 #endif
