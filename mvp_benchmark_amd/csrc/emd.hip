@@ -400,6 +400,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ int s_alarm[2];  // by round parity: set in Bid, read after the barrier, cleared a round later
   __shared__ unsigned s_gout[2 * kMaxCluster];
 #ifdef MVP_EMD_PROFILE
+  __shared__ int s_wbusy[kEmdWaves];
+  __shared__ unsigned long long s_hist2[4];
+  if (threadIdx.x < 4) s_hist2[threadIdx.x] = 0;
   __shared__ unsigned long long s_hist[16];  // wave-mode bids: [0..7] duration buckets, [8] sum nsub, [9] sum cells visited, [10] count, [11] linear scans, [12] sum cycles
   if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
 #endif
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   // alone (same code, workgroup barriers), the others leave.
   bool clustered = W > 1;
 #ifdef MVP_EMD_PROFILE
-  long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0;
+  long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0;
 #endif
   for (int it = 0; it < iters; ++it) {
     if (Utot == 0) break;
@@ -902,6 +905,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         const float seed_b2 = wave_second_largest(a1, a2);
         st.tm = (3.0f - seed_b2) + kMargin;
       }
+#ifdef MVP_EMD_PROFILE
+      const long long tb1 = __builtin_readcyclecounter();
+      long long t_visit = 0;
+      int n_visit = 0;
+#endif
 
       // (2) Only cells that intersect the cube |o - q|_inf <= tm can hold a
       // relevant object (prices are >= 0).  Enumerate that sub-box of the
@@ -941,6 +949,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       // in flight at once and a typical bid (~10 surviving cells) needs ONE
       // dependent memory round trip here.
       auto visit = [&]() {
+#ifdef MVP_EMD_PROFILE
+        const long long tv0 = __builtin_readcyclecounter();
+        n_visit += (nlist + 15) / 16;
+#endif
         for (int k0 = 0; k0 < nlist; k0 += 16) {
           int s[4], s1[4];
 #pragma unroll
@@ -979,6 +991,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           }
         }
         nlist = 0;
+#ifdef MVP_EMD_PROFILE
+        t_visit += __builtin_readcyclecounter() - tv0;
+#endif
       };
       // When the search cube covers most of the grid (high prices everywhere,
       // e.g. a clustered prediction against a spread target) the cell
@@ -1038,6 +1053,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         atomicAdd(&s_hist[10], 1ull);
         if (linear) atomicAdd(&s_hist[11], 1ull);
         atomicAdd(&s_hist[12], (unsigned long long)d);
+        atomicAdd(&s_hist2[0], (unsigned long long)(tb1 - tb0));
+        atomicAdd(&s_hist2[1], (unsigned long long)t_visit);
+        atomicAdd(&s_hist2[2], (unsigned long long)n_visit);
       }
 #endif
       if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
@@ -1077,6 +1095,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     if (t == 0) s_cnt[cur ^ 1] = 0;
 #ifdef MVP_EMD_PROFILE
     const long long tp1 = __builtin_readcyclecounter();
+    if (lane == 0) s_wbusy[wave] = (int)(tp1 - tp0);
 #endif
     // ---------------- all bids of the round are placed
     bool any_alarm;
@@ -1367,6 +1386,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
     const long long tp4 = __builtin_readcyclecounter();
     cyc_bid += tp1 - tp0; cyc_sync1 += tp2 - tp1; cyc_assign += tp3 - tp2; cyc_sync2 += tp4 - tp3;
+    if (t == 0 && it >= 100 && U <= kRowModeMin) {
+      int mx = 0, sm = 0;
+      for (int w = 0; w < kEmdWaves; ++w) { mx = max(mx, s_wbusy[w]); sm += s_wbusy[w]; }
+      s_hist[13] += mx; s_hist[14] += sm / kEmdWaves; s_hist[15] += 1; prof_u += U;
+    }
 #endif
     cur ^= 1;
   }
@@ -1380,6 +1404,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     if (s_err) stats[0] = -1;
     atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
 #ifdef MVP_EMD_PROFILE
+    if (cloud < 2)
+      printf("cloud %d wg %d per wave-mode bid: seed %llu cycles, visits %llu cycles in %.2f steps, rest (enumeration, finish) %llu\n", cloud, wg,
+             s_hist2[0] / (s_hist[10] + 1), s_hist2[1] / (s_hist[10] + 1), (double)s_hist2[2] / (double)(s_hist[10] + 1),
+             (s_hist[12] - s_hist2[0] - s_hist2[1]) / (s_hist[10] + 1));
+    if (cloud < 2)
+      printf("cloud %d wg %d tail rounds %llu: bidders/round %.1f, busiest wave %llu cycles/round, mean wave %llu\n", cloud, wg, s_hist[15],
+             (double)prof_u / (double)(s_hist[15] + 1), s_hist[13] / (s_hist[15] + 1), s_hist[14] / (s_hist[15] + 1));
     if (cloud < 2)
       printf("cloud %d wg %d wave-mode bids after round 100: %llu, mean cycles %llu, mean sub-box cells %llu, mean cells visited %llu, linear %llu | <2k %llu <4k %llu <8k %llu <16k %llu <32k %llu <64k %llu <128k %llu more %llu\n",
              cloud, wg, s_hist[10], s_hist[12] / (s_hist[10] + 1), s_hist[8] / (s_hist[10] + 1), s_hist[9] / (s_hist[10] + 1), s_hist[11],
