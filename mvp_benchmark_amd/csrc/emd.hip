@@ -79,7 +79,7 @@ constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushe
 constexpr int kMaxCluster = 8;   // workgroups per cloud (W)
 constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
 constexpr int kSoloMax = 16;     // unassigned persons below which one workgroup finishes the auction alone
-constexpr unsigned kSpinLimit = 1u << 22;  // bound of every cluster wait (a few seconds), then abort
+constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens of seconds), then abort
 
 // Filter slack.  An object is skipped only if
 //   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
@@ -548,6 +548,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     __syncthreads();
     if (!ok) {
       if (wg == 0 && t == 0) stats[0] = -2;
+      for (int j = t; j < n; j += kEmdThreads) {
+        dist[j] = __builtin_nanf("");
+        ass[j] = -1;
+      }
       return;
     }
   } else {
@@ -1396,7 +1400,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   }
 
   if (aborted) {
+    // A cluster wait ran into its bound (the members were not co-resident for
+    // tens of seconds).  Fail loudly: NaN distances, -1 assignments.
     if (t == 0) stats[0] = -2;
+    for (int j = t; j < n; j += kEmdThreads) {
+      dist[j] = __builtin_nanf("");
+      ass[j] = -1;
+    }
     return;
   }
   if (t == 0) {
