@@ -100,7 +100,8 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * dist (b,n) squared matched distance, assignment (b,n) index into xyz2
  * (may be non-injective after the forced last round).
  * Guards as emd_cuda.cu:236-249: n %% 1024 == 0, b <= 512 (-> MVP_EBADSHAPE);
- * iters >= 1.  Deterministic: GetMax's racy last-writer (emd_cuda.cu:188-191)
+ * iters >= 1; eps > 0 (-> MVP_EBADARG: the auction needs strictly positive bid
+ * increments, and the search prunes on prices that never fall).  Deterministic: GetMax's racy last-writer (emd_cuda.cu:188-191)
  * is pinned to the highest qualifying bidder index.
  * One persistent (cooperative) launch; up to 8 workgroups share a cloud when
  * b leaves CUs free (b*W <= CU count; MVP_EMD_CLUSTER=1|2|4|8 caps W).  The

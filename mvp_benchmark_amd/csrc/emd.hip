@@ -1509,6 +1509,8 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
                                long long scratch_bytes, void *stream) {
   if (b < 0 || n <= 0 || iters < 1) return MVP_EBADSHAPE;
   if (b > 512 || n % 1024 != 0) return MVP_EBADSHAPE;  // emd_cuda.cu:236-249
+  // the pruning bounds rely on prices that never fall, i.e. on positive bid increments
+  if (!(eps > 0.f)) return MVP_EBADARG;
   if (n > (1 << 20)) return MVP_EBADSHAPE;
   if (b == 0) return MVP_OK;
   if (!xyz1 || !xyz2 || !dist || !assignment || !scratch) return MVP_EBADARG;

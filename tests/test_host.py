@@ -36,6 +36,7 @@ def test_argument_guards_need_no_gpu():
     assert lib.mvp_emd_forward(1, 1000, null, null, null, null, 0.005, 50, null, 0, null) == -1
     assert lib.mvp_emd_forward(513, 1024, null, null, null, null, 0.005, 50, null, 0, null) == -1
     assert lib.mvp_emd_forward(1, 1024, null, null, null, null, 0.005, 0, null, 0, null) == -1
+    assert lib.mvp_emd_forward(1, 1024, null, null, null, null, 0.0, 50, null, 0, null) == -2     # eps must be > 0
     # null buffers -> MVP_EBADARG
     assert lib.mvp_emd_forward(1, 1024, null, null, null, null, 0.005, 50, null, 0, null) == -2
     assert lib.mvp_chamfer_forward(1, 8, 8, null, null, null, null, null, null, null) == -2
