@@ -159,6 +159,15 @@ int mvp_ball_query(int b, int n, int m, float min_radius, float max_radius,
 int mvp_knn(int b, int n, int m, int nsample, const float *xyz,
             const float *new_xyz, int *idx, float *dist2, void *stream);
 
+/* Feature-space neighbour search of the models (no native counterpart in the
+ * reference: completion/model_utils.py:242-247 builds `-xx - inner - xx^T` on a
+ * materialised (B,N,N) matrix and calls torch.topk).  dot (b,n,n) = x^T x from a
+ * library GEMM, sq (b,n) = |x_i|^2 -> idx (b,n,k): per row i the k largest of
+ * fl(fl(-sq[j] + 2 dot[i][j]) - sq[i]), sorted descending (self first); equal
+ * to torch.topk's indices wherever the values are distinct.  k <= 100, k <= n. */
+int mvp_topk_gram(int b, int n, int k, const float *dot, const float *sq,
+                  int *idx, void *stream);
+
 /* Replaces interpolate_ext.three_nn_wrapper
  * (utils/mm3d_pn2/ops/interpolate/src/interpolate.cpp:46-56,88) ->
  * three_nn_kernel_launcher (src/three_nn_cuda.cu:67-89).

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mvp_furthest_point_sampling_with_dist": "iiippp",
     "mvp_ball_query": "iiiffippp",
     "mvp_knn": "iiiipppp",
+    "mvp_topk_gram": "iiippp",
     "mvp_three_nn": "iiipppp",
     "mvp_three_interpolate": "iiiipppp",
     "mvp_three_interpolate_grad": "iiiipppp",

@@ -235,6 +235,89 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(
   }
 }
 
+// Feature-space neighbours of the models: the k largest of
+//   val[i][j] = fl(fl(-sq[j] - (-2 * dot[i][j])) - sq[i])
+// per row i of a (N x N) Gram matrix `dot` = x^T x that the caller computed
+// with a library GEMM -- exactly the expression model_utils.knn builds
+// (completion/model_utils.py:242-247: `-xx - inner - xx.transpose(2, 1)`), so
+// the selected indices equal torch.topk's wherever the values are distinct.
+// Replaces three elementwise passes over the (B,N,N) matrix plus a radix
+// top-k by one pass: a block owns 128 rows, tiles of 128 x 32 values are
+// loaded with coalesced row reads and handed to the row's lane through LDS
+// (row stride 33: conflict-free), and each lane runs the knn kernel's
+// screened heap on key = -val.
+constexpr int kFkRows = 128;
+constexpr int kFkCols = 32;
+
+__global__ __launch_bounds__(kFkRows) void topk_gram_kernel(
+    int n, int k, const float *__restrict__ dot, const float *__restrict__ sq,
+    int *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *tile = reinterpret_cast<float *>(smem);                 // kFkRows * (kFkCols + 1)
+  float *sqc = tile + kFkRows * (kFkCols + 1);                    // kFkCols
+  float *hd = sqc + kFkCols;                                      // k * kFkRows
+  int *hi = reinterpret_cast<int *>(hd + (size_t)k * kFkRows);   // k * kFkRows
+  const int t = threadIdx.x;
+  const int cloud = blockIdx.y;
+  const int row0 = blockIdx.x * kFkRows;
+  const int row = row0 + t;
+  const bool active = row < n;
+  dot += (size_t)cloud * n * n;
+  sq += (size_t)cloud * n;
+  const float sqi = active ? sq[row] : 0.f;
+  for (int i = 0; i < k; ++i) {
+    hd[i * kFkRows + t] = __builtin_inff();
+    hi[i * kFkRows + t] = 0;
+  }
+  float rootd = __builtin_inff();
+  for (int c0 = 0; c0 < n; c0 += kFkCols) {
+    __syncthreads();
+    // 128 x 32 tile: thread (r = e / 32, c = e % 32) -> 32 consecutive floats per row
+    for (int e = t; e < kFkRows * kFkCols; e += kFkRows) {
+      const int r = e / kFkCols, c = e % kFkCols;
+      const bool ok = row0 + r < n && c0 + c < n;
+      tile[r * (kFkCols + 1) + c] = ok ? dot[(size_t)(row0 + r) * n + c0 + c] : 0.f;
+    }
+    if (t < kFkCols) sqc[t] = c0 + t < n ? sq[c0 + t] : __builtin_inff();   // key = +inf: never admitted
+    __syncthreads();
+    unsigned mask = 0u;
+#pragma unroll
+    for (int c = 0; c < kFkCols; ++c) {
+      const float inner = -2.f * tile[t * (kFkCols + 1) + c];
+      const float key = -((-sqc[c] - inner) - sqi);
+      mask |= (key < rootd ? 1u : 0u) << c;
+    }
+    while (__any(mask != 0u)) {
+      if (mask != 0u) {
+        const int c = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        const float inner = -2.f * tile[t * (kFkCols + 1) + c];
+        const float key = -((-sqc[c] - inner) - sqi);
+        if (key < rootd) {
+          hd[t] = key;
+          hi[t] = c0 + c;
+          knn_reheap<kFkRows>(hd, hi, t, k);
+          rootd = hd[t];
+        }
+      }
+    }
+  }
+  for (int i = k - 1; i > 0; i--) {  // heap sort: ascending key = descending value
+    const float tf = hd[t];
+    hd[t] = hd[i * kFkRows + t];
+    hd[i * kFkRows + t] = tf;
+    const int ti = hi[t];
+    hi[t] = hi[i * kFkRows + t];
+    hi[i * kFkRows + t] = ti;
+    knn_reheap<kFkRows>(hd, hi, t, i);
+  }
+  if (active) {
+    int *o = idx + ((size_t)cloud * n + row) * k;
+    for (int i = 0; i < k; ++i) o[i] = hi[i * kFkRows + t];
+  }
+}
+
+
 }  // namespace mvp
 
 using namespace mvp;
@@ -284,6 +367,19 @@ extern "C" int mvp_knn(int b, int n, int m, int nsample, const float *xyz,
                        m, nsample, xyz, new_xyz, idx, dist2);
   }
   return check_launch("mvp_knn");
+}
+
+extern "C" int mvp_topk_gram(int b, int n, int k, const float *dot, const float *sq, int *idx,
+                             void *stream) {
+  if (b < 0 || n < 0 || k < 1 || k > 100 || k > n) return MVP_EBADSHAPE;
+  if (b == 0 || n == 0) return MVP_OK;
+  if (!dot || !sq || !idx) return MVP_EBADARG;
+  if (b > 65535) return MVP_EBADSHAPE;
+  const size_t lds = (size_t)(kFkRows * (kFkCols + 1) + kFkCols) * 4 + (size_t)k * kFkRows * 8;
+  if (lds > 64 * 1024) return MVP_EBADSHAPE;
+  dim3 grid((n + kFkRows - 1) / kFkRows, b);
+  hipLaunchKernelGGL(topk_gram_kernel, grid, dim3(kFkRows), lds, as_stream(stream), n, k, dot, sq, idx);
+  return check_launch("mvp_topk_gram");
 }
 
 extern "C" int mvp_three_nn(int b, int n, int m, const float *unknown,

@@ -217,6 +217,19 @@ class GroupingOperation(Function):
         return grad_features, None
 
 
+def gram_topk(dot, sq, k):
+    """Feature-space neighbours: dot (B,N,N) = x^T x, sq (B,N) = |x_i|^2 ->
+    idx (B,N,k) int32, per row the k largest of (-sq[j] + 2 dot[i][j]) - sq[i]
+    in descending order (self first) -- the selection model_utils.knn makes with
+    torch.topk on the materialised negative-distance matrix, in one scan.  Not
+    part of the reference's operator set (row N1 of the widening plan)."""
+    _need_contiguous(dot, sq)
+    B, N = sq.shape
+    idx = _new(dot, B, N, k, dtype=torch.int32)
+    call("mvp_topk_gram", dot.device, B, N, k, dot, sq, idx)
+    return idx
+
+
 furthest_point_sample = FurthestPointSampling.apply
 furthest_point_sample_with_dist = FurthestPointSamplingWithDist.apply
 ball_query = BallQuery.apply

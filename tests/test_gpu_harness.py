@@ -64,9 +64,21 @@ def test_coordinate_knn_goes_through_the_op(oracle):
     differ = ref_idx != pn.cpu().numpy()
     gap = np.abs(np.take_along_axis(d2, ref_idx, -1) - chosen)
     assert (gap[differ] < 2e-6).all() and differ.mean() < 1e-3
-    # feature-space searches keep the PyTorch formulation
-    feat = dev(rand_clouds(7, 2, 24, 256))
-    assert mu.knn(feat, 8).shape == (2, 256, 8)
+    # feature-space searches: library GEMM + one scan of the Gram matrix; the
+    # same indices as topk on the materialised matrix wherever values differ
+    for C, n, kk in [(24, 700, 16), (48, 1024, 16), (256, 300, 4), (5, 40, 40)]:
+        feat = dev(rand_clouds(7 + C, 2, C, n))
+        got = mu.knn(feat, kk)
+        assert got.shape == (2, n, kk) and got.dtype == torch.int64
+        sq = (feat * feat).sum(dim=1, keepdim=True)
+        neg = -sq - (-2 * torch.matmul(feat.transpose(2, 1), feat)) - sq.transpose(2, 1)
+        want_v, want_i = neg.topk(k=kk, dim=-1)
+        got_v = torch.gather(neg, 2, got)
+        assert torch.equal(got_v, want_v)                      # same values in the same (descending) order
+        distinct = torch.ones_like(want_v, dtype=torch.bool)
+        distinct[..., 1:] &= want_v[..., 1:] != want_v[..., :-1]
+        distinct[..., :-1] &= want_v[..., :-1] != want_v[..., 1:]
+        assert torch.equal(got[distinct], want_i[distinct])     # same indices where no tie is involved
 
 
 def test_edge_feature_gathers_match_advanced_indexing():
