@@ -270,7 +270,7 @@ __device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
 template <int W, bool DRAIN = true>
 __device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned epoch,
                                                    const int *p0, const int *p1,
-                                                   unsigned *s_gout, int *s_abort) {
+                                                   unsigned *s_gout, int *s_abort, bool same_xcd = false) {
   // DRAIN = false: nothing stored since the last gather has to be visible to
   // the other workgroups before the NEXT draining gather
   if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -280,8 +280,12 @@ __device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned 
     u64 *base = slots + (size_t)(epoch & 1u) * (2 * W);
     if (lane < 2) {
       const unsigned pv = (unsigned)(lane == 0 ? *p0 : *p1);
-      __hip_atomic_store(base + 2 * wg + lane, ((u64)epoch << 32) | pv, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      if (same_xcd)  // the pollers share this XCD's L2: no need to write through
+        __hip_atomic_store(base + 2 * wg + lane, ((u64)epoch << 32) | pv, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+      else
+        __hip_atomic_store(base + 2 * wg + lane, ((u64)epoch << 32) | pv, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
     u64 x = (u64)epoch << 32;
     bool done = false;
@@ -302,7 +306,7 @@ __device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned 
 template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     int b, int bpad, int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    float *__restrict__ dist, int *assignment, float eps, int iters, char *scratch) {
+    float *__restrict__ dist, int *assignment, float eps, int iters, char *scratch, int fast_ok) {
   // Block -> (cloud, member): members of a cluster are bpad (a multiple of 8)
   // blocks apart, so they share an XCD under the round-robin dispatch (faster
   // L2 sharing only; nothing below depends on placement).
@@ -353,13 +357,20 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   };
+  // Stores of shared words.  When every member of the cluster was observed on
+  // the same XCD (same_xcd, below) they share one L2, the coherence point of
+  // that XCD's CUs: a plain store (L1 is write-through) is visible to the
+  // others' L1-bypassing loads as soon as it is acknowledged, and the line
+  // stays in L2 instead of being written through to memory and dropped.
+  bool same_xcd = false;
   auto st_person_hi = [&](int j, int bid, int p1, int p2, float inc) {
     if constexpr (W == 1) {
       sc.person[2 * j + 1] = make_float4(__int_as_float(bid), __int_as_float(p1), __int_as_float(p2), inc);
     } else {
       v4u v;
       v.x = (unsigned)bid; v.y = (unsigned)p1; v.z = (unsigned)p2; v.w = __float_as_uint(inc);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rs, (2u * (unsigned)n + 2u * (unsigned)j + 1u) * 16u, 0, 16);
+      if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (2u * (unsigned)n + 2u * (unsigned)j + 1u) * 16u, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(v, rs, (2u * (unsigned)n + 2u * (unsigned)j + 1u) * 16u, 0, 16);
     }
   };
   auto st_ostate = [&](int s, int owner) {  // key = 0 (no bid), new owner
@@ -368,15 +379,18 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     } else {
       v4u v;
       v.x = 0u; v.y = 0u; v.z = (unsigned)owner; v.w = 0u;
-      __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((unsigned)n + (unsigned)s) * 16u, 0, 16);
+      if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((unsigned)n + (unsigned)s) * 16u, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((unsigned)n + (unsigned)s) * 16u, 0, 16);
     }
   };
   auto st_i32 = [&](int *p, int v) {
     if constexpr (W == 1) *p = v;
+    else if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto st_f32 = [&](float *p, float v) {
     if constexpr (W == 1) *p = v;
+    else if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto ld_key = [&](int s) -> u64 {
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ int s_wsum[kEmdWaves];
   __shared__ int s_cnt[2];
   __shared__ int s_next;             // next undrawn list position of the round (wave-mode bids)
-  __shared__ int s_err, s_abort, s_nchg;
+  __shared__ int s_err, s_abort, s_nchg, s_xcc;
   __shared__ int s_alarm[2];  // by round parity: set in Bid, read after the barrier, cleared a round later
   __shared__ unsigned s_gout[2 * kMaxCluster];
 #ifdef MVP_EMD_PROFILE
@@ -543,9 +557,19 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     __syncthreads();
     if (wg == 0 && t == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool ok = emd_cluster_gather<W>(slots, wg, ++epoch, &s_cnt[1], &s_cnt[1], s_gout, &s_abort);
+    if (t == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      s_xcc = (int)(xcc & 0xFu) + 1;
+    }
+    const bool ok = emd_cluster_gather<W>(slots, wg, ++epoch, &s_xcc, &s_xcc, s_gout, &s_abort);
     if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
+    // every member on one XCD (the launch places them so; the registers say
+    // whether it happened): the cheaper same-L2 store flavour is valid
+    same_xcd = fast_ok != 0;
+#pragma unroll
+    for (int w = 1; w < W; ++w) same_xcd &= s_gout[2 * w] == s_gout[0];
     if (!ok) {
       if (wg == 0 && t == 0) stats[0] = -2;
       for (int j = t; j < n; j += kEmdThreads) {
@@ -1106,7 +1130,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     if (clustered) {
       // The bids themselves are complete (their atomics have returned); the
       // bidders' hint records are only read after the next draining gather.
-      if (!emd_cluster_gather<W, false>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort)) {
+      if (!emd_cluster_gather<W, false>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort, same_xcd)) {
         aborted = true;
         break;
       }
@@ -1141,7 +1165,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           atomicMax(reinterpret_cast<u64 *>(&sc.ostate[o]), (key & 0xFFFFFFFF00000000ull) | (u64)((unsigned)j + 1u));
       }
       if (clustered) {
-        if (!emd_cluster_gather<W>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort)) {
+        if (!emd_cluster_gather<W>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort, same_xcd)) {
           aborted = true;
           break;
         }
@@ -1204,9 +1228,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           c_pmin[c] = pm;
           if (clustered) {
             const int q = atomicAdd(&s_nchg, 1);
-            if (q < kChgCap)
-              __hip_atomic_store(my_chg + q, ((u64)(unsigned)c << 32) | (u64)__float_as_uint(pm),
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q < kChgCap) {
+              const u64 e = ((u64)(unsigned)c << 32) | (u64)__float_as_uint(pm);
+              if (same_xcd) __hip_atomic_store(my_chg + q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              else __hip_atomic_store(my_chg + q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
       } else {
@@ -1229,7 +1255,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #endif
     // ---------------- end of round: next list sizes + refreshed price bounds
     if (clustered) {
-      if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort)) {
+      if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort, same_xcd)) {
         aborted = true;
         break;
       }
@@ -1246,7 +1272,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         // ---- hand everything to member 0 (lists of <= kSoloMax persons live
         // in LDS only: publish the person ids; their records are in memory)
         if (wg != 0 && t < cntw[wg]) st_i32(my_ulist + t, s_ri[nxt][t].x);
-        if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort)) {
+        if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
           aborted = true;
           break;
         }
@@ -1304,7 +1330,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             const int pos = my_cnt - my_exc + i;
             st_i32(dead + i, pos < kRecCap ? s_ri[nxt][pos].x : Lnext[pos]);
           }
-          if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort)) {
+          if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
             aborted = true;
             break;
           }
@@ -1484,12 +1510,15 @@ static hipError_t emd_launch(int b, int n, const float *xyz1, const float *xyz2,
   int bpad = W == 1 ? b : (b + 7) / 8 * 8;
   if (W == 1) {
     hipLaunchKernelGGL(emd_auction_kernel<1>, dim3(b), dim3(kEmdThreads), 0, stream, b, bpad, n,
-                       xyz1, xyz2, dist, assignment, eps, iters, scratch);
+                       xyz1, xyz2, dist, assignment, eps, iters, scratch, 0);
     return hipSuccess;
   }
   // cluster members wait for each other: the launch must be checked against
   // the device's residency (cooperative launch does exactly that)
-  void *args[] = {&b, &bpad, &n, &xyz1, &xyz2, &dist, &assignment, &eps, &iters, &scratch};
+  // MVP_EMD_SAME_XCD=0 keeps the write-through stores even when the members share an XCD
+  int fast_ok = 1;
+  if (const char *e = getenv("MVP_EMD_SAME_XCD")) fast_ok = atoi(e) != 0;
+  void *args[] = {&b, &bpad, &n, &xyz1, &xyz2, &dist, &assignment, &eps, &iters, &scratch, &fast_ok};
   return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_auction_kernel<W>),
                                     dim3(W * bpad), dim3(kEmdThreads), args, 0, stream);
 }
