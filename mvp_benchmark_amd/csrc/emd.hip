@@ -936,7 +936,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
       const long long tb1 = __builtin_readcyclecounter();
       long long t_visit = 0;
-      int n_visit = 0;
+      int n_visit = 0, prof_fold = 0;
 #endif
 
       // (2) Only cells that intersect the cube |o - q|_inf <= tm can hold a
@@ -1006,6 +1006,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               const float tq = st.tm - o[r].w;
               const bool ps = s[r] < s1[r] && tq >= 0.f && sd <= tq * tq;
               const unsigned long long m = __ballot(ps);
+#ifdef MVP_EMD_PROFILE
+              prof_fold += __builtin_popcountll(m);
+#endif
               if (m) emd_fold(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm);
             }
             // cells with more than 16 members (rare): next 16
@@ -1084,6 +1087,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         atomicAdd(&s_hist2[0], (unsigned long long)(tb1 - tb0));
         atomicAdd(&s_hist2[1], (unsigned long long)t_visit);
         atomicAdd(&s_hist2[2], (unsigned long long)n_visit);
+        atomicAdd(&s_hist2[3], (unsigned long long)prof_fold);
       }
 #endif
       if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
@@ -1441,8 +1445,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
 #ifdef MVP_EMD_PROFILE
     if (cloud < 2)
-      printf("cloud %d wg %d per wave-mode bid: seed %llu cycles, visits %llu cycles in %.2f steps, rest (enumeration, finish) %llu\n", cloud, wg,
-             s_hist2[0] / (s_hist[10] + 1), s_hist2[1] / (s_hist[10] + 1), (double)s_hist2[2] / (double)(s_hist[10] + 1),
+      printf("cloud %d wg %d per wave-mode bid: seed %llu cycles, visits %llu cycles in %.2f steps folding %.1f candidates, rest (enumeration, finish) %llu\n", cloud, wg,
+             s_hist2[0] / (s_hist[10] + 1), s_hist2[1] / (s_hist[10] + 1), (double)s_hist2[2] / (double)(s_hist[10] + 1), (double)s_hist2[3] / (double)(s_hist[10] + 1),
              (s_hist[12] - s_hist2[0] - s_hist2[1]) / (s_hist[10] + 1));
     if (cloud < 2)
       printf("cloud %d wg %d tail rounds %llu: bidders/round %.1f, busiest wave %llu cycles/round, mean wave %llu\n", cloud, wg, s_hist[15],
