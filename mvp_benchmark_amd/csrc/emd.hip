@@ -15,7 +15,9 @@
 //     bid keys) is shared through write-through (sc1) stores and L1-bypassing
 //     (sc1) loads, and the round structure is kept by two all-gathers of
 //     8-byte tagged granules per round (the data is the flag; no fences in
-//     the loop).  W = 1 uses plain accesses and workgroup barriers only;
+//     the loop).  When the members find themselves on one XCD (the launch
+//     places them so, HW_REG_XCC_ID tells) they share its L2 and the stores
+//     stay plain.  W = 1 uses plain accesses and workgroup barriers only;
 //   * rounds stop as soon as nobody is unassigned (exact: such rounds are
 //     no-ops in the reference, emd_cuda.cu:105-106,185,199);
 //   * the unassigned lists are maintained incrementally (losers stay, an
