@@ -402,9 +402,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   };
 
   // Per-cell metadata (SoA, conflict-free lane-per-cell reads).
-  __shared__ float c_minx[kMaxCells], c_miny[kMaxCells], c_minz[kMaxCells];
-  __shared__ float c_maxx[kMaxCells], c_maxy[kMaxCells], c_maxz[kMaxCells];
-  __shared__ float c_pmin[kMaxCells];
+  // per cell: {box min x, y, z, price lower bound} and {box max x, y, z, -}:
+  // a cell test is two ds_read_b128 per lane
+  __shared__ float4 c_lo[kMaxCells], c_hi[kMaxCells];
   __shared__ int c_start[kMaxCells + 1];
   __shared__ int s_tmp[kMaxCells];  // counts / fill cursors during the build
   __shared__ unsigned short w_list[kEmdWaves][4 * kRowListCap];  // surviving cells, per 16-lane row
@@ -596,9 +596,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       by1 = __builtin_fmaxf(by1, o.y);
       bz1 = __builtin_fmaxf(bz1, o.z);
     }
-    c_minx[c] = bx0; c_miny[c] = by0; c_minz[c] = bz0;
-    c_maxx[c] = bx1; c_maxy[c] = by1; c_maxz[c] = bz1;
-    c_pmin[c] = 0.f;
+    c_lo[c] = make_float4(bx0, by0, bz0, 0.f);
+    c_hi[c] = make_float4(bx1, by1, bz1, 0.f);
   }
   __syncthreads();
 
@@ -815,10 +814,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             const int ky = (int)(((float)rem + 0.5f) * inv_nx);
             const int kx = rem - ky * nx;
             c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
-            const float dx = __builtin_fmaxf(__builtin_fmaxf(c_minx[c] - qx, qx - c_maxx[c]), 0.f);
-            const float dy = __builtin_fmaxf(__builtin_fmaxf(c_miny[c] - qy, qy - c_maxy[c]), 0.f);
-            const float dz = __builtin_fmaxf(__builtin_fmaxf(c_minz[c] - qz, qz - c_maxz[c]), 0.f);
-            const float tq = tm - c_pmin[c];
+            const float4 cl = c_lo[c], ch = c_hi[c];
+            const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
+            const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
+            const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
+            const float tq = tm - cl.w;
             cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
           }
           const unsigned rmask = (unsigned)((__ballot(cpass) >> rsh) & 0xFFFFull);
@@ -1059,10 +1059,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const int ky = (int)(((float)rem + 0.5f) * inv_nx);
           const int kx = rem - ky * nx;
           c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
-          const float dx = __builtin_fmaxf(__builtin_fmaxf(c_minx[c] - qx, qx - c_maxx[c]), 0.f);
-          const float dy = __builtin_fmaxf(__builtin_fmaxf(c_miny[c] - qy, qy - c_maxy[c]), 0.f);
-          const float dz = __builtin_fmaxf(__builtin_fmaxf(c_minz[c] - qz, qz - c_maxz[c]), 0.f);
-          const float tq = st.tm - c_pmin[c];
+          const float4 cl = c_lo[c], ch = c_hi[c];
+          const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
+          const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
+          const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
+          const float tq = st.tm - cl.w;
           cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
         }
         const unsigned long long cmask = __ballot(cpass);
@@ -1120,7 +1121,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       if (chg_have) {
         const int pmb = (int)(unsigned)chg_pend;
         if (pmb >= 0)  // bits of a non-negative float order like ints
-          atomicMax(reinterpret_cast<int *>(&c_pmin[(int)(chg_pend >> 32)]), pmb);
+          atomicMax(reinterpret_cast<int *>(&c_lo[(int)(chg_pend >> 32)].w), pmb);
         chg_have = false;
       }
     }
@@ -1225,13 +1226,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         // are old or new -- either way a valid bound) and the new bound is
         // broadcast to the other workgroups of the cluster.
         const int c = emd_cell(gg, oo.x, oo.y, oo.z);
-        if (oo.w <= c_pmin[c]) {
+        if (oo.w <= c_lo[c].w) {
           float pm = oo.w + bi;
           const int e1 = c_start[c + 1];
 #pragma unroll 8
           for (int s = c_start[c]; s < e1; ++s)
             pm = __builtin_fminf(pm, s == o ? pm : ld_obj(s).w);
-          c_pmin[c] = pm;
+          c_lo[c].w = pm;
           if (clustered) {
             const int q = atomicAdd(&s_nchg, 1);
             if (q < kChgCap) {
@@ -1374,7 +1375,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         for (int c = t; c < ncell; c += kEmdThreads) {
           float pm = __builtin_inff();
           for (int s = c_start[c]; s < c_start[c + 1]; ++s) pm = __builtin_fminf(pm, ld_obj(s).w);
-          if (pm >= c_pmin[c]) c_pmin[c] = pm;
+          if (pm >= c_lo[c].w) c_lo[c].w = pm;
         }
       } else {
         // Fetch the other workgroups' refreshed bounds now, fold them in after
@@ -1407,7 +1408,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               const u64 e = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               const int pmb = (int)(unsigned)e;
               if (pmb >= 0)  // bits of a non-negative float order like ints
-                atomicMax(reinterpret_cast<int *>(&c_pmin[(int)(e >> 32)]), pmb);
+                atomicMax(reinterpret_cast<int *>(&c_lo[(int)(e >> 32)].w), pmb);
             }
           }
           chg_have = false;
