@@ -615,7 +615,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   // alone (same code, workgroup barriers), the others leave.
   bool clustered = W > 1;
 #ifdef MVP_EMD_PROFILE
-  long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0;
+  long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0, prof_a1 = 0, prof_an = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0;
 #endif
   for (int it = 0; it < iters; ++it) {
     if (Utot == 0) break;
@@ -1191,7 +1191,14 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     // ---------------- Assign (emd_cuda.cu:196-215)
     const int nxt = cur ^ 1;
     u64 *my_chg = sc.chg + (size_t)wg * kChgCap;
-    for (int u = t; u < U; u += kEmdThreads) {
+    // Few bidders (the long tail): one or two per WAVE instead of all of them in
+    // the lanes of wave 0 -- winners, losers and bound refreshes are divergent
+    // paths with their own memory round trips, which a single wave would run
+    // one after the other.  (Many bidders: consecutive lanes, conflict-free LDS.)
+    const bool spread = U <= 4 * kEmdWaves * 4;
+    for (int ub = 0; ub < U; ub += kEmdThreads) {
+      const int u = ub + (spread ? lane * kEmdWaves + wave : t);
+      if (u >= U) continue;
       int j, o, b2k;
       float bi;
       if (u < kBidCache) {
@@ -1201,8 +1208,18 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         const float4 g = ld_person(j, 1);
         o = __float_as_int(g.x); b2k = __float_as_int(g.z); bi = g.w;
       }
+#ifdef MVP_EMD_PROFILE
+      const long long ta0 = __builtin_readcyclecounter();
+#endif
       const int4 os = ld_ostate(o);
       const float4 oo = ld_obj(o);  // independent of `os`: same round trip
+#ifdef MVP_EMD_PROFILE
+      if (t == 0 && it >= 100) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        prof_a1 += __builtin_readcyclecounter() - ta0;
+        prof_an += 1;
+      }
+#endif
       if (last || (unsigned)os.x == (unsigned)j + 1u) {  // a loser may read after the winner reset the key to 0
         const int prev = os.z;
         if (!last && prev != -1) {
@@ -1217,6 +1234,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             s_ri[nxt][pos] = make_int4(prev, __float_as_int(pb.y), __float_as_int(pb.z), 0);
           }
         }
+#ifdef MVP_EMD_PROFILE
+        if (t == 0 && it >= 100) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); prof_a2 += __builtin_readcyclecounter() - ta0; }
+#endif
         st_ostate(o, j);
         st_i32(&ass[j], o);
         st_f32(&sc.obj[o].w, oo.w + bi);
@@ -1233,6 +1253,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           for (int s = c_start[c]; s < e1; ++s)
             pm = __builtin_fminf(pm, s == o ? pm : ld_obj(s).w);
           c_lo[c].w = pm;
+#ifdef MVP_EMD_PROFILE
+          if (it >= 100) atomicAdd(&s_hist2[0], 1ull << 40);  // refresh count in the high bits
+#endif
           if (clustered) {
             const int q = atomicAdd(&s_nchg, 1);
             if (q < kChgCap) {
@@ -1256,9 +1279,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           s_ri[nxt][pos] = make_int4(j, o, b2k, 0);
         }
       }
+#ifdef MVP_EMD_PROFILE
+      if (t == 0 && it >= 100) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); prof_a3 += __builtin_readcyclecounter() - ta0; }
+#endif
     }
 #ifdef MVP_EMD_PROFILE
     const long long tp3 = __builtin_readcyclecounter();
+    if (t == 0 && it >= 100) prof_a4 += tp3 - tp2;
 #endif
     // ---------------- end of round: next list sizes + refreshed price bounds
     if (clustered) {
@@ -1432,6 +1459,16 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     cur ^= 1;
   }
 
+#ifdef MVP_EMD_PROFILE
+  if (clustered && !aborted) {  // cost of the bare all-gather
+    const long long tg0 = __builtin_readcyclecounter();
+    for (int g = 0; g < 256; ++g)
+      if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) break;
+    if (t == 0 && cloud < 2 && wg == 0)
+      printf("cloud %d: bare cluster all-gather %lld cycles each (W = %d, same_xcd %d)\n", cloud,
+             (__builtin_readcyclecounter() - tg0) / 256, W, (int)same_xcd);
+  }
+#endif
   if (aborted) {
     // A cluster wait ran into its bound (the members were not co-resident for
     // tens of seconds).  Fail loudly: NaN distances, -1 assignments.
@@ -1451,6 +1488,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       printf("cloud %d wg %d per wave-mode bid: seed %llu cycles, visits %llu cycles in %.2f steps folding %.1f candidates, rest (enumeration, finish) %llu\n", cloud, wg,
              s_hist2[0] / (s_hist[10] + 1), s_hist2[1] / (s_hist[10] + 1), (double)s_hist2[2] / (double)(s_hist[10] + 1), (double)s_hist2[3] / (double)(s_hist[10] + 1),
              (s_hist[12] - s_hist2[0] - s_hist2[1]) / (s_hist[10] + 1));
+    if (cloud < 2)
+      printf("cloud %d wg %d price-bound refreshes after round 100: %llu\n", cloud, wg, s_hist2[0] >> 40);
+    if (cloud < 2)
+      printf("cloud %d wg %d Assign (thread 0, %lld samples): loads done at %lld cycles, eviction handled at %lld (sum over winning rounds / all), body done at %lld, phase %lld\n", cloud, wg, prof_an, prof_a1 / (prof_an + 1), prof_a2 / (prof_an + 1), prof_a3 / (prof_an + 1), prof_a4 / (prof_an + 1));
     if (cloud < 2)
       printf("cloud %d wg %d tail rounds %llu: bidders/round %.1f, busiest wave %llu cycles/round, mean wave %llu\n", cloud, wg, s_hist[15],
              (double)prof_u / (double)(s_hist[15] + 1), s_hist[13] / (s_hist[15] + 1), s_hist[14] / (s_hist[15] + 1));
