@@ -30,6 +30,8 @@ class PCN_encoder(nn.Module):
         self.conv4 = pointwise1d(512, output_size)
 
     def forward(self, x):
+        # x (B, 3, N) -> per-point features (B, 256, N) -> global max (B, 256, 1), tiled back and
+        # concatenated (B, 512, N) -> second per-point MLP (B, output_size, N) -> global max (B, output_size)
         num_points = x.size(2)
         local = self.conv2(F.relu(self.conv1(x)))
         pooled = local.max(dim=2, keepdim=True)[0]
@@ -58,6 +60,12 @@ class PCN_decoder(nn.Module):
         self.conv3 = pointwise1d(512, 3)
 
     def forward(self, x):
+        # x: global feature (B, 1024).  Shapes below: S = scale, Nc = num_coarse, Nf = num_fine = Nc * S.
+        #   coarse      (B, 3, Nc)     three-layer MLP, reshaped
+        #   center      (B, 3, Nf)     every coarse point repeated S times (the fine points fold around it)
+        #   grid_feat   (B, 2, Nf)     the same S-point 2-D patch under every coarse point
+        #   global_feat (B, 1024, Nf)  the global feature under every fine point
+        #   fine        (B, 3, Nf)     per-point MLP on the 2 + 3 + 1024 channels, added to its centre
         batch_size = x.size(0)
         coarse = self.fc3(F.relu(self.fc2(F.relu(self.fc1(x))))).view(-1, 3, self.num_coarse)
 
@@ -72,6 +80,9 @@ class PCN_decoder(nn.Module):
 
 
 class Model(nn.Module):
+    """PCN = PCN_encoder + PCN_decoder + the loss / metric tail shared by the three networks
+    (models/_common.py).  `args` needs num_points (fine size), loss ('cd' | 'emd') and eval_emd."""
+
     def __init__(self, args, num_coarse=1024):
         super().__init__()
         self.num_coarse = num_coarse

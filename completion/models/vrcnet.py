@@ -158,6 +158,15 @@ class MSAP_SKN_decoder(nn.Module):
 
 
 class Model(nn.Module):
+    """Variational completion network.  Training runs two paths through ONE doubled batch: the
+    reconstruction path (posterior q(z | partial) against the prior p(z | complete)) and the completion
+    path; both decode `feat_partial + generator(z)`.  Outputs of forward():
+      train: (fine (2B, num_points, 3), per-cloud CD of fine (2B,), scalar loss =
+              10 CD(coarse_raw) + 0.5 CD(coarse_high) + CD(coarse) + alpha CD(fine) + 20 (KLD or MMD terms))
+      val:   metric dictionary of models/_common.eval_outputs;   test: {'result': fine}
+    `args`: layers, knn_list, pk, local_folding, points_label, num_coarse_raw, num_fps, num_coarse,
+    num_points, distribution_loss ('KLD' | 'MMD'), loss ('cd'), eval_emd."""
+
     def __init__(self, args, size_z=128, global_feature_size=1024):
         super().__init__()
         layers = [int(i) for i in str(args.layers).split(',')]
