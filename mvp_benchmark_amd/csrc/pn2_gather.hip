@@ -107,6 +107,51 @@ __global__ __launch_bounds__(kGThreads) void three_interpolate_grad_kernel(
   }
 }
 
+constexpr int kScThreads = 1024;
+constexpr int kScFloats = 24576;  // 96 KiB of LDS rows / accumulators per workgroup
+
+// Gather through LDS.  The direct kernel reads 4 scattered bytes per output
+// element, i.e. a whole cache sector: with the points of one (cloud, channel)
+// row spread over N*4 bytes every block pulls most of that row through L1/L2
+// again.  Here a workgroup stages `ch` complete rows of one cloud in LDS with
+// coalesced loads (the feature tensor is read exactly once), then produces all
+// M outputs of those rows from LDS (random ds_read_b32) with coalesced stores;
+// an index is read once per strip.  WEIGHTED: three_interpolate (3 indices and
+// weights per output, the oracle's fma chain).
+template <bool WEIGHTED>
+__global__ __launch_bounds__(kScThreads) void gather_lds_kernel(
+    int c, int n_src, int m_out, int ch, const float *__restrict__ points,
+    const int *__restrict__ idx, const float *__restrict__ weight, float *__restrict__ out) {
+  __shared__ float rows[kScFloats];
+  const int t = threadIdx.x;
+  const int cloud = blockIdx.y;
+  const int c0 = blockIdx.x * ch;
+  const int cn = min(ch, c - c0);
+  const float *src = points + ((size_t)cloud * c + c0) * n_src;  // rows c0.. are contiguous
+  for (int i = t; i < cn * n_src; i += kScThreads) rows[i] = src[i];
+  __syncthreads();
+  float *dst = out + ((size_t)cloud * c + c0) * m_out;
+  if constexpr (!WEIGHTED) {
+    const int *id = idx + (size_t)cloud * m_out;
+    for (int p = t; p < m_out; p += kScThreads) {
+      const int j = id[p];
+      for (int k = 0; k < cn; ++k) dst[(size_t)k * m_out + p] = rows[k * n_src + j];
+    }
+  } else {
+    const int *id = idx + (size_t)cloud * m_out * 3;
+    const float *w = weight + (size_t)cloud * m_out * 3;
+    for (int p = t; p < m_out; p += kScThreads) {
+      const int i0 = id[p * 3 + 0], i1 = id[p * 3 + 1], i2 = id[p * 3 + 2];
+      const float w0 = w[p * 3 + 0], w1 = w[p * 3 + 1], w2 = w[p * 3 + 2];
+      for (int k = 0; k < cn; ++k) {
+        const float *row = rows + k * n_src;
+        // w0*p0 + w1*p1 + w2*p2 == fma(w2,p2, fma(w1,p1, w0*p0)) (oracle chain)
+        dst[(size_t)k * m_out + p] = __builtin_fmaf(w2, row[i2], __builtin_fmaf(w1, row[i1], w0 * row[i0]));
+      }
+    }
+  }
+}
+
 // Scatter-add gradients without global atomics.  One workgroup owns `ch`
 // channels of one cloud: it accumulates grad_points[b, c0..c0+ch, :] in LDS
 // (ds_add_f32) while streaming grad_out rows with coalesced reads -- an index
@@ -116,9 +161,6 @@ __global__ __launch_bounds__(kGThreads) void three_interpolate_grad_kernel(
 // into every source point from spatially close (= temporally close) lanes;
 // as global float atomics those collide in L2 (3.5 ms per call at the VRCNet
 // shapes), in LDS the whole call is one pass over grad_out.
-constexpr int kScThreads = 1024;
-constexpr int kScFloats = 24576;  // 96 KiB of accumulators per workgroup
-
 template <bool WEIGHTED>
 __global__ __launch_bounds__(kScThreads) void scatter_lds_kernel(
     int c, int n_dst, int m_src, int ch, const float *__restrict__ grad_out,
@@ -189,6 +231,14 @@ extern "C" int mvp_gather_points(int b, int c, int n, int npoints,
   if (b == 0 || c == 0 || npoints == 0) return MVP_OK;
   if (n == 0) return MVP_EBADSHAPE;
   if (!points || !idx || !out) return MVP_EBADARG;
+  // rows short enough to stage and enough outputs per row to pay for staging
+  if (const int ch = scatter_channels(c, n); ch > 0 && 2LL * npoints >= n) {
+    dim3 sgrid((c + ch - 1) / ch, b);
+    if (!grid_ok(sgrid.x, sgrid.y, 1)) return MVP_EBADSHAPE;
+    hipLaunchKernelGGL(gather_lds_kernel<false>, sgrid, dim3(kScThreads), 0, as_stream(stream), c, n, npoints,
+                       ch, points, idx, static_cast<const float *>(nullptr), out);
+    return check_launch("mvp_gather_points");
+  }
   dim3 grid((npoints + kGThreads - 1) / kGThreads, (c + kChan - 1) / kChan, b);
   if (!grid_ok(grid.x, grid.y, grid.z)) return MVP_EBADSHAPE;
   hipLaunchKernelGGL(gather_kernel, grid, dim3(kGThreads), 0, as_stream(stream),
@@ -246,6 +296,13 @@ extern "C" int mvp_three_interpolate(int b, int c, int m, int n,
   if (b == 0 || c == 0 || n == 0) return MVP_OK;
   if (m == 0) return MVP_EBADSHAPE;
   if (!points || !idx || !weight || !out) return MVP_EBADARG;
+  if (const int ch = scatter_channels(c, m); ch > 0 && 2LL * n >= m) {
+    dim3 sgrid((c + ch - 1) / ch, b);
+    if (!grid_ok(sgrid.x, sgrid.y, 1)) return MVP_EBADSHAPE;
+    hipLaunchKernelGGL(gather_lds_kernel<true>, sgrid, dim3(kScThreads), 0, as_stream(stream), c, m, n, ch,
+                       points, idx, weight, out);
+    return check_launch("mvp_three_interpolate");
+  }
   dim3 grid((n + kGThreads - 1) / kGThreads, (c + kChan - 1) / kChan, b);
   if (!grid_ok(grid.x, grid.y, grid.z)) return MVP_EBADSHAPE;
   hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(kGThreads), 0,
