@@ -51,3 +51,11 @@ if which in ("all", "pn2"):
         x = R(64, n, 3); ctr = x[:, :m].contiguous()
         ms = timeit(lambda: ball_query(0.0, r, s, x, ctr))
         print("ball_query (64,%d) M=%d S=%d: %.3f ms" % (n, m, s, ms), flush=True)
+if which in ("all", "grad"):
+    for (b, c, n, m) in [(64, 64, 3072, 49152), (64, 128, 1536, 24576), (64, 256, 768, 12288), (64, 512, 384, 6144)]:
+        f = R(b, c, n).requires_grad_()
+        idx = torch.randint(0, n, (b, m), generator=g).int().to(dev)
+        out = gather_points(f, idx)
+        go = torch.rand_like(out)
+        ms = timeit(lambda: torch.autograd.grad(out, f, go, retain_graph=True))
+        print("gather grad (%d,%d,%d)<-%d: %.3f ms  %.1f GB/s of grad_out read" % (b, c, n, m, ms, 4.0 * b * c * m / ms / 1e6), flush=True)
