@@ -132,6 +132,17 @@ int mvp_emd_backward(int b, int n, const float *xyz1, const float *xyz2,
 int mvp_furthest_point_sampling(int b, int n, int m, const float *points,
                                 float *temp, int *idx, void *stream);
 
+/* Same contract and index-identical results as mvp_furthest_point_sampling for
+ * 4096 < n <= 16384 (elsewhere it simply forwards to it): the cloud is first
+ * Morton-sorted into the caller's scratch (mvp_fps_scratch_bytes(b,n) bytes,
+ * 16-byte aligned, contents irrelevant) so that a lane owns a compact run of
+ * points and whole waves skip the distance update when the new sample cannot
+ * lower any of their running minima. */
+long long mvp_fps_scratch_bytes(int b, int n);
+int mvp_furthest_point_sampling_sorted(int b, int n, int m, const float *points,
+                                       float *temp, int *idx, void *scratch,
+                                       long long scratch_bytes, void *stream);
+
 /* Replaces furthest_point_sampling_with_dist_wrapper
  * (furthest_point_sample.cpp:45-58,63) -> ..._with_dist_kernel_launcher
  * (furthest_point_sample_cuda.cu:333-400).  points_dist (b,n,n). */

@@ -25,6 +25,7 @@ SIGNATURES = {
     "mvp_emd_forward": "iippppfipq",
     "mvp_emd_backward": "iippppp",
     "mvp_furthest_point_sampling": "iiippp",
+    "mvp_furthest_point_sampling_sorted": "iiippppq",
     "mvp_furthest_point_sampling_with_dist": "iiippp",
     "mvp_ball_query": "iiiffippp",
     "mvp_knn": "iiiipppp",
@@ -63,6 +64,8 @@ def load():
     lib.mvp_last_hip_error.restype = ctypes.c_char_p
     lib.mvp_emd_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_emd_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.mvp_fps_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_fps_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_chamfer_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_chamfer_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     for name, sig in SIGNATURES.items():
@@ -113,11 +116,15 @@ def emd_scratch_bytes(b, n):
     return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
 
 
+def fps_scratch_bytes(b, n):
+    return int(load().mvp_fps_scratch_bytes(int(b), int(n)))
+
+
 def chamfer_scratch_bytes(b, n, m):
     return int(load().mvp_chamfer_scratch_bytes(int(b), int(n), int(m)))
 
 
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
-    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_chamfer_scratch_bytes"] \
+    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes"] \
         + list(SIGNATURES)

@@ -16,7 +16,7 @@ Reference wrappers mirrored here (paths under utils/mm3d_pn2/ops/):
 import torch
 from torch.autograd import Function
 
-from .._lib import call
+from .._lib import call, fps_scratch_bytes
 
 
 def _need_contiguous(*tensors):
@@ -40,7 +40,14 @@ class FurthestPointSampling(Function):
         B, N = points_xyz.shape[:2]
         out = _new(points_xyz, B, num_points, dtype=torch.int32, zero=True)
         scratch = _new(points_xyz, B, N).fill_(1e10)      # running min-distances
-        call("mvp_furthest_point_sampling", points_xyz.device, B, N, num_points, points_xyz, scratch, out)
+        if 8192 < N <= 16384 and num_points > 1:
+            # the largest clouds: Morton-sorted copy + wave-level skipping of the distance update (same indices)
+            nbytes = fps_scratch_bytes(B, N)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=points_xyz.device)
+            call("mvp_furthest_point_sampling_sorted", points_xyz.device, B, N, num_points, points_xyz, scratch, out,
+                 ws, nbytes)
+        else:
+            call("mvp_furthest_point_sampling", points_xyz.device, B, N, num_points, points_xyz, scratch, out)
         ctx.mark_non_differentiable(out)
         return out
 

@@ -295,6 +295,48 @@ def test_fps_ties_on_lattice(oracle):
         np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample(x, m))
 
 
+@pytest.mark.parametrize("b,n,m", [(3, 4097, 500), (2, 6000, 1000), (2, 8192, 2048), (2, 12000, 700), (2, 16384, 2048)])
+def test_fps_sorted_variant_matches_oracle(oracle, b, n, m):
+    """The Morton-sorted kernel for 4096 < N <= 16384 (whole waves skip the
+    distance update): indices and the final running minima equal the plain
+    kernel's / the oracle's."""
+    from mvp_benchmark_amd import _lib
+    x = rand_clouds(n * 7 + m, b, n, 3)
+    tx = dev(x)
+    outs = []
+    for name in ("mvp_furthest_point_sampling", "mvp_furthest_point_sampling_sorted"):
+        temp = torch.full((b, n), 1e10, device=DEV)
+        idx = torch.zeros(b, m, dtype=torch.int32, device=DEV)
+        if name.endswith("sorted"):
+            nbytes = _lib.fps_scratch_bytes(b, n)
+            ws = torch.full((nbytes,), 0xCD, dtype=torch.uint8, device=DEV)
+            _lib.call(name, tx.device, b, n, m, tx, temp, idx, ws, nbytes)
+        else:
+            _lib.call(name, tx.device, b, n, m, tx, temp, idx)
+        outs.append((idx, temp))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[1][0].cpu().numpy(), oracle.furthest_point_sample(x, m))
+
+
+def test_fps_sorted_variant_ties(oracle):
+    """Lattice and duplicated points in the sorted kernel's size range: most
+    rounds have several points at the maximum, so the original-index tie rule
+    (bit-reversed slot, then lowest index) decides."""
+    from mvp_benchmark_amd import _lib
+    g = np.stack(np.meshgrid(*[np.arange(18) / 32.0] * 3, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    lattice = np.ascontiguousarray(np.concatenate([g, g[:, np.random.default_rng(0).permutation(g.shape[1])]], 0))   # 5832 points
+    dup = np.tile(rand_clouds(3, 2, 1500, 3), (1, 4, 1))                                                              # 6000 points
+    for x, m in [(lattice, 900), (dup, 1600)]:
+        b, n = x.shape[:2]
+        tx = dev(x)
+        temp = torch.full((b, n), 1e10, device=DEV)
+        idx = torch.zeros(b, m, dtype=torch.int32, device=DEV)
+        nbytes = _lib.fps_scratch_bytes(b, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        _lib.call("mvp_furthest_point_sampling_sorted", tx.device, b, n, m, tx, temp, idx, ws, nbytes)
+        np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample(x, m))
+
+
 def test_fps_with_dist_matches_oracle(oracle):
     from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample_with_dist
     for n, m in [(50, 20), (300, 100), (1500, 64)]:
