@@ -44,34 +44,47 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
-// One DPP data-movement step on a 32-bit value (rows = 16 lanes).
+// Unsigned 32-bit max with one DPP-modified operand: a single v_max_u32 per
+// step (lanes a row mask leaves unwritten combine with 0, the identity).
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
-  const unsigned lo = dpp_u32<CTRL, ROW_MASK>((unsigned)v);
-  const unsigned hi = dpp_u32<CTRL, ROW_MASK>((unsigned)(v >> 32));
-  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+__device__ __forceinline__ unsigned dpp_umax32(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
   return o > v ? o : v;
 }
+__device__ __forceinline__ unsigned wave_umax32(unsigned v) {
+  v = dpp_umax32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_umax32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_umax32<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_umax32<0x140, 0xF>(v);  // row_mirror
+  v = dpp_umax32<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
+  v = dpp_umax32<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned row16_umax32(unsigned v) {  // butterfly: every lane of the row gets the max
+  v = dpp_umax32<0xB1, 0xF>(v);
+  v = dpp_umax32<0x4E, 0xF>(v);
+  v = dpp_umax32<0x141, 0xF>(v);
+  v = dpp_umax32<0x140, 0xF>(v);
+  return v;
+}
 
-// Wave64 max of a u64 using DPP moves only (no LDS crossbar): butterfly inside
-// each 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror), then
-// row_bcast15 / row_bcast31 so that lane 63 holds the maximum of all lanes;
-// the result is broadcast from lane 63.
+// Wave64 max of a u64 key {value bits, tie word}, returned wave-uniform.  A
+// 64-bit compare-and-select costs five dependent instructions per DPP step;
+// the lexicographic max is instead taken as two 32-bit reductions -- the value,
+// then the tie word among the lanes that hold that value (0 elsewhere).
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  v = dpp_max_step<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v = dpp_max_step<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v = dpp_max_step<0x141, 0xF>(v);  // row_half_mirror
-  v = dpp_max_step<0x140, 0xF>(v);  // row_mirror
-  v = dpp_max_step<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
-  v = dpp_max_step<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-  return ((unsigned long long)hi << 32) | lo;
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = wave_umax32(hi);
+  const unsigned ml = wave_umax32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
+}
+// The same over the 16 lanes of row 0 (valid in every lane of that row; taken
+// from lane 0).
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_umax32(hi));
+  const unsigned ml = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_umax32(hi == mh ? lo : 0u));
+  return ((unsigned long long)mh << 32) | ml;
 }
 
 // P > 0: register-resident (n <= P*BS).  P == 0: streaming fallback.
@@ -181,14 +194,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(
       // 16 wave maxima -> block maximum: ONE LDS read per wave (lanes 0-15
       // take one entry each; slots of absent waves hold 0), a 4-step DPP
       // butterfly inside that 16-lane row, broadcast from lane 0.
-      unsigned long long v = lane < 16 ? wbest[j & 1][lane] : 0ull;
-      v = dpp_max_step<0xB1, 0xF>(v);
-      v = dpp_max_step<0x4E, 0xF>(v);
-      v = dpp_max_step<0x141, 0xF>(v);
-      v = dpp_max_step<0x140, 0xF>(v);
-      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-      key = ((unsigned long long)hi << 32) | lo;
+      key = row16_max_u64(lane < 16 ? wbest[j & 1][lane] : 0ull);
     }
     const int tstar = (int)(key & 0xFFFFFu);  // winning thread
     if (wave == (tstar >> 6)) {               // wave-uniform
@@ -380,12 +386,7 @@ __device__ __noinline__ unsigned fps_resolve_tie(const float (*s_pt)[1024], cons
   unsigned long long k2 = wave_max_u64(((unsigned long long)tk << 10) | (unsigned)t);
   if (lane == 0) wbest[slot][wave] = k2;
   lds_barrier();
-  unsigned long long v = wbest[slot][lane & 15];
-  v = dpp_max_step<0xB1, 0xF>(v);
-  v = dpp_max_step<0x4E, 0xF>(v);
-  v = dpp_max_step<0x141, 0xF>(v);
-  v = dpp_max_step<0x140, 0xF>(v);
-  const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned r = (unsigned)row16_max_u64(wbest[slot][lane & 15]);
   return ((r & 0x3FFu) << 4) | ((r >> 10) & 15u);
 }
 
@@ -457,14 +458,7 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(int n, int m, const fl
     if (lane == 0) wbest[j & 1][wave] = key;
     lds_barrier();
     {
-      unsigned long long v = lane < 16 ? wbest[j & 1][lane] : 0ull;
-      v = dpp_max_step<0xB1, 0xF>(v);
-      v = dpp_max_step<0x4E, 0xF>(v);
-      v = dpp_max_step<0x141, 0xF>(v);
-      v = dpp_max_step<0x140, 0xF>(v);
-      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-      key = ((unsigned long long)hi << 32) | lo;
+      key = row16_max_u64(lane < 16 ? wbest[j & 1][lane] : 0ull);
     }
     const float vbest = __uint_as_float((unsigned)(key >> 32));
     int tstar = (int)((unsigned)key & 0x3FFu);   // a holder of the maximum
