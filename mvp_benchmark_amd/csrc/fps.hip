@@ -18,10 +18,12 @@
 //     per round there is no global/LDS traffic for point data at all, HBM is
 //     touched once (12 B/point in, 4 B/sample out);
 //   * the hot loop only updates the running minima and their per-lane maximum
-//     (no index tracking); the arg-max is ONE packed 64-bit max reduction
+//     (no index tracking); the arg-max is ONE max reduction of the packed key
 //       key = float_bits(best) << 32 | (BS-1 - bitrev(t)) << 20 | t
 //     done with DPP row operations inside the wave and one LDS hop across the
-//     <=16 waves.  Only the winning lane then resolves which of its points
+//     <=16 waves -- as two 32-bit maxima (the value, then the tie word among
+//     its holders): one DPP-fused v_max_u32 per step instead of a 64-bit
+//     compare-and-select chain.  Only the winning lane then resolves which of its points
 //     holds the maximum and publishes index + coordinates from its registers
 //     through LDS (2 barriers per round instead of ~11, no global read for the
 //     selected point).  The key reproduces the reference's tie rule exactly:
