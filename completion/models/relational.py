@@ -43,14 +43,23 @@ class SA_module(nn.Module):
         x, idx = input                                   # x: (B, C, 1, N), idx: (B, N, k)
         batch_size, _, _, num_points = x.size()
         act = self.activation_fn(x)
-        nbr = get_edge_features(act, idx)                # (B, C, k, N)
+        # The reference gathers the k neighbours' C-channel features first and maps
+        # the (B, C, k, N) tensor with conv2 / conv3.  A per-point linear map commutes
+        # with the gather, so map the N points once (k times fewer multiply-adds, no
+        # (B, C, k, N) intermediate) and gather the r + mid mapped channels in one
+        # grouping call; same parameters, same result up to fp32 summation order.
         query = self.conv1(act)                          # (B, r, 1, N)
-        keys = self.conv2(nbr).reshape(batch_size, -1, 1, num_points)    # (B, k*r, 1, N)
-        values = self.conv3(nbr)                         # (B, mid, k, N)
+        r = query.size(1)
+        mapped = torch.cat([self.conv2(act), self.conv3(act)], 1)            # (B, r + mid, 1, N)
+        nbr = get_edge_features(mapped, idx)             # (B, r + mid, k, N)
+        keys = nbr[:, :r].reshape(batch_size, -1, 1, num_points)             # (B, r*k, 1, N), channel = r_i*k + k_i
+        values = nbr[:, r:]                              # (B, mid, k, N)
 
-        w = self.conv_w(torch.cat([query, keys], 1)).view(batch_size, -1, self.k, num_points)
-        w = w.repeat(1, self.share_planes, 1, 1)         # (B, mid, k, N)
-        out = (w * values).sum(dim=2, keepdim=True)
+        w = self.conv_w(torch.cat([query, keys], 1))     # (B, k*mid/share, 1, N)
+        # weights are shared by the `share_planes` channel groups: broadcast instead of repeat
+        w = w.view(batch_size, 1, -1, self.k, num_points)
+        grouped = values.reshape(batch_size, self.share_planes, -1, self.k, num_points)
+        out = (w * grouped).sum(dim=3).view(batch_size, -1, 1, num_points)
         out = self.conv_out(self.activation_fn(out))     # (B, C_out, 1, N)
         return [out + x, idx]
 

@@ -237,3 +237,29 @@ def test_pcn_forward_matches_reference_golden():
     with torch.no_grad():
         res = net(torch.tensor(g["x"]), prefix="test")["result"]
     np.testing.assert_allclose(res.numpy(), g["result"], rtol=1e-5, atol=1e-6)
+
+
+def test_sa_module_equals_gather_then_map_formulation():
+    """SA_module maps the points with conv2 / conv3 before gathering the
+    neighbours; the reference (vrcnet.py:36-57) gathers first.  Same parameters,
+    same function: compare against the gather-first formulation written out."""
+    from model_utils import get_edge_features
+    from models.relational import SA_module
+    torch.manual_seed(3)
+    B, C, N, k, share = 2, 32, 40, 6, 8
+    sam = SA_module(C, C // 16, C // 4, C, share_planes=share, k=k).double()
+    x = torch.randn(B, C, 1, N, dtype=torch.float64, requires_grad=True)
+    idx = torch.randint(0, N, (B, N, k))
+    out, _ = sam([x, idx])
+
+    act = torch.relu(x)
+    nbr = get_edge_features(act, idx)                               # (B, C, k, N)
+    query = sam.conv1(act)
+    keys = sam.conv2(nbr).reshape(B, -1, 1, N)
+    values = sam.conv3(nbr)
+    w = sam.conv_w(torch.cat([query, keys], 1)).view(B, -1, k, N).repeat(1, share, 1, 1)
+    ref = sam.conv_out(torch.relu((w * values).sum(dim=2, keepdim=True))) + x
+    assert torch.allclose(out, ref, rtol=1e-10, atol=1e-10)
+    g1, = torch.autograd.grad(out.square().sum(), x, retain_graph=True)
+    g2, = torch.autograd.grad(ref.square().sum(), x)
+    assert torch.allclose(g1, g2, rtol=1e-9, atol=1e-9)
