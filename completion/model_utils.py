@@ -145,24 +145,25 @@ def get_edge_features(x, idx):
     return feature.view(batch_size, num_points, k, num_dims).permute(0, 3, 2, 1)
 
 
+def group_neighbours(x, idx):
+    """x (B,C,N), idx (B,N,k) -> the neighbours' features (B,C,N,k): the grouping
+    operator on the GPU (scatter-add gradient included), advanced indexing on a
+    transposed copy for host tensors."""
+    if _on_op_layer(x):
+        return grouping_operation(x.contiguous(), idx.int().contiguous())
+    batch_size, num_points, k = idx.size()
+    num_dims = x.size(1)
+    base = torch.arange(batch_size, device=x.device).view(-1, 1, 1) * num_points
+    nbr = x.transpose(2, 1).reshape(batch_size * num_points, num_dims)[(idx + base).view(-1)]
+    return nbr.view(batch_size, num_points, k, num_dims).permute(0, 3, 1, 2)
+
+
 def get_graph_feature(x, k=20, minus_center=True):
     """DGCNN edge features of x (B,C,N): (B,2C,N,k) = [centre, neighbour -
     centre] (or [centre, neighbour]) (model_utils.py:156-178)."""
-    idx = knn(x, k=k)
-    batch_size, num_points, _ = idx.size()
-    num_dims = x.size(1)
-    if _on_op_layer(x):
-        x = x.contiguous()
-        nbr = grouping_operation(x, idx.int().contiguous())                 # (B,C,N,k)
-        ctr = x.unsqueeze(3).expand(-1, -1, -1, k)
-        return torch.cat((ctr, nbr - ctr if minus_center else nbr), dim=1)
-    pts = x.transpose(2, 1).contiguous()                                   # (B,N,C)
-    base = torch.arange(batch_size, device=x.device).view(-1, 1, 1) * num_points
-    nbr = pts.view(batch_size * num_points, num_dims)[(idx + base).view(-1)]
-    nbr = nbr.view(batch_size, num_points, k, num_dims)
-    ctr = pts.view(batch_size, num_points, 1, num_dims).expand(-1, -1, k, -1)
-    second = nbr - ctr if minus_center else nbr
-    return torch.cat((ctr, second), dim=3).permute(0, 3, 1, 2)
+    nbr = group_neighbours(x, knn(x, k=k))                                  # (B,C,N,k)
+    ctr = x.unsqueeze(3).expand(-1, -1, -1, k)
+    return torch.cat((ctr, nbr - ctr if minus_center else nbr), dim=1)
 
 
 # --------------------------------------------------------------------------

@@ -4,7 +4,7 @@ reference completion/models/ecg.py:21-33, :36-65, :68-158; sub-module names
 are kept so checkpoints interchange.  Split out of ecg.py, which keeps the
 decoder and the Model.
 
-Op-layer calls per encoder forward: kNN graphs inside get_graph_feature, FPS +
+Op-layer calls per encoder forward: kNN graphs + neighbour gather inside Dense_conv, FPS +
 gather + group inside edge_preserve_sampling (3072 -> 1024 -> 256 -> 64 points
 at the default cfg), three_nn + three_interpolate back up.
 """
@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from model_utils import edge_preserve_sampling, get_graph_feature, three_nn_upsampling
+from model_utils import edge_preserve_sampling, group_neighbours, knn, three_nn_upsampling
 from mm3d_pn2 import three_interpolate
 from models._common import dense, pointwise1d, pointwise2d
 
@@ -55,9 +55,38 @@ class Dense_conv(nn.Module):
         self.input_size = width - growth_rate if dense_n > 1 else width
 
     def forward(self, x):
-        edge = F.relu(self.first_conv(get_graph_feature(x, k=self.k)))        # (B, g, N, k)
-        edge = torch.cat((edge, x.unsqueeze(3).expand(-1, -1, -1, self.k)), 1)
-        return self.model(edge).max(dim=3)[0]
+        """x (B, C, N) -> (B, C + growth_rate * dense_n, N).
+
+        The reference (ecg.py:36-65) materialises the (B, 2C, N, k) edge tensor
+        [centre, neighbour - centre], keeps the expanded centre features in the
+        dense stack and takes the max over k at the end.  Every layer is a
+        per-edge LINEAR map, so the centre columns of its weight act on a (B, C, N)
+        tensor and are broadcast over k, first_conv's neighbour columns are applied
+        before the gather, and only the genuinely per-edge channels stay
+        (B, ., N, k).  Same parameters, same function up to fp32 summation order.
+        """
+        c, g = x.size(1), self.growth_rate
+        idx = knn(x, self.k)                                                 # (B, N, k)
+        w = self.first_conv.weight.flatten(1)                                # (g, 2C) = [centre | neighbour - centre]
+        w_ctr, w_nbr = w[:, :c], w[:, c:]
+        bias = self.first_conv.bias
+        # W [ctr; nbr - ctr] + b = (W_ctr - W_nbr) ctr + b  +  W_nbr nbr
+        both = F.conv1d(x, torch.cat((w_ctr - w_nbr, w_nbr), 0).unsqueeze(2), torch.cat((bias, torch.zeros_like(bias))))
+        edge = F.relu(both[:, :g].unsqueeze(3) + group_neighbours(both[:, g:], idx))   # (B, g, N, k)
+        stack = edge                                 # per-edge channels so far: [edge, y_1, ...]
+        outs = [edge.max(dim=3)[0], x]               # max over k of [edge, centre (constant over k), y_1, ...]
+        layers = list(self.model)
+        for i, layer in enumerate(layers):
+            conv = layer.model.conv
+            w = conv.weight.flatten(1)               # input channels: [edge (g), centre (C), y_1 .. y_{i}]
+            w_edge = torch.cat((w[:, :g], w[:, g + c:]), 1)
+            y = F.conv2d(stack, w_edge[:, :, None, None]) + F.conv1d(x, w[:, g:g + c].unsqueeze(2), conv.bias).unsqueeze(3)
+            if hasattr(layer.model, 'act'):
+                y = layer.model.act(y)
+            outs.append(y.max(dim=3)[0])
+            if i + 1 < len(layers):
+                stack = torch.cat((stack, y), 1)
+        return torch.cat(outs, 1)
 
 
 class EF_encoder(nn.Module):

@@ -263,3 +263,32 @@ def test_sa_module_equals_gather_then_map_formulation():
     g1, = torch.autograd.grad(out.square().sum(), x, retain_graph=True)
     g2, = torch.autograd.grad(ref.square().sum(), x)
     assert torch.allclose(g1, g2, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("dense_n", [1, 3])
+def test_dense_conv_equals_edge_tensor_formulation(dense_n):
+    """Dense_conv applies the centre columns of every layer per point and
+    first_conv's neighbour columns before the gather; the reference
+    (ecg.py:36-65) runs every layer on the materialised (B, ., N, k) edge
+    tensor.  Same parameters, same function."""
+    import torch.nn.functional as F
+    from model_utils import get_graph_feature
+    from models.edge_unet import Dense_conv
+    torch.manual_seed(5)
+    B, C, N, k = 2, 12, 50, 5
+    dc = Dense_conv(C, growth_rate=8, dense_n=dense_n, k=k).double()
+    x = torch.randn(B, C, N, dtype=torch.float64, requires_grad=True)
+    out = dc(x)
+    assert out.shape == (B, C + 8 * dense_n, N)
+
+    edge = F.relu(dc.first_conv(get_graph_feature(x, k=k)))
+    edge = torch.cat((edge, x.unsqueeze(3).expand(-1, -1, -1, k)), 1)
+    ref = dc.model(edge).max(dim=3)[0]
+    assert torch.allclose(out, ref, rtol=1e-10, atol=1e-10)
+    g1, = torch.autograd.grad(out.square().sum(), x, retain_graph=True)
+    g2, = torch.autograd.grad(ref.square().sum(), x, retain_graph=True)
+    assert torch.allclose(g1, g2, rtol=1e-9, atol=1e-9)
+    p1 = torch.autograd.grad(out.square().sum(), list(dc.parameters()))
+    p2 = torch.autograd.grad(ref.square().sum(), list(dc.parameters()))
+    for a, b in zip(p1, p2):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
