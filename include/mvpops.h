@@ -40,7 +40,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 2
+#define MVP_ABI_VERSION 3
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -235,6 +235,34 @@ int mvp_group_points(int b, int c, int n, int npoints, int nsample,
 int mvp_group_points_grad(int b, int c, int n, int npoints, int nsample,
                           const float *grad_out, const int *idx,
                           float *grad_points, void *stream);
+
+/* ---- the three scatter-add gradients with caller-provided scratch.
+ * Same contracts as mvp_gather_points_grad / mvp_group_points_grad /
+ * mvp_three_interpolate_grad (same reference launchers; grad_points is
+ * accumulated into).  The index array is inverted once per call into `scratch`
+ * (counting sort by destination per cloud and chunk of grad_out columns), then
+ * every destination is summed by one thread from LDS-staged grad_out columns:
+ * no float atomics, grad_out read once.  mvp_scatter_scratch_bytes(b, n_dst,
+ * m_src, r): bytes needed for b clouds, n_dst destination points (the n of
+ * gather/group, the m of three_interpolate), m_src grad_out columns (npoints,
+ * npoints*nsample, or three_interpolate's n) and r index entries per column
+ * (1, or 3 for three_interpolate); 0 = shape not covered (n_dst > 8192).  With
+ * scratch == NULL, scratch_bytes too small or a shape that is not covered the
+ * _ws entry points run the plain ones. */
+long long mvp_scatter_scratch_bytes(int b, int n_dst, int m_src, int r);
+int mvp_gather_points_grad_ws(int b, int c, int n, int npoints,
+                              const float *grad_out, const int *idx,
+                              float *grad_points, void *scratch,
+                              long long scratch_bytes, void *stream);
+int mvp_group_points_grad_ws(int b, int c, int n, int npoints, int nsample,
+                             const float *grad_out, const int *idx,
+                             float *grad_points, void *scratch,
+                             long long scratch_bytes, void *stream);
+int mvp_three_interpolate_grad_ws(int b, int c, int n, int m,
+                                  const float *grad_out, const int *idx,
+                                  const float *weight, float *grad_points,
+                                  void *scratch, long long scratch_bytes,
+                                  void *stream);
 
 #ifdef __cplusplus
 }

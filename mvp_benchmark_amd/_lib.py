@@ -37,6 +37,9 @@ SIGNATURES = {
     "mvp_gather_points_grad": "iiiippp",
     "mvp_group_points": "iiiiippp",
     "mvp_group_points_grad": "iiiiippp",
+    "mvp_gather_points_grad_ws": "iiiippppq",
+    "mvp_group_points_grad_ws": "iiiiippppq",
+    "mvp_three_interpolate_grad_ws": "iiiipppppq",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
@@ -68,11 +71,13 @@ def load():
     lib.mvp_fps_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_chamfer_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_chamfer_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.mvp_scatter_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_scatter_scratch_bytes.argtypes = [ctypes.c_int] * 4
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [_CT[k] for k in sig] + [ctypes.c_void_p]  # + stream
-    if lib.mvp_abi_version() != 2:
+    if lib.mvp_abi_version() != 3:
         raise MvpOpsError("libmvpops.so ABI version mismatch")
     _lib = lib
     return lib
@@ -124,7 +129,13 @@ def chamfer_scratch_bytes(b, n, m):
     return int(load().mvp_chamfer_scratch_bytes(int(b), int(n), int(m)))
 
 
+def scatter_scratch_bytes(b, n_dst, m_src, r):
+    """Scratch of the *_grad_ws entry points (0: shape not covered, they run the plain kernels)."""
+    return int(load().mvp_scatter_scratch_bytes(int(b), int(n_dst), int(m_src), int(r)))
+
+
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
-    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes"] \
+    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes",
+            "mvp_scatter_scratch_bytes"] \
         + list(SIGNATURES)

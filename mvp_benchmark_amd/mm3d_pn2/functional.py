@@ -16,7 +16,7 @@ Reference wrappers mirrored here (paths under utils/mm3d_pn2/ops/):
 import torch
 from torch.autograd import Function
 
-from .._lib import call, fps_scratch_bytes
+from .._lib import call, fps_scratch_bytes, scatter_scratch_bytes
 
 
 def _need_contiguous(*tensors):
@@ -27,6 +27,14 @@ def _need_contiguous(*tensors):
 def _new(ref, *shape, dtype=torch.float32, zero=False):
     make = torch.zeros if zero else torch.empty
     return make(*shape, dtype=dtype, device=ref.device)
+
+
+def _scatter_scratch(ref, b, n_dst, m_src, r):
+    """Workspace of the scatter-add gradients (the transposed index list);
+    0 bytes when the shape is not covered -- the entry point then runs the
+    plain kernels."""
+    nbytes = scatter_scratch_bytes(b, n_dst, m_src, r)
+    return (torch.empty(nbytes, dtype=torch.uint8, device=ref.device) if nbytes else None), nbytes
 
 
 # ------------------------------------------------------------------ sampling
@@ -168,8 +176,9 @@ class ThreeInterpolate(Function):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.shape
         grad_features = _new(grad_out, B, c, m, zero=True)
-        call("mvp_three_interpolate_grad", grad_out.device, B, c, n, m, grad_out.data.contiguous(), idx, weight,
-             grad_features)
+        scratch, nbytes = _scatter_scratch(grad_out, B, m, n, 3)
+        call("mvp_three_interpolate_grad_ws", grad_out.device, B, c, n, m, grad_out.data.contiguous(), idx, weight,
+             grad_features, scratch, nbytes)
         return grad_features, None, None
 
 
@@ -194,8 +203,9 @@ class GatherPoints(Function):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.shape
         grad_features = _new(grad_out, B, C, N, zero=True)
-        call("mvp_gather_points_grad", grad_out.device, B, C, N, npoint, grad_out.data.contiguous(), idx,
-             grad_features)
+        scratch, nbytes = _scatter_scratch(grad_out, B, N, npoint, 1)
+        call("mvp_gather_points_grad_ws", grad_out.device, B, C, N, npoint, grad_out.data.contiguous(), idx,
+             grad_features, scratch, nbytes)
         return grad_features, None
 
 
@@ -219,8 +229,9 @@ class GroupingOperation(Function):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.shape
         grad_features = _new(grad_out, B, C, N, zero=True)
-        call("mvp_group_points_grad", grad_out.device, B, C, N, npoint, nsample, grad_out.data.contiguous(), idx,
-             grad_features)
+        scratch, nbytes = _scatter_scratch(grad_out, B, N, npoint * nsample, 1)
+        call("mvp_group_points_grad_ws", grad_out.device, B, C, N, npoint, nsample, grad_out.data.contiguous(), idx,
+             grad_features, scratch, nbytes)
         return grad_features, None
 
 

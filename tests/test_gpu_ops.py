@@ -394,7 +394,8 @@ def test_three_nn_matches_oracle(oracle, n, m):
 
 
 # ------------------------------------------------- gather/group/interpolate
-@pytest.mark.parametrize("b,c,n,m", [(2, 3, 3072, 1536), (3, 64, 1536, 15360), (1, 13, 100, 7), (2, 1, 5, 300)])
+@pytest.mark.parametrize("b,c,n,m", [(2, 3, 3072, 1536), (3, 64, 1536, 15360), (1, 13, 100, 7), (2, 1, 5, 300),
+                                     (2, 20, 5000, 9000), (2, 9, 8192, 4000), (1, 4, 9000, 3000), (2, 17, 2048, 3073)])
 def test_gather_points_fwd_bwd(oracle, b, c, n, m):
     from mvp_benchmark_amd.mm3d_pn2 import gather_points
     f = rand_clouds(0, b, c, n)
@@ -407,7 +408,8 @@ def test_gather_points_fwd_bwd(oracle, b, c, n, m):
     np.testing.assert_allclose(tf.grad.cpu().numpy(), oracle.gather_points_grad(g, idx, n), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("b,c,n,p,s", [(2, 3, 2048, 102, 24), (2, 64, 1536, 768, 1), (1, 10, 50, 7, 5)])
+@pytest.mark.parametrize("b,c,n,p,s", [(2, 3, 2048, 102, 24), (2, 64, 1536, 768, 1), (1, 10, 50, 7, 5),
+                                       (2, 80, 768, 768, 16), (2, 12, 3072, 3072, 16)])
 def test_grouping_operation_fwd_bwd(oracle, b, c, n, p, s):
     from mvp_benchmark_amd.mm3d_pn2 import grouping_operation
     f = rand_clouds(0, b, c, n)
@@ -421,7 +423,8 @@ def test_grouping_operation_fwd_bwd(oracle, b, c, n, p, s):
     np.testing.assert_allclose(tf.grad.cpu().numpy(), oracle.grouping_operation_grad(g, idx, n), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("b,c,m,n", [(2, 512, 384, 768), (2, 128, 1536, 3072), (1, 5, 10, 33)])
+@pytest.mark.parametrize("b,c,m,n", [(2, 512, 384, 768), (2, 128, 1536, 3072), (1, 5, 10, 33), (2, 9, 1024, 3100),
+                                     (1, 3, 9000, 500)])
 def test_three_interpolate_fwd_bwd(oracle, b, c, m, n):
     from mvp_benchmark_amd.mm3d_pn2 import three_interpolate
     f = rand_clouds(0, b, c, m)
@@ -433,6 +436,34 @@ def test_three_interpolate_fwd_bwd(oracle, b, c, m, n):
     g = rand_clouds(2, b, c, n)
     out.backward(dev(g))
     np.testing.assert_allclose(tf.grad.cpu().numpy(), oracle.three_interpolate_grad(g, idx, w, m), rtol=1e-5, atol=1e-5)
+
+
+def test_scatter_gradients_hub_graph_and_plain_entry_points(oracle):
+    """Every entry scatters into one of three destinations (the longest possible
+    lists of the transposed index), and the *_ws entry points agree with the
+    plain ones they fall back to."""
+    from mvp_benchmark_amd import _lib
+    b, c, n, p, s = 2, 11, 1500, 700, 9
+    rng = np.random.default_rng(4)
+    idx = rng.integers(0, 3, (b, p, s)).astype(np.int32) * 700
+    g = rand_clouds(5, b, c, p, s)
+    want = oracle.grouping_operation_grad(g, idx, n)
+    tg, ti = dev(g), dev(idx)
+    plain = torch.zeros(b, c, n, device=DEV)
+    _lib.call("mvp_group_points_grad", DEV, b, c, n, p, s, tg, ti, plain)
+    nbytes = _lib.scatter_scratch_bytes(b, n, p * s, 1)
+    assert nbytes > 0
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(b, c, n, device=DEV)
+    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, ws, scratch, nbytes)
+    nows = torch.zeros(b, c, n, device=DEV)
+    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, nows, None, 0)
+    for got in (plain, ws, nows):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-4)
+    # accumulate-into contract: a second call doubles the result
+    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, ws, scratch, nbytes)
+    np.testing.assert_allclose(ws.cpu().numpy(), 2 * want, rtol=2e-5, atol=4e-4)
+    assert _lib.scatter_scratch_bytes(b, 8193, 100, 1) == 0 and _lib.scatter_scratch_bytes(b, 100, 100, 2) == 0
 
 
 def test_query_and_group_composition(oracle):
