@@ -20,10 +20,14 @@
 //   * the hot loop only updates the running minima and their per-lane maximum
 //     (no index tracking); the arg-max is ONE max reduction of the packed key
 //       key = float_bits(best) << 32 | (BS-1 - bitrev(t)) << 20 | t
-//     done with DPP row operations inside the wave and one LDS hop across the
-//     <=16 waves -- as two 32-bit maxima (the value, then the tie word among
-//     its holders): one DPP-fused v_max_u32 per step instead of a 64-bit
-//     compare-and-select chain.  Only the winning lane then resolves which of its points
+//     done with DPP row operations inside the wave -- as two 32-bit maxima
+//     (the value, then the tie word among its holders; a single holder's tie
+//     word is fetched with one v_readlane): one DPP-fused v_max_u32 per step
+//     instead of a 64-bit compare-and-select chain -- and ONE ds_max_u64 per
+//     wave on a double-buffered LDS word across the <=16 waves (a round is
+//     bound by the ~80 instruction slots every wave spends on it, 4 waves to
+//     a SIMD; the LDS atomic replaces a second reduction stage of ~25 slots).
+//     Only the winning lane then resolves which of its points
 //     holds the maximum and publishes index + coordinates from its registers
 //     through LDS (2 barriers per round instead of ~11, no global read for the
 //     selected point).  The key reproduces the reference's tie rule exactly:
@@ -74,10 +78,17 @@ __device__ __forceinline__ unsigned row16_umax32(unsigned v) {  // butterfly: ev
 // 64-bit compare-and-select costs five dependent instructions per DPP step;
 // the lexicographic max is instead taken as two 32-bit reductions -- the value,
 // then the tie word among the lanes that hold that value (0 elsewhere).
+// When a single lane holds the maximal value (every round on generic data) its
+// tie word is fetched with one v_readlane instead of a second DPP reduction.
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
   const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
   const unsigned mh = wave_umax32(hi);
-  const unsigned ml = wave_umax32(hi == mh ? lo : 0u);
+  const unsigned long long holders = __ballot(hi == mh);  // never empty
+  unsigned ml;
+  if ((holders & (holders - 1ull)) == 0ull)  // wave-uniform
+    ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(holders));
+  else
+    ml = wave_umax32(hi == mh ? lo : 0u);
   return ((unsigned long long)mh << 32) | ml;
 }
 // The same over the 16 lanes of row 0 (valid in every lane of that row; taken
@@ -85,7 +96,12 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 __device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
   const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
   const unsigned mh = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_umax32(hi));
-  const unsigned ml = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_umax32(hi == mh ? lo : 0u));
+  const unsigned long long holders = __ballot(hi == mh) & 0xFFFFull;  // row 0 only; never empty
+  unsigned ml;
+  if ((holders & (holders - 1ull)) == 0ull)
+    ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(holders));
+  else
+    ml = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_umax32(hi == mh ? lo : 0u));
   return ((unsigned long long)mh << 32) | ml;
 }
 
@@ -107,7 +123,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(
   temp += (size_t)cloud * n;
   idxs += (size_t)cloud * m;
 
-  __shared__ unsigned long long wbest[2][16];
+  __shared__ unsigned long long s_max[2];  // block maximum of the packed key, by round parity
   __shared__ float s_sel[2][4];  // {old as int bits, x, y, z} of the selected point
 
   // bit-reverse t within log2bs bits; smaller reversed id wins ties.
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(
       for (int k = t; k < n; k += bs) temp[k] = 1e10f;
   }
 
-  if (t < 32) wbest[t >> 4][t & 15] = 0ull;  // slots of absent waves never win
+  if (t < 2) s_max[t] = 0ull;
   __syncthreads();
   int old = 0;
   if (t == 0) idxs[0] = old;
@@ -191,12 +207,13 @@ __global__ __launch_bounds__(1024) void fps_kernel(
     if (!live) key = 0;
     key = wave_max_u64(key);
     if (nwaves > 1) {
-      if (lane == 0) wbest[j & 1][wave] = key;
+      // <= 16 wave maxima -> block maximum: one ds_max_u64 per wave on a
+      // double-buffered LDS word, one broadcast read after the barrier (no
+      // second reduction stage); the other word is cleared for the next round.
+      if (lane == 0) atomicMax(&s_max[j & 1], key);
       lds_barrier();
-      // 16 wave maxima -> block maximum: ONE LDS read per wave (lanes 0-15
-      // take one entry each; slots of absent waves hold 0), a 4-step DPP
-      // butterfly inside that 16-lane row, broadcast from lane 0.
-      key = row16_max_u64(lane < 16 ? wbest[j & 1][lane] : 0ull);
+      key = s_max[j & 1];
+      if (t == 0) s_max[(j + 1) & 1] = 0ull;
     }
     const int tstar = (int)(key & 0xFFFFFu);  // winning thread
     if (wave == (tstar >> 6)) {               // wave-uniform
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(int n, int m, const fl
                                                           const float4 *__restrict__ sorted,
                                                           float *__restrict__ temp, int *__restrict__ idxs) {
   if (m <= 0) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
   const int cloud = blockIdx.x;
   dataset += (size_t)cloud * n * 3;
   sorted += (size_t)cloud * (1024 * P);
@@ -406,6 +423,7 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(int n, int m, const fl
   __shared__ unsigned long long wbest[2][16];
   __shared__ float s_sel[2][4];
   __shared__ int s_tie[2];  // last round (by parity) in which the maximum was not unique
+  __shared__ unsigned long long s_max[2];  // block maximum {value bits, a holder}, by round parity
   // original indices ([i][t]: conflict-free): read only by the publishing lane
   // and in tie rounds; s_pt receives the running minima in tie rounds
   __shared__ int s_pk[P][1024];
@@ -431,7 +449,10 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(int n, int m, const fl
   for (int i = 1; i < P; ++i) lane_max = __builtin_fmaxf(lane_max, pt[i]);
   bool lane_dup = true;  // all valid points start equal
 
-  if (t < 2) s_tie[t] = 0;
+  if (t < 2) {
+    s_tie[t] = 0;
+    s_max[t] = 0ull;
+  }
   if (t == 0) idxs[0] = 0;
   float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
   __syncthreads();
@@ -457,11 +478,10 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(int n, int m, const fl
     // lanes of padding contribute the smallest key
     unsigned long long key = lane_max >= 0.f ? ((unsigned long long)__float_as_uint(lane_max) << 32) | (unsigned)t : 0ull;
     key = wave_max_u64(key);
-    if (lane == 0) wbest[j & 1][wave] = key;
+    if (lane == 0) atomicMax(&s_max[j & 1], key);
     lds_barrier();
-    {
-      key = row16_max_u64(lane < 16 ? wbest[j & 1][lane] : 0ull);
-    }
+    key = s_max[j & 1];
+    if (t == 0) s_max[(j + 1) & 1] = 0ull;
     const float vbest = __uint_as_float((unsigned)(key >> 32));
     int tstar = (int)((unsigned)key & 0x3FFu);   // a holder of the maximum
     // is the maximum attained once only?  (another lane, or twice in the holder)

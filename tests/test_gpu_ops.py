@@ -295,6 +295,42 @@ def test_fps_ties_on_lattice(oracle):
         np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample(x, m))
 
 
+@pytest.mark.parametrize("b,n,m", [(3, 1025, 300), (2, 1536, 1536), (2, 1537, 100), (3, 2047, 512), (2, 3000, 1500),
+                                   (2, 4096, 1024), (2, 4097, 333), (2, 6144, 2000), (2, 7000, 512), (2, 8192, 700)])
+def test_fps_fat_wave_kernel_matches_oracle(oracle, b, n, m):
+    """1024 < N <= 8192 runs on 4 (8) waves that own N / 256 (N / 512) points per
+    lane: indices equal the oracle's, the running minima left in `temp` are the
+    distances to the nearest selected point."""
+    from mvp_benchmark_amd import _lib
+    x = rand_clouds(n * 3 + m, b, n, 3)
+    tx = dev(x)
+    temp = torch.full((b, n), 1e10, device=DEV)
+    idx = torch.zeros(b, m, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_furthest_point_sampling", tx.device, b, n, m, tx, temp, idx)
+    want = oracle.furthest_point_sample(x, m)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    sel = np.take_along_axis(x, want[:, :-1, None].astype(np.int64), 1).astype(np.float64)     # the last pick updates nothing
+    d = ((x[:, :, None, :].astype(np.float64) - sel[:, None, :, :]) ** 2).sum(-1).min(-1) if m > 1 else np.full((b, n), 1e10)
+    np.testing.assert_allclose(temp.cpu().numpy(), d, rtol=1e-5, atol=1e-7)
+
+
+def test_fps_fat_wave_kernel_ties(oracle):
+    """Lattices and duplicated points across the fat-wave size range: most rounds
+    have several points at the maximum, inside one lane and across lanes."""
+    from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample
+    cases = []
+    for side, m in [(11, 700), (13, 900), (16, 1200), (18, 600), (20, 500)]:
+        g = np.stack(np.meshgrid(*[np.arange(side) / 32.0] * 3, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+        perm = np.random.default_rng(side).permutation(g.shape[1])
+        cases.append((np.ascontiguousarray(np.concatenate([g, g[:, perm]], 0)), m))
+    cases.append((np.tile(rand_clouds(3, 2, 700, 3), (1, 4, 1)), 1000))       # 2800 points, every point 4 times
+    cases.append((np.tile(rand_clouds(4, 2, 1000, 3), (1, 7, 1)), 1500))      # 7000 points, every point 7 times
+    cases.append((np.zeros((2, 3000, 3), np.float32), 50))                    # all points identical
+    for x, m in cases:
+        idx = furthest_point_sample(dev(x), m)
+        np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample(x, m))
+
+
 @pytest.mark.parametrize("b,n,m", [(3, 4097, 500), (2, 6000, 1000), (2, 8192, 2048), (2, 12000, 700), (2, 16384, 2048)])
 def test_fps_sorted_variant_matches_oracle(oracle, b, n, m):
     """The Morton-sorted kernel for 4096 < N <= 16384 (whole waves skip the

@@ -22,7 +22,7 @@ def R(*shape):
     return torch.rand(*shape, generator=g).to(dev)
 
 if which in ("all", "fps"):
-    for (b, n, m) in [(64, 16384, 2048), (64, 2048, 512), (64, 2048, 2048), (64, 3072, 1536), (64, 1536, 768), (64, 768, 384), (32, 2048, 2048)]:
+    for (b, n, m) in [(64, 16384, 2048), (64, 2048, 512), (64, 2048, 2048), (64, 3072, 1536), (64, 1536, 768), (64, 768, 384), (32, 2048, 2048), (32, 3072, 1536), (64, 4096, 1024), (64, 8192, 1024)]:
         x = R(b, n, 3)
         ms = timeit(lambda: furthest_point_sample(x, m))
         print("fps (%d,%d)->%d: %.3f ms  %.3g sampled pts/s  %.3g updates/s  %.2f us/round" % (b, n, m, ms, b * m / ms * 1e3, b * (m - 1) * n / ms * 1e3, ms * 1e3 / (m - 1)), flush=True)
