@@ -44,6 +44,8 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
+ABI_VERSION = 3   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+
 _lib = None
 
 
@@ -77,7 +79,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [_CT[k] for k in sig] + [ctypes.c_void_p]  # + stream
-    if lib.mvp_abi_version() != 3:
+    if lib.mvp_abi_version() != ABI_VERSION:
         raise MvpOpsError("libmvpops.so ABI version mismatch")
     _lib = lib
     return lib

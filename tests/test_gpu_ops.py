@@ -22,7 +22,7 @@ def dev(a, dtype=None):
 def test_extension_is_loaded_not_a_fallback():
     from mvp_benchmark_amd import _lib
     lib = _lib.load()
-    assert lib.mvp_abi_version() == 2
+    assert lib.mvp_abi_version() == _lib.ABI_VERSION
     assert "libmvpops.so" in open("/proc/self/maps").read()
     assert torch.cuda.is_available()
 
