@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from model_utils import edge_preserve_sampling, group_neighbours, knn, three_nn_upsampling
+from model_utils import edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling
 from mm3d_pn2 import three_interpolate
 from models._common import dense, pointwise1d, pointwise2d
 
@@ -72,18 +72,20 @@ class Dense_conv(nn.Module):
         bias = self.first_conv.bias
         # W [ctr; nbr - ctr] + b = (W_ctr - W_nbr) ctr + b  +  W_nbr nbr
         both = F.conv1d(x, torch.cat((w_ctr - w_nbr, w_nbr), 0).unsqueeze(2), torch.cat((bias, torch.zeros_like(bias))))
-        edge = F.relu(both[:, :g].unsqueeze(3) + group_neighbours(both[:, g:], idx))   # (B, g, N, k)
+        # per-edge tensors are kept (B, ., k, N): the max over the k neighbours then reduces a strided
+        # dimension with N contiguous instead of 16-element rows (the layers are 1x1, the layout is free)
+        edge = F.relu(both[:, :g].unsqueeze(2) + get_edge_features(both[:, g:], idx))   # (B, g, k, N)
         stack = edge                                 # per-edge channels so far: [edge, y_1, ...]
-        outs = [edge.max(dim=3)[0], x]               # max over k of [edge, centre (constant over k), y_1, ...]
+        outs = [edge.max(dim=2)[0], x]               # max over k of [edge, centre (constant over k), y_1, ...]
         layers = list(self.model)
         for i, layer in enumerate(layers):
             conv = layer.model.conv
             w = conv.weight.flatten(1)               # input channels: [edge (g), centre (C), y_1 .. y_{i}]
             w_edge = torch.cat((w[:, :g], w[:, g + c:]), 1)
-            y = F.conv2d(stack, w_edge[:, :, None, None]) + F.conv1d(x, w[:, g:g + c].unsqueeze(2), conv.bias).unsqueeze(3)
+            y = F.conv2d(stack, w_edge[:, :, None, None]) + F.conv1d(x, w[:, g:g + c].unsqueeze(2), conv.bias).unsqueeze(2)
             if hasattr(layer.model, 'act'):
                 y = layer.model.act(y)
-            outs.append(y.max(dim=3)[0])
+            outs.append(y.max(dim=2)[0])
             if i + 1 < len(layers):
                 stack = torch.cat((stack, y), 1)
         return torch.cat(outs, 1)
