@@ -187,8 +187,11 @@ def edge_preserve_sampling(feature_input, point_input, num_samples, k=10):
     pk = int(min(k, num_points))
     pn_idx = knn_point_idx(pk, point_input, point_output)
     pn_idx = pn_idx.detach().int()
-    neighbor_feature = gather_points(feature_input, pn_idx.view(batch_size, num_samples * pk))
-    neighbor_feature = neighbor_feature.view(batch_size, feature_size, num_samples, pk).max(dim=3)[0]
+    # gathered neighbour-major, (B, C, pk, S): the max over the pk neighbours then reduces a strided
+    # dimension with S contiguous instead of pk-element rows
+    nbr_major = pn_idx.transpose(1, 2).contiguous().view(batch_size, pk * num_samples)
+    neighbor_feature = gather_points(feature_input, nbr_major)
+    neighbor_feature = neighbor_feature.view(batch_size, feature_size, pk, num_samples).max(dim=2)[0]
 
     center_feature = grouping_operation(feature_input, p_idx.unsqueeze(2)) \
         .view(batch_size, -1, num_samples)
