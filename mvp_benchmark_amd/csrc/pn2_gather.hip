@@ -319,18 +319,19 @@ __global__ __launch_bounds__(kScThreads) __attribute__((amdgpu_waves_per_eu(D ==
     const int pn = min(CHUNK, m_src - p0);
     const int *off = offsets + ((size_t)cloud * nq + q) * (n_dst + 1);
     const int *lst = list + ((size_t)cloud * nq + q) * ((size_t)CHUNK * R) * (WEIGHTED ? 2 : 1);
+    // List reads are unconditional (position clamped into the chunk's list, the
+    // result discarded when !live): four of them issue back to back instead of
+    // four exec-masked load + wait sequences.
     auto entry = [&](int i, bool live, int &e, float &w) {  // list position i -> chunk-local column, weight (0 if !live)
-      e = 0;
-      w = 0.f;
-      if (live) {
-        if constexpr (WEIGHTED) {
-          const int2 ew = reinterpret_cast<const int2 *>(lst)[i];
-          e = ew.x;
-          w = __int_as_float(ew.y);
-        } else {
-          e = lst[i];
-          w = 1.f;
-        }
+      const int ii = min(i, CHUNK * R - 1);
+      if constexpr (WEIGHTED) {
+        const int2 ew = reinterpret_cast<const int2 *>(lst)[ii];
+        e = live ? ew.x : 0;
+        w = live ? __int_as_float(ew.y) : 0.f;
+      } else {
+        const int ev = lst[ii];
+        e = live ? ev : 0;
+        w = live ? 1.f : 0.f;
       }
     };
     // offsets and the first entry of every destination are fetched under the
@@ -375,12 +376,12 @@ __global__ __launch_bounds__(kScThreads) __attribute__((amdgpu_waves_per_eu(D ==
         for (int u = 0; u < 4; ++u) entry(i + u, i + u < o1[d], e[u], w[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          if (i + u < o1[d]) {
+          const bool live = i + u < o1[d];
 #pragma unroll
-            for (int k = 0; k < CH; ++k) {
-              const float g = stage[k * CHUNK + e[u]];
-              acc[d][k] += WEIGHTED ? g * w[u] : g;
-            }
+          for (int k = 0; k < CH; ++k) {
+            const float g = stage[k * CHUNK + e[u]];  // column 0 when !live: read, not added
+            const float term = WEIGHTED ? g * w[u] : g;
+            acc[d][k] += live ? term : 0.f;
           }
         }
       }

@@ -59,3 +59,11 @@ if which in ("all", "grad"):
         go = torch.rand_like(out)
         ms = timeit(lambda: torch.autograd.grad(out, f, go, retain_graph=True))
         print("gather grad (%d,%d,%d)<-%d: %.3f ms  %.1f GB/s of grad_out read" % (b, c, n, m, ms, 4.0 * b * c * m / ms / 1e6), flush=True)
+    for (b, c, m, n) in [(32, 512, 1024, 3072), (32, 768, 256, 1024), (64, 128, 1536, 3072)]:
+        f = R(b, c, m).requires_grad_()
+        idx = torch.randint(0, m, (b, n, 3), generator=g).int().to(dev)
+        w = R(b, n, 3)
+        out = three_interpolate(f, idx, w)
+        go = torch.rand_like(out)
+        ms = timeit(lambda: torch.autograd.grad(out, f, go, retain_graph=True))
+        print("three_interpolate grad (%d,%d,%d)<-%d: %.3f ms  %.1f GB/s of grad_out read" % (b, c, m, n, ms, 4.0 * b * c * n / ms / 1e6), flush=True)
