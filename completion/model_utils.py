@@ -82,7 +82,7 @@ def knn(x, k):
         pts = x.detach().transpose(2, 1)
         return _knn_xyz(k, pts, pts)
     sq = (x * x).sum(dim=1, keepdim=True)                       # (B,1,N)
-    if _on_op_layer(x) and 0 < k <= min(100, x.size(2)):
+    if _on_op_layer(x) and 0 < k <= min(64, x.size(2)) and x.size(2) <= 16384:
         # features: the GEMM stays a library call; the three elementwise passes over
         # the (B,N,N) matrix and the radix top-k become one scan of the Gram matrix
         xd = x.detach()

@@ -175,7 +175,9 @@ int mvp_knn(int b, int n, int m, int nsample, const float *xyz,
  * materialised (B,N,N) matrix and calls torch.topk).  dot (b,n,n) = x^T x from a
  * library GEMM, sq (b,n) = |x_i|^2 -> idx (b,n,k): per row i the k largest of
  * fl(fl(-sq[j] + 2 dot[i][j]) - sq[i]), sorted descending (self first); equal
- * to torch.topk's indices wherever the values are distinct.  k <= 100, k <= n. */
+ * to torch.topk's indices wherever the values are distinct.  k <= n; k <= 64 and
+ * n <= 16384: one wave per row streaming the matrix (equal values keep the lower
+ * column first); otherwise the tile kernel, k <= 47 (MVP_EBADSHAPE beyond). */
 int mvp_topk_gram(int b, int n, int k, const float *dot, const float *sq,
                   int *idx, void *stream);
 

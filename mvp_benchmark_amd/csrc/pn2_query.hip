@@ -318,6 +318,139 @@ __global__ __launch_bounds__(kFkRows) void topk_gram_kernel(
 }
 
 
+// The same selection with one WAVE per row (k <= 64): the row is streamed
+// straight from the Gram matrix (no LDS transpose, no workgroup barriers in the
+// scan; VEC = 4: four 16-byte loads per lane = 4 KB per wave in flight), the
+// running top-k lives SORTED in lanes 0..k-1 of two registers, candidates are
+// screened 64 at a time against the k-th key with one ballot, and a survivor
+// is inserted with a one-lane shift (DPP wave_shr) of the entries behind it.
+// After the first few hundred columns a row admits a candidate every ~35
+// columns (k ln(n/k) insertions in total), so the kernel is a stream of the
+// 4 n^2 bytes.  The list is ordered by (key, column): equal keys keep the lower
+// column first whatever the visiting order.
+constexpr int kTwWaves = 4;   // waves (= rows in flight) per workgroup
+constexpr int kTwRows = 8;    // consecutive rows per wave
+
+template <int VEC>
+__global__ __launch_bounds__(kTwWaves * kWave) void topk_gram_wave_kernel(
+    int n, int k, const float *__restrict__ dot, const float *__restrict__ sq, int *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_sq = reinterpret_cast<float *>(smem);  // n rounded up to 4
+  const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+  const int cloud = blockIdx.y;
+  dot += (size_t)cloud * n * n;
+  sq += (size_t)cloud * n;
+  for (int i = t; i < n; i += kTwWaves * kWave) s_sq[i] = sq[i];
+  __syncthreads();
+  const int row0 = (blockIdx.x * kTwWaves + wave) * kTwRows;
+  for (int row = row0; row < min(row0 + kTwRows, n); ++row) {
+    const float *__restrict__ drow = dot + (size_t)row * n;
+    const float sqi = s_sq[row];
+    float lv = __builtin_inff();  // key = -value, ascending in lanes 0..k-1; lanes >= k never shift
+    int li = 0x7FFFFFFF;
+    float tau = __builtin_inff();  // exclusive bound: a candidate must be strictly smaller
+    // Until k entries are in, the list's k-th key is +inf and everything would
+    // pass the screen.  The first block of columns gives a bound for free: the
+    // largest of the 64 per-lane minima has >= 64 >= k keys at or below it.
+    float seed = __builtin_inff();
+    auto insert = [&](float kv, int col) {
+      const bool gt = lane < k && (lv > kv || (lv == kv && li > col));  // entries that move one lane up
+      // wave_shr:1 -- lane l reads lane l-1 (lane 0: 0), one DPP move each
+      const float plv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv), 0x138, 0xF, 0xF, true));
+      const int pli = __builtin_amdgcn_update_dpp(0, li, 0x138, 0xF, 0xF, true);
+      const bool pgt = __builtin_amdgcn_update_dpp(0, gt ? 1 : 0, 0x138, 0xF, 0xF, true) != 0;
+      lv = gt ? (pgt ? plv : kv) : lv;
+      li = gt ? (pgt ? pli : col) : li;
+      tau = __builtin_fminf(seed, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv), k - 1)));
+    };
+    // seed = the k-th smallest of the 64 per-lane minima of the first block (k
+    // keys at or below it): radix select on the order-preserving bit pattern,
+    // one ballot per bit, all bookkeeping scalar.
+    auto seed_from = [&](float lane_min) {
+      const unsigned fb = __float_as_uint(lane_min);
+      const unsigned ord = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
+      unsigned long long cand = ~0ull;
+      unsigned prefix = 0u;
+      int kk = k;
+#pragma unroll
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned long long zeros = cand & ~__ballot((ord >> bit) & 1u);
+        const int cz = __builtin_popcountll(zeros);
+        if (kk <= cz) {
+          cand = zeros;
+        } else {
+          kk -= cz;
+          cand &= ~zeros;
+          prefix |= 1u << bit;
+        }
+      }
+      const unsigned pb = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
+      const float kth = __uint_as_float(pb);
+      // next float above kth (finite): the bound is exclusive
+      const int mb = __float_as_int(kth == 0.f ? 0.f : kth);
+      seed = kth < __builtin_inff() ? __int_as_float(mb >= 0 ? mb + 1 : mb - 1) : kth;
+      tau = seed;
+    };
+    auto screen = [&](float key, int colbase, int colstride) {  // lane's candidate: column colbase + colstride * lane
+      unsigned long long m = __ballot(key < tau);
+      while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const float kv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key), l));
+        if (kv < tau) insert(kv, colbase + colstride * l);  // wave-uniform
+      }
+    };
+    if constexpr (VEC == 4) {  // n % 4 == 0: rows are 16-byte aligned
+      for (int c0 = 0; c0 < n; c0 += 4 * 4 * kWave) {
+        float4 d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + (u * kWave + lane) * 4;
+          d[u] = c < n ? *reinterpret_cast<const float4 *>(drow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float key[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + (u * kWave + lane) * 4;
+          const bool ok = c < n;
+          const float4 q = ok ? *reinterpret_cast<const float4 *>(s_sq + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float inf = __builtin_inff();
+          key[u][0] = ok ? -((-q.x - (-2.f * d[u].x)) - sqi) : inf;
+          key[u][1] = ok ? -((-q.y - (-2.f * d[u].y)) - sqi) : inf;
+          key[u][2] = ok ? -((-q.z - (-2.f * d[u].z)) - sqi) : inf;
+          key[u][3] = ok ? -((-q.w - (-2.f * d[u].w)) - sqi) : inf;
+        }
+        if (c0 == 0) {
+          float lm = key[0][0];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) lm = __builtin_fminf(lm, key[u][v]);
+          seed_from(lm);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) screen(key[u][v], c0 + u * kWave * 4 + v, 4);
+      }
+    } else {
+      for (int c0 = 0; c0 < n; c0 += 4 * kWave) {
+        float key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + u * kWave + lane;
+          const float d = c < n ? drow[c] : 0.f;
+          key[u] = c < n ? -((-s_sq[c] - (-2.f * d)) - sqi) : __builtin_inff();
+        }
+        if (c0 == 0) seed_from(__builtin_fminf(__builtin_fminf(key[0], key[1]), __builtin_fminf(key[2], key[3])));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) screen(key[u], c0 + u * kWave, 1);
+      }
+    }
+    if (lane < k) idx[((size_t)cloud * n + row) * k + lane] = li;
+  }
+}
+
 }  // namespace mvp
 
 using namespace mvp;
@@ -375,6 +508,17 @@ extern "C" int mvp_topk_gram(int b, int n, int k, const float *dot, const float 
   if (b == 0 || n == 0) return MVP_OK;
   if (!dot || !sq || !idx) return MVP_EBADARG;
   if (b > 65535) return MVP_EBADSHAPE;
+  if (k <= kWave && n <= 16384) {
+    dim3 wgrid((n + kTwWaves * kTwRows - 1) / (kTwWaves * kTwRows), b);
+    const size_t wlds = (size_t)((n + 3) & ~3) * 4;
+    if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(dot) & 15) == 0)
+      hipLaunchKernelGGL(topk_gram_wave_kernel<4>, wgrid, dim3(kTwWaves * kWave), wlds, as_stream(stream), n, k, dot,
+                         sq, idx);
+    else
+      hipLaunchKernelGGL(topk_gram_wave_kernel<1>, wgrid, dim3(kTwWaves * kWave), wlds, as_stream(stream), n, k, dot,
+                         sq, idx);
+    return check_launch("mvp_topk_gram");
+  }
   const size_t lds = (size_t)(kFkRows * (kFkCols + 1) + kFkCols) * 4 + (size_t)k * kFkRows * 8;
   if (lds > 64 * 1024) return MVP_EBADSHAPE;
   dim3 grid((n + kFkRows - 1) / kFkRows, b);

@@ -66,7 +66,8 @@ def test_coordinate_knn_goes_through_the_op(oracle):
     assert (gap[differ] < 2e-6).all() and differ.mean() < 1e-3
     # feature-space searches: library GEMM + one scan of the Gram matrix; the
     # same indices as topk on the materialised matrix wherever values differ
-    for C, n, kk in [(24, 700, 16), (48, 1024, 16), (256, 300, 4), (5, 40, 40)]:
+    for C, n, kk in [(24, 700, 16), (48, 1024, 16), (256, 300, 4), (5, 40, 40), (24, 3072, 20), (8, 130, 64),
+                     (8, 130, 70), (16, 257, 1)]:
         feat = dev(rand_clouds(7 + C, 2, C, n))
         got = mu.knn(feat, kk)
         assert got.shape == (2, n, kk) and got.dtype == torch.int64
