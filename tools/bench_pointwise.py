@@ -56,11 +56,21 @@ for key, cnt in sorted(shapes.items(), key=lambda kv: -kv[0][1] * kv[0][2] * kv[
         y = y.view(shp[0], cout, *shp[2:])
         y.backward(y)
     tc, tg = timed(f_conv), timed(f_gemm)
+    t1 = None
+    if len(shp) == 4 and shp[2] == 1:   # (B, C, 1, N) through the 1-d convolution
+        def f_conv1d():
+            y = F.conv1d(x.squeeze(2), w.squeeze(3), b).unsqueeze(2)
+            y.backward(y)
+        t1 = timed(f_conv1d)
     L = 1
     for d in shp[2:]:
         L *= d
     gf = 3 * 2.0 * shp[0] * L * cin * cout / 1e9
     tot_c += tc * cnt; tot_g += tg * cnt
-    print("%s %4d->%4d x%-2d in %-22s contig %d: conv %.3f ms  gemm %.3f ms  (%.1f GFLOP fwd+bwd, gemm %.1f TF/s)" % (
-        kind, cin, cout, cnt, shp, contig, tc, tg, gf, gf / tg), flush=True)
+    print("%s %4d->%4d x%-2d in %-22s contig %d: conv %.3f ms  gemm %.3f ms  (%.1f GFLOP fwd+bwd, gemm %.1f TF/s)%s" % (
+        kind, cin, cout, cnt, shp, contig, tc, tg, gf, gf / tg, "" if t1 is None else "  as conv1d %.3f ms" % t1), flush=True)
+    if t1 is not None:
+        tot_1 = globals().get("tot_1", 0.0) + (t1 - tc) * cnt
+        globals()["tot_1"] = tot_1
 print("%s: all pointwise layers fwd+bwd: conv %.2f ms, gemm %.2f ms" % (name, tot_c, tot_g))
+print("conv2d (B,C,1,N) layers routed through conv1d: %+.2f ms in total" % globals().get("tot_1", 0.0))
