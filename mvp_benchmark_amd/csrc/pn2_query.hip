@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kTwWaves * kWave) void topk_gram_wave_kernel(
     const float *__restrict__ drow = dot + (size_t)row * n;
     const float sqi = s_sq[row];
     float lv = __builtin_inff();  // key = -value, ascending in lanes 0..k-1; lanes >= k never shift
-    int li = 0x7FFFFFFF;
+    int li = 0;  // slots never filled (fewer than k finite keys: NaN input) point at column 0
     float tau = __builtin_inff();  // exclusive bound: a candidate must be strictly smaller
     // Until k entries are in, the list's k-th key is +inf and everything would
     // pass the screen.  The first block of columns gives a bound for free: the
