@@ -14,7 +14,7 @@ down, three_nn + three_interpolate on the way up.
 import torch
 import torch.nn as nn
 
-from model_utils import edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling
+from model_utils import aggregate_shared, edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling
 from mm3d_pn2 import three_interpolate
 from models._common import dense, pointwise2d
 
@@ -46,20 +46,16 @@ class SA_module(nn.Module):
         # The reference gathers the k neighbours' C-channel features first and maps
         # the (B, C, k, N) tensor with conv2 / conv3.  A per-point linear map commutes
         # with the gather, so map the N points once (k times fewer multiply-adds, no
-        # (B, C, k, N) intermediate) and gather the r + mid mapped channels in one
-        # grouping call; same parameters, same result up to fp32 summation order.
+        # (B, C, k, N) intermediate) and gather the r and the mid mapped channels;
+        # same parameters, same result up to fp32 summation order.
         query = self.conv1(act)                          # (B, r, 1, N)
-        r = query.size(1)
-        mapped = torch.cat([self.conv2(act), self.conv3(act)], 1)            # (B, r + mid, 1, N)
-        nbr = get_edge_features(mapped, idx)             # (B, r + mid, k, N)
-        keys = nbr[:, :r].reshape(batch_size, -1, 1, num_points)             # (B, r*k, 1, N), channel = r_i*k + k_i
-        values = nbr[:, r:]                              # (B, mid, k, N)
+        keys = get_edge_features(self.conv2(act), idx).reshape(batch_size, -1, 1, num_points)   # (B, r*k, 1, N), channel = r_i*k + k_i
+        values = get_edge_features(self.conv3(act), idx)                     # (B, mid, k, N)
 
         w = self.conv_w(torch.cat([query, keys], 1))     # (B, k*mid/share, 1, N)
-        # weights are shared by the `share_planes` channel groups: broadcast instead of repeat
-        w = w.view(batch_size, 1, -1, self.k, num_points)
-        grouped = values.reshape(batch_size, self.share_planes, -1, self.k, num_points)
-        out = (w * grouped).sum(dim=3).view(batch_size, -1, 1, num_points)
+        # weights are shared by the `share_planes` channel groups: one fused pass, no repeat / product tensor
+        out = aggregate_shared(w.view(batch_size, -1, self.k, num_points), values, self.share_planes)
+        out = out.view(batch_size, -1, 1, num_points)
         out = self.conv_out(self.activation_fn(out))     # (B, C_out, 1, N)
         return [out + x, idx]
 

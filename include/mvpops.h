@@ -40,7 +40,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 3
+#define MVP_ABI_VERSION 4
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -265,6 +265,23 @@ int mvp_three_interpolate_grad_ws(int b, int c, int n, int m,
                                   const float *weight, float *grad_points,
                                   void *scratch, long long scratch_bytes,
                                   void *stream);
+
+/* Shared-weight neighbourhood aggregation of VRCNet's point self-attention (no
+ * native counterpart in the reference: completion/models/vrcnet.py:52-55
+ * materialises w.repeat(1, share, 1, 1), the product and its sum over k).
+ * w (b,cw,k,n), v (b,share*cw,k,n) -> out (b,share*cw,n):
+ *   out[b, s*cw+m, n] = sum_k w[b,m,k,n] * v[b, s*cw+m, k, n]   (k ascending).
+ * share in {1,2,4,8,16} (MVP_EBADSHAPE otherwise). */
+int mvp_share_weighted_sum(int b, int share, int cw, int k, int n,
+                           const float *w, const float *v, float *out,
+                           void *stream);
+/* Its gradients in one pass: grad_v (b,share*cw,k,n) = w * grad_out (broadcast
+ * over k), grad_w (b,cw,k,n) = sum_s grad_out[b,s*cw+m,n] * v[b,s*cw+m,k,n];
+ * both overwritten. */
+int mvp_share_weighted_sum_grad(int b, int share, int cw, int k, int n,
+                                const float *w, const float *v,
+                                const float *grad_out, float *grad_w,
+                                float *grad_v, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,11 +40,13 @@ SIGNATURES = {
     "mvp_gather_points_grad_ws": "iiiippppq",
     "mvp_group_points_grad_ws": "iiiiippppq",
     "mvp_three_interpolate_grad_ws": "iiiipppppq",
+    "mvp_share_weighted_sum": "iiiiippp",
+    "mvp_share_weighted_sum_grad": "iiiiippppp",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 3   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 4   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 _lib = None
 

@@ -248,7 +248,42 @@ def gram_topk(dot, sq, k):
     return idx
 
 
+class ShareWeightedSum(Function):
+    """out[b, s*Cw + m, n] = sum_k w[b, m, k, n] * v[b, s*Cw + m, k, n]:
+    (w (B,Cw,k,N), v (B,share*Cw,k,N)) -> (B, share*Cw, N), differentiable in
+    both.  The neighbourhood aggregation of VRCNet's SA_module (vrcnet.py:52-55:
+    `w.repeat(1, share, 1, 1)`, product, sum over k) as one streaming pass each
+    way.  Not part of the reference's operator set."""
+
+    SHARES = (1, 2, 4, 8, 16)
+
+    @staticmethod
+    def forward(ctx, w, v):
+        _need_contiguous(w, v)
+        B, Cw, k, N = w.shape
+        C = v.shape[1]
+        share = C // max(Cw, 1)
+        assert v.shape == (B, share * Cw, k, N) and share in ShareWeightedSum.SHARES
+        out = _new(v, B, C, N)
+        call("mvp_share_weighted_sum", v.device, B, share, Cw, k, N, w, v, out)
+        ctx.save_for_backward(w, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        w, v = ctx.saved_tensors
+        B, Cw, k, N = w.shape
+        share = v.shape[1] // max(Cw, 1)
+        grad_w, grad_v = torch.empty_like(w), torch.empty_like(v)
+        if k == 0:
+            return grad_w, grad_v
+        call("mvp_share_weighted_sum_grad", v.device, B, share, Cw, k, N, w, v, grad_out.data.contiguous(),
+             grad_w, grad_v)
+        return grad_w, grad_v
+
+
 furthest_point_sample = FurthestPointSampling.apply
+share_weighted_sum = ShareWeightedSum.apply
 furthest_point_sample_with_dist = FurthestPointSamplingWithDist.apply
 ball_query = BallQuery.apply
 knn = KNN.apply

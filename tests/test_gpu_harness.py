@@ -281,3 +281,30 @@ def test_ecg_vrcnet_train_val_test_steps(name):
     assert t['result'].shape == (2, 2048, 3)
     for k in ('cd_p', 'cd_t', 'f1', 'emd'):
         assert r[k].shape == (2,) and torch.isfinite(r[k]).all(), k
+
+
+@pytest.mark.parametrize("B,share,Cw,k,N", [(2, 8, 2, 16, 3072), (3, 8, 16, 10, 384), (1, 4, 3, 5, 77), (2, 1, 5, 3, 300),
+                                            (2, 16, 1, 20, 257), (1, 2, 7, 1, 64)])
+def test_share_weighted_sum_matches_torch(B, share, Cw, k, N):
+    """The fused neighbourhood aggregation of SA_module against the plain
+    PyTorch fp32 formulation of vrcnet.py:52-55 (repeat, product, sum over k):
+    forward and both gradients, 1e-5 relative (the summation order over k differs
+    from torch's reduction)."""
+    import model_utils as mu
+    from mvp_benchmark_amd.mm3d_pn2.functional import share_weighted_sum
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    w = torch.randn(B, Cw, k, N, generator=g).to(DEV).requires_grad_()
+    v = torch.randn(B, share * Cw, k, N, generator=g).to(DEV).requires_grad_()
+    go = torch.randn(B, share * Cw, N, generator=g).to(DEV)
+    out = share_weighted_sum(w, v)
+    ref = (w.repeat(1, share, 1, 1) * v).sum(dim=2)
+    assert out.shape == ref.shape
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    gw, gv = torch.autograd.grad(out, (w, v), go)
+    rw, rv = torch.autograd.grad(ref, (w, v), go)
+    assert torch.allclose(gv, rv, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gw, rw, rtol=1e-5, atol=1e-5)
+    # the models' entry point: op layer on the GPU, the broadcast formulation elsewhere
+    got = mu.aggregate_shared(w, v, share)
+    cpu = mu.aggregate_shared(w.detach().cpu().double(), v.detach().cpu().double(), share)
+    assert torch.allclose(got.detach().cpu().double(), cpu, rtol=1e-5, atol=1e-5)
