@@ -478,6 +478,60 @@ __global__ __launch_bounds__(256) void nm_distance_grad_kernel(
   atomicAdd(gc + 2, -gz);
 }
 
+// The same gradient for training-size clouds (n + m <= 8192 points): one
+// workgroup per cloud accumulates both gradient arrays in LDS -- a point's own
+// term with a plain add, the scattered term with ds_add_f32 -- and adds the
+// result to the (zero-filled) outputs with coalesced, non-atomic writes.  Six
+// global float atomics per point (each a full L2 read-modify-write; nearest
+// neighbours collide) become six LDS operations: (64, 2048, 2048) 0.19 ->
+// 0.02 ms.
+constexpr int kCgThreads = 1024;
+constexpr int kCgMaxPoints = 8192;  // (n + m) * 12 B of LDS
+
+__global__ __launch_bounds__(kCgThreads) void nm_distance_grad_lds_kernel(
+    int n1, int n2, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ graddist1, const float *__restrict__ graddist2, const int *__restrict__ idx1,
+    const int *__restrict__ idx2, float *__restrict__ gradxyz1, float *__restrict__ gradxyz2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *acc1 = reinterpret_cast<float *>(smem);  // n1 * 3
+  float *acc2 = acc1 + (size_t)n1 * 3;            // n2 * 3
+  const int t = threadIdx.x;
+  const int cloud = blockIdx.x;
+  xyz1 += (size_t)cloud * n1 * 3;
+  xyz2 += (size_t)cloud * n2 * 3;
+  for (int i = t; i < (n1 + n2) * 3; i += kCgThreads) acc1[i] = 0.f;
+  __syncthreads();
+  for (int dir = 0; dir < 2; ++dir) {
+    const int n = dir == 0 ? n1 : n2;
+    const float *pa = dir == 0 ? xyz1 : xyz2;
+    const float *pc = dir == 0 ? xyz2 : xyz1;
+    const float *gd = (dir == 0 ? graddist1 : graddist2) + (size_t)cloud * n;
+    const int *id = (dir == 0 ? idx1 : idx2) + (size_t)cloud * n;
+    float *own = dir == 0 ? acc1 : acc2;
+    float *oth = dir == 0 ? acc2 : acc1;
+    for (int j = t; j < n; j += kCgThreads) {
+      const int j2 = id[j];
+      const float g = gd[j] * 2;
+      const float gx = g * (pa[j * 3 + 0] - pc[j2 * 3 + 0]);
+      const float gy = g * (pa[j * 3 + 1] - pc[j2 * 3 + 1]);
+      const float gz = g * (pa[j * 3 + 2] - pc[j2 * 3 + 2]);
+      // `own[j]` is also a scatter target of the other direction, which runs
+      // in the other pass of this loop (separated by the barrier below)
+      own[j * 3 + 0] += gx;
+      own[j * 3 + 1] += gy;
+      own[j * 3 + 2] += gz;
+      atomicAdd(&oth[j2 * 3 + 0], -gx);
+      atomicAdd(&oth[j2 * 3 + 1], -gy);
+      atomicAdd(&oth[j2 * 3 + 2], -gz);
+    }
+    __syncthreads();
+  }
+  float *o1 = gradxyz1 + (size_t)cloud * n1 * 3;
+  float *o2 = gradxyz2 + (size_t)cloud * n2 * 3;
+  for (int i = t; i < n1 * 3; i += kCgThreads) o1[i] += acc1[i];
+  for (int i = t; i < n2 * 3; i += kCgThreads) o2[i] += acc2[i];
+}
+
 }  // namespace mvp
 
 using namespace mvp;
@@ -554,6 +608,11 @@ extern "C" int mvp_chamfer_backward(int b, int n, int m, const float *xyz1,
       !idx1 || !idx2)
     return MVP_EBADARG;
   if (b > 65535) return MVP_EBADSHAPE;
+  if (n + m <= kCgMaxPoints) {
+    hipLaunchKernelGGL(nm_distance_grad_lds_kernel, dim3(b), dim3(kCgThreads), (size_t)(n + m) * 12, as_stream(stream),
+                       n, m, xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2);
+    return check_launch("mvp_chamfer_backward");
+  }
   const int big = n > m ? n : m;
   dim3 grid((big + 255) / 256, b, 2);
   hipLaunchKernelGGL(nm_distance_grad_kernel, grid, dim3(256), 0,

@@ -113,16 +113,20 @@ def test_chamfer_exact_ties(oracle):
     _cd_check(oracle, a, b)
 
 
-def test_chamfer_backward(oracle):
+@pytest.mark.parametrize("bsz,n,m", [(4, 700, 300), (3, 2048, 2048), (2, 1, 8191), (2, 6000, 5000), (2, 4097, 4096)])
+def test_chamfer_backward(oracle, bsz, n, m):
+    """n + m <= 8192: gradients accumulated in LDS per cloud; above: global
+    float atomics.  The (1, 8191) case scatters every point of one side onto a
+    single point of the other."""
     from mvp_benchmark_amd.metrics import cd
-    a, b = rand_clouds(1, 4, 700, 3), rand_clouds(2, 4, 300, 3)
+    a, b = rand_clouds(1, bsz, n, 3), rand_clouds(2, bsz, m, 3)
     ta, tb = dev(a).requires_grad_(), dev(b).requires_grad_()
     d1, d2, i1, i2 = cd()(ta, tb)
-    g1, g2 = rand_clouds(3, 4, 700), rand_clouds(4, 4, 300)
+    g1, g2 = rand_clouds(3, bsz, n), rand_clouds(4, bsz, m)
     (d1 * dev(g1)).sum().add((d2 * dev(g2)).sum()).backward()
     gx1, gx2 = oracle.chamfer_backward(a, b, g1, g2, i1.cpu().numpy(), i2.cpu().numpy())
-    np.testing.assert_allclose(ta.grad.cpu().numpy(), gx1, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(tb.grad.cpu().numpy(), gx2, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), gx1, rtol=1e-5, atol=1e-6 * max(1, m // 64))
+    np.testing.assert_allclose(tb.grad.cpu().numpy(), gx2, rtol=1e-5, atol=1e-6 * max(1, n // 64))
 
 
 def test_chamfer_full_size_properties():
