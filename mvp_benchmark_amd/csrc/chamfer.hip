@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void nm_distance_grad_kernel(
 // result to the (zero-filled) outputs with coalesced, non-atomic writes.  Six
 // global float atomics per point (each a full L2 read-modify-write; nearest
 // neighbours collide) become six LDS operations: (64, 2048, 2048) 0.19 ->
-// 0.02 ms.
+// 0.03 ms.
 constexpr int kCgThreads = 1024;
 constexpr int kCgMaxPoints = 8192;  // (n + m) * 12 B of LDS
 

@@ -67,6 +67,17 @@ if which in ("all", "grad"):
         go = torch.rand_like(out)
         ms = timeit(lambda: torch.autograd.grad(out, f, go, retain_graph=True))
         print("three_interpolate grad (%d,%d,%d)<-%d: %.3f ms  %.1f GB/s of grad_out read" % (b, c, m, n, ms, 4.0 * b * c * n / ms / 1e6), flush=True)
+if which in ("all", "grad", "cdgrad"):
+    from mvp_benchmark_amd import _lib
+    for (b, n, m) in [(64, 2048, 2048), (64, 2048, 3072), (64, 8192, 8192)]:
+        x1, x2 = R(b, n, 3), R(b, m, 3)
+        d1 = torch.empty(b, n, device=dev); d2 = torch.empty(b, m, device=dev)
+        i1 = torch.empty(b, n, dtype=torch.int32, device=dev); i2 = torch.empty(b, m, dtype=torch.int32, device=dev)
+        _lib.call("mvp_chamfer_forward", dev, b, n, m, x1, x2, d1, d2, i1, i2)
+        g1, g2 = R(b, n), R(b, m)
+        gx1, gx2 = torch.zeros(b, n, 3, device=dev), torch.zeros(b, m, 3, device=dev)
+        ms = timeit(lambda: _lib.call("mvp_chamfer_backward", dev, b, n, m, x1, x2, gx1, gx2, g1, g2, i1, i2))
+        print("cd backward (%d,%d)x(%d): %.3f ms" % (b, n, m, ms), flush=True)
 if which in ("all", "topk"):
     from mvp_benchmark_amd.mm3d_pn2.functional import gram_topk
     for (b, c, n, k) in [(32, 24, 3072, 16), (32, 48, 1024, 16), (32, 48, 256, 16)]:
