@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from model_utils import edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling
 from mm3d_pn2 import three_interpolate
 from models._common import dense, pointwise1d, pointwise2d
+from mvp_benchmark_amd.pointwise import pointwise_conv
 
 
 class Stack_conv(nn.Module):
@@ -71,7 +72,7 @@ class Dense_conv(nn.Module):
         w_ctr, w_nbr = w[:, :c], w[:, c:]
         bias = self.first_conv.bias
         # W [ctr; nbr - ctr] + b = (W_ctr - W_nbr) ctr + b  +  W_nbr nbr
-        both = F.conv1d(x, torch.cat((w_ctr - w_nbr, w_nbr), 0).unsqueeze(2), torch.cat((bias, torch.zeros_like(bias))))
+        both = pointwise_conv(x, torch.cat((w_ctr - w_nbr, w_nbr), 0).unsqueeze(2), torch.cat((bias, torch.zeros_like(bias))))
         # per-edge tensors are kept (B, ., k, N): the max over the k neighbours then reduces a strided
         # dimension with N contiguous instead of 16-element rows (the layers are 1x1, the layout is free)
         edge = F.relu(both[:, :g].unsqueeze(2) + get_edge_features(both[:, g:], idx))   # (B, g, k, N)
@@ -82,7 +83,8 @@ class Dense_conv(nn.Module):
             conv = layer.model.conv
             w = conv.weight.flatten(1)               # input channels: [edge (g), centre (C), y_1 .. y_{i}]
             w_edge = torch.cat((w[:, :g], w[:, g + c:]), 1)
-            y = F.conv2d(stack, w_edge[:, :, None, None]) + F.conv1d(x, w[:, g:g + c].unsqueeze(2), conv.bias).unsqueeze(2)
+            y = pointwise_conv(stack, w_edge[:, :, None, None].contiguous()) \
+                + pointwise_conv(x, w[:, g:g + c].unsqueeze(2).contiguous(), conv.bias).unsqueeze(2)
             if hasattr(layer.model, 'act'):
                 y = layer.model.act(y)
             outs.append(y.max(dim=2)[0])

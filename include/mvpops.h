@@ -40,7 +40,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 4
+#define MVP_ABI_VERSION 5
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -282,6 +282,21 @@ int mvp_share_weighted_sum_grad(int b, int share, int cw, int k, int n,
                                 const float *w, const float *v,
                                 const float *grad_out, float *grad_w,
                                 float *grad_v, void *stream);
+
+/* Weight (and bias) gradient of a per-point / per-edge linear map -- a 1x1
+ * convolution y = W x + bias on x (b,cin,len), len = N or k*N positions per
+ * cloud -- for few output channels (the models' Conv1d/Conv2d(kernel_size=1)
+ * layers of completion/models; the reference leaves them to cuDNN):
+ *   gw[co][ci] = sum_{b,l} gy[b][co][l] * x[b][ci][l]   (overwritten)
+ *   gb[co]     = sum_{b,l} gy[b][co][l]                 (overwritten; gb may be NULL)
+ * cout <= 64, len % 4 == 0, x and gy 16-byte aligned.  scratch:
+ * mvp_pointwise_wgrad_scratch_bytes(b, cin, cout, len) bytes of per-workgroup
+ * partial sums (0 = shape not covered), added up in a fixed order.  Forward and
+ * data gradient are not provided (the library convolution handles them well). */
+long long mvp_pointwise_wgrad_scratch_bytes(int b, int cin, int cout, int len);
+int mvp_pointwise_wgrad(int b, int cin, int cout, int len, const float *x,
+                        const float *gy, float *gw, float *gb, void *scratch,
+                        long long scratch_bytes, void *stream);
 
 #ifdef __cplusplus
 }

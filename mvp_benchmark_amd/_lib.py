@@ -42,11 +42,12 @@ SIGNATURES = {
     "mvp_three_interpolate_grad_ws": "iiiipppppq",
     "mvp_share_weighted_sum": "iiiiippp",
     "mvp_share_weighted_sum_grad": "iiiiippppp",
+    "mvp_pointwise_wgrad": "iiiipppppq",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 4   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 5   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 _lib = None
 
@@ -77,6 +78,8 @@ def load():
     lib.mvp_chamfer_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.mvp_scatter_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_scatter_scratch_bytes.argtypes = [ctypes.c_int] * 4
+    lib.mvp_pointwise_wgrad_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_pointwise_wgrad_scratch_bytes.argtypes = [ctypes.c_int] * 4
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
@@ -138,8 +141,13 @@ def scatter_scratch_bytes(b, n_dst, m_src, r):
     return int(load().mvp_scatter_scratch_bytes(int(b), int(n_dst), int(m_src), int(r)))
 
 
+def pointwise_wgrad_scratch_bytes(b, cin, cout, length):
+    """Scratch of mvp_pointwise_wgrad (0: shape not covered)."""
+    return int(load().mvp_pointwise_wgrad_scratch_bytes(int(b), int(cin), int(cout), int(length)))
+
+
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
     return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes",
-            "mvp_scatter_scratch_bytes"] \
+            "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes"] \
         + list(SIGNATURES)

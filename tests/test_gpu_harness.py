@@ -308,3 +308,52 @@ def test_share_weighted_sum_matches_torch(B, share, Cw, k, N):
     got = mu.aggregate_shared(w, v, share)
     cpu = mu.aggregate_shared(w.detach().cpu().double(), v.detach().cpu().double(), share)
     assert torch.allclose(got.detach().cpu().double(), cpu, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,cout,bias", [((32, 48, 16, 1024), 24, True), ((4, 24, 16, 3072), 24, False),
+                                             ((8, 256, 1, 768), 16, True), ((8, 64, 3072), 4, True),
+                                             ((3, 16, 1, 300), 64, True), ((2, 512, 1, 384), 32, False),
+                                             ((2, 130, 5, 44), 33, True), ((1, 1, 4), 1, True), ((2, 7, 1028), 5, True)])
+def test_pointwise_conv_weight_gradient(shape, cout, bias):
+    """Per-point / per-edge linear maps: same output as the library convolution
+    (it IS the library convolution), weight and bias gradients from
+    mvp_pointwise_wgrad against PyTorch's fp32 convolution_backward at 1e-4 of
+    the gradient's scale (different summation order over ~1e5..1e6 terms), input
+    gradient identical."""
+    import torch.nn.functional as F
+    from mvp_benchmark_amd import _lib
+    from mvp_benchmark_amd.pointwise import MAX_CIN, pointwise_conv, _PointwiseConv
+    g = torch.Generator().manual_seed(shape[1] * 131 + cout)
+    x = torch.randn(*shape, generator=g).to(DEV).requires_grad_()
+    w = torch.randn(cout, shape[1], *([1] * (len(shape) - 2)), generator=g).to(DEV).requires_grad_()
+    b = torch.randn(cout, generator=g).to(DEV).requires_grad_() if bias else None
+    conv = F.conv1d if len(shape) == 3 else F.conv2d
+    ref = conv(x, w, b)
+    go = torch.randn_like(ref)
+    params = (x, w) + ((b,) if bias else ())
+    want = torch.autograd.grad(ref, params, go)
+    close = lambda a_, b_: torch.allclose(a_, b_, rtol=1e-4, atol=1e-4 * float(b_.abs().max()))
+    # the kernel itself, every shape (the models only route layers with <= MAX_CIN input channels to it)
+    B, cin, length = shape[0], shape[1], x[0, 0].numel()
+    nbytes = _lib.pointwise_wgrad_scratch_bytes(B, cin, cout, length)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    gw, gb = torch.full_like(w, float("nan")), torch.full((cout,), float("nan"), device=DEV)
+    _lib.call("mvp_pointwise_wgrad", DEV, B, cin, cout, length, x.detach(), go, gw, gb if bias else None, ws, nbytes)
+    assert close(gw, want[1]) and (not bias or close(gb, want[2]))
+    gw2 = torch.empty_like(w)
+    _lib.call("mvp_pointwise_wgrad", DEV, B, cin, cout, length, x.detach(), go, gw2, None, ws, nbytes)
+    assert torch.equal(gw, gw2)                                          # fixed summation order: reproducible
+    # the autograd route
+    y = pointwise_conv(x, w, b)
+    assert torch.equal(y, ref)
+    assert isinstance(y.grad_fn, _PointwiseConv._backward_cls) == (cin <= MAX_CIN)
+    got = torch.autograd.grad(y, params, go)
+    assert torch.equal(got[0], want[0])
+    for a_, b_ in zip(got[1:], want[1:]):
+        assert close(a_, b_)
+    # a length that is not a multiple of 4 is outside the kernel's cover: library gradient
+    if shape[-1] > 1:
+        x3 = x.detach()[..., :-1].contiguous().requires_grad_()
+        y3 = pointwise_conv(x3, w, b)
+        assert (x3[0, 0].numel() % 4 == 0) or not isinstance(y3.grad_fn, _PointwiseConv._backward_cls)
