@@ -327,10 +327,31 @@ class EF_expansion(nn.Module):
         self.conv3 = nn.Conv2d(output_size, output_size, 1)
 
     def forward(self, x):
-        batch_size, _, num_points = x.size()
-        edge_in = get_graph_feature(x, self.k, minus_center=False).permute(0, 1, 3, 2).contiguous()  # B C K N
-        edge = F.relu(torch.cat((self.conv1(edge_in), edge_in), 1))
-        edge = F.relu(self.conv2(edge))                                                            # B C K N
+        """x (B, C, N) -> (B, output_size, N * step_ratio).
+
+        The reference materialises edge_in = [centre, neighbour] (B, 2C, k, N), maps
+        it with conv1, concatenates and maps the (2C + out)-channel tensor with
+        conv2.  Both layers are per-edge LINEAR maps and ReLU acts element-wise, so
+        it commutes with the gather: the centre columns of W1 / W2 act on (B, C, N)
+        tensors and are broadcast over k, the neighbour columns are applied to x
+        (to relu(x)) before the gather, and only conv1's output stays per-edge
+        input of conv2 (out instead of 2C + out channels).  Same parameters, same
+        function up to fp32 summation order."""
+        batch_size, c, num_points = x.size()
+        out = self.output_size
+        idx = knn(x, self.k)                                                   # (B, N, k)
+        w1 = self.conv1.weight.flatten(1)                                      # (out, 2C) = [centre | neighbour]
+        both1 = F.conv1d(x, torch.cat((w1[:, :c], w1[:, c:]), 0).unsqueeze(2),
+                         torch.cat((self.conv1.bias, torch.zeros_like(self.conv1.bias))))
+        h = both1[:, :out].unsqueeze(2) + get_edge_features(both1[:, out:], idx)          # conv1(edge_in): (B, out, k, N)
+        w2 = self.conv2.weight.flatten(1)                                      # (out*step, out + 2C) = [h | centre | neighbour]
+        rx = F.relu(x)                                                         # relu(gather(x)) = gather(relu(x))
+        n2 = w2.size(0)
+        both2 = F.conv1d(rx, torch.cat((w2[:, out:out + c], w2[:, out + c:]), 0).unsqueeze(2),
+                         torch.cat((self.conv2.bias, torch.zeros_like(self.conv2.bias))))
+        edge = F.conv2d(F.relu(h), w2[:, :out, None, None]) + both2[:, :n2].unsqueeze(2) \
+            + get_edge_features(both2[:, n2:], idx)
+        edge = F.relu(edge)                                                                        # B C K N
         edge = edge.permute(0, 2, 3, 1).contiguous() \
             .view(batch_size, self.k, num_points * self.step_ratio, self.output_size) \
             .permute(0, 3, 1, 2)

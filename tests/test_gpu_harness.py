@@ -357,3 +357,26 @@ def test_pointwise_conv_weight_gradient(shape, cout, bias):
         x3 = x.detach()[..., :-1].contiguous().requires_grad_()
         y3 = pointwise_conv(x3, w, b)
         assert (x3[0, 0].numel() % 4 == 0) or not isinstance(y3.grad_fn, _PointwiseConv._backward_cls)
+
+
+def test_ef_expansion_on_the_op_layer():
+    """EF_expansion (ECG / VRCNet up-sampling heads, scale >= 2) on the GPU:
+    knn through the Gram top-k, gathers through the grouping operator; output
+    and gradients against the reference's edge-tensor formulation in fp32."""
+    import torch.nn.functional as F
+    import model_utils as mu
+    torch.manual_seed(2)
+    B, C, N, k, out, step = 2, 64, 512, 4, 16, 2
+    ef = mu.EF_expansion(C, output_size=out, step_ratio=step, k=k).to(DEV)
+    x = torch.randn(B, C, N, device=DEV, requires_grad=True)
+    got = ef(x)
+    edge_in = mu.get_graph_feature(x, k, minus_center=False).permute(0, 1, 3, 2).contiguous()
+    edge = F.relu(torch.cat((ef.conv1(edge_in), edge_in), 1))
+    edge = F.relu(ef.conv2(edge))
+    edge = edge.permute(0, 2, 3, 1).contiguous().view(B, k, N * step, out).permute(0, 3, 1, 2)
+    ref = ef.conv3(edge).max(dim=2)[0]
+    assert got.shape == ref.shape == (B, out, N * step)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4)
+    params = [x] + list(ef.parameters())
+    for a, b in zip(torch.autograd.grad(got.square().sum(), params), torch.autograd.grad(ref.square().sum(), params)):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max()))

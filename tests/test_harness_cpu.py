@@ -292,3 +292,31 @@ def test_dense_conv_equals_edge_tensor_formulation(dense_n):
     p2 = torch.autograd.grad(ref.square().sum(), list(dc.parameters()))
     for a, b in zip(p1, p2):
         assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("step", [1, 3])
+def test_ef_expansion_equals_edge_tensor_formulation(step):
+    """EF_expansion applies the centre / neighbour columns of conv1 and conv2
+    per point and gathers the mapped channels; the reference
+    (model_utils.py:26-55) maps the materialised (B, 2C, k, N) edge tensor.
+    Same parameters, same function (outputs and all gradients, float64)."""
+    import torch.nn.functional as F
+    from model_utils import EF_expansion, get_graph_feature
+    torch.manual_seed(11)
+    B, C, N, k, out = 2, 10, 37, 4, 6
+    ef = EF_expansion(C, output_size=out, step_ratio=step, k=k).double()
+    x = torch.randn(B, C, N, dtype=torch.float64, requires_grad=True)
+    got = ef(x)
+    assert got.shape == (B, out, N * step)
+
+    edge_in = get_graph_feature(x, k, minus_center=False).permute(0, 1, 3, 2).contiguous()
+    edge = F.relu(torch.cat((ef.conv1(edge_in), edge_in), 1))
+    edge = F.relu(ef.conv2(edge))
+    edge = edge.permute(0, 2, 3, 1).contiguous().view(B, k, N * step, out).permute(0, 3, 1, 2)
+    ref = ef.conv3(edge).max(dim=2)[0]
+    assert torch.allclose(got, ref, rtol=1e-10, atol=1e-10)
+    params = [x] + list(ef.parameters())
+    g1 = torch.autograd.grad(got.square().sum(), params)
+    g2 = torch.autograd.grad(ref.square().sum(), params)
+    for a, b in zip(g1, g2):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
