@@ -255,11 +255,12 @@ def get_uniform_loss(pcd, percentages=[0.004, 0.006, 0.008, 0.010, 0.012], radiu
     npoint = int(N * 0.05)
     pcd_t = pcd.transpose(1, 2).contiguous()
     loss = 0
+    # the seeds do not depend on the percentage (the reference re-runs the same FPS in every iteration)
+    new_xyz = gather_points(pcd_t, furthest_point_sample(pcd, npoint)).transpose(1, 2).contiguous()
     for p in percentages:
         nsample = int(N * p)
         r = math.sqrt(p * radius)
         disk_area = math.pi * (radius ** 2) * p / nsample
-        new_xyz = gather_points(pcd_t, furthest_point_sample(pcd, npoint)).transpose(1, 2).contiguous()
         idx = ball_query(0, r, nsample, pcd, new_xyz)
         expect_len = math.sqrt(disk_area)
 
