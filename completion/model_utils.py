@@ -267,8 +267,16 @@ def get_uniform_loss(pcd, percentages=[0.004, 0.006, 0.008, 0.010, 0.012], radiu
         grouped_pcd = grouping_operation(pcd_t, idx)
         grouped_pcd = grouped_pcd.permute(0, 2, 3, 1).contiguous().view(-1, nsample, 3)
 
-        var, _ = knn_point(2, grouped_pcd, grouped_pcd)
-        uniform_dis = -var[:, :, 1:]
+        # knn_point(2, g, g)[0][:, :, 1:] -- the second largest entry of every row of the negative
+        # squared-distance matrix, multiplicity counted -- as two max reductions (mask the first arg-max)
+        # instead of a radix top-k over rows of <= 100 elements
+        inner = -2 * torch.matmul(grouped_pcd, grouped_pcd.transpose(2, 1))
+        sq = (grouped_pcd * grouped_pcd).sum(dim=2)
+        pairwise = -sq.unsqueeze(2) - inner - sq.unsqueeze(1)
+        first = pairwise.argmax(dim=-1, keepdim=True)
+        second = pairwise.scatter(-1, first, float('-inf')).max(dim=-1, keepdim=True)[0] if nsample > 1 \
+            else pairwise.new_empty(pairwise.shape[:2] + (0,))
+        uniform_dis = -second
         uniform_dis = torch.sqrt(torch.abs(uniform_dis + 1e-8)).mean(dim=-1)
         uniform_dis = (uniform_dis - expect_len) ** 2 / (expect_len + 1e-8)
         loss = loss + uniform_dis.mean() * math.pow(p * 100, 2)

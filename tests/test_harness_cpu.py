@@ -320,3 +320,22 @@ def test_ef_expansion_equals_edge_tensor_formulation(step):
     g2 = torch.autograd.grad(ref.square().sum(), params)
     for a, b in zip(g1, g2):
         assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
+def test_uniform_loss_second_neighbour_equals_topk():
+    """get_uniform_loss takes the second largest entry per row of the negative
+    distance matrix with two max reductions; the reference calls
+    knn_point(2, g, g) (model_utils.py:201-227, 250-259).  Same values, duplicates
+    (ball_query pads with the first hit) included."""
+    from model_utils import knn_point
+    torch.manual_seed(4)
+    g = torch.rand(50, 12, 3)
+    g[:, 7:] = g[:, :1]                      # padded slots repeat the first point
+    g[3, :] = g[3, :1]                       # a ball with a single distinct point
+    want = knn_point(2, g, g)[0][:, :, 1:]
+    inner = -2 * torch.matmul(g, g.transpose(2, 1))
+    sq = (g * g).sum(dim=2)
+    pairwise = -sq.unsqueeze(2) - inner - sq.unsqueeze(1)
+    first = pairwise.argmax(dim=-1, keepdim=True)
+    got = pairwise.scatter(-1, first, float('-inf')).max(dim=-1, keepdim=True)[0]
+    assert torch.equal(got, want)
