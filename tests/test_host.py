@@ -47,6 +47,41 @@ def test_argument_guards_need_no_gpu():
     assert lib.mvp_gather_points(0, 3, 8, 8, null, null, null, null) == 0
 
 
+def test_guards_and_scratch_sizes_of_the_widened_entry_points():
+    """Host logic of the entry points beyond the reference's operator set: shape
+    guards, scratch formulas, no launch."""
+    from mvp_benchmark_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    # transposed scatter gradients: chunk 1536 up to 2048 destinations, 3072 above; not covered beyond 8192
+    assert _lib.scatter_scratch_bytes(2, 1024, 3000, 1) == 2 * 2 * ((1024 + 1) * 4 + 1536 * 4)
+    assert _lib.scatter_scratch_bytes(1, 3072, 49152, 1) == 16 * ((3072 + 1) * 4 + 3072 * 4)
+    assert _lib.scatter_scratch_bytes(1, 1024, 3072, 3) == 2 * ((1024 + 1) * 4 + 1536 * 3 * 8)
+    assert _lib.scatter_scratch_bytes(1, 8193, 100, 1) == 0 and _lib.scatter_scratch_bytes(1, 100, 100, 2) == 0
+    # ... and the _ws entry points fall back to the plain ones (which accept the empty batch)
+    assert lib.mvp_gather_points_grad_ws(0, 3, 8, 8, null, null, null, null, 0, null) == 0
+    assert lib.mvp_three_interpolate_grad_ws(1, 3, 8, 0, null, null, null, null, null, 0, null) == -1    # m == 0
+    # Gram top-k
+    assert lib.mvp_topk_gram(1, 8, 9, null, null, null, null) == -1        # k > n
+    assert lib.mvp_topk_gram(1, 8, 0, null, null, null, null) == -1
+    assert lib.mvp_topk_gram(1, 8, 4, null, null, null, null) == -2
+    assert lib.mvp_topk_gram(0, 8, 4, null, null, null, null) == 0
+    # shared-weight aggregation: share in {1,2,4,8,16}
+    assert lib.mvp_share_weighted_sum(1, 3, 2, 4, 8, null, null, null, null) == -1
+    assert lib.mvp_share_weighted_sum(1, 8, 2, 4, 8, null, null, null, null) == -2
+    assert lib.mvp_share_weighted_sum(0, 8, 2, 4, 8, null, null, null, null) == 0
+    assert lib.mvp_share_weighted_sum_grad(1, 8, 2, 4, 8, null, null, null, null, null, null) == -2
+    # pointwise weight gradient: cout <= 64, positions a multiple of 4; one partial per run of 1024 positions
+    assert _lib.pointwise_wgrad_scratch_bytes(2, 24, 24, 4096) == 2 * 4 * (24 * 24 + 24) * 4
+    assert _lib.pointwise_wgrad_scratch_bytes(1, 24, 65, 4096) == 0
+    assert _lib.pointwise_wgrad_scratch_bytes(1, 24, 24, 4094) == 0
+    assert lib.mvp_pointwise_wgrad(1, 24, 24, 4094, null, null, null, null, null, 0, null) == -1
+    assert lib.mvp_pointwise_wgrad(1, 24, 24, 4096, null, null, null, null, null, 0, null) == -2
+    # chamfer / fps scratch
+    assert _lib.fps_scratch_bytes(3, 16384) == 3 * 16384 * 16
+    assert lib.mvp_furthest_point_sampling_sorted(1, 0, 4, null, null, null, null, 0, null) == -1
+
+
 def test_operator_surface_matches_reference_names():
     import mvp_benchmark_amd.metrics as metrics
     import mvp_benchmark_amd.mm3d_pn2 as pn2
