@@ -21,6 +21,8 @@ MAX_CIN = 64    # beyond this MIOpen's weight gradient is as fast or faster (too
 def _covered(x, weight):
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() in (3, 4)):
         return False
+    if x.numel() == 0 or weight.numel() == 0:
+        return False
     length = x[0, 0].numel()
     return weight.size(0) <= MAX_COUT and weight.size(1) <= MAX_CIN and length % 4 == 0 and length > 0 \
         and x.size(0) <= 65535
