@@ -36,6 +36,7 @@
 //     smallest bit-reversed thread id win among equal maxima.
 //   * N > 16384 falls back to a streaming variant (temp in global memory).
 #include <cmath>
+#include <type_traits>
 
 #include "common.h"
 
@@ -164,7 +165,10 @@ __global__ __launch_bounds__(1024) void fps_kernel(
     z1 = dataset[2];
   }
 
-  for (int j = 1; j < m; ++j) {
+  // One round; PAR = j & 1 as a compile-time constant (the loop below alternates the two instances), so that the
+  // double-buffer addressing folds into immediate offsets.
+  auto round = [&](const int j, auto par_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
     float best = -1.f;
     int besti = 0;  // only tracked by the streaming variant
     if (P > 0) {
@@ -210,10 +214,10 @@ __global__ __launch_bounds__(1024) void fps_kernel(
       // <= 16 wave maxima -> block maximum: one ds_max_u64 per wave on a
       // double-buffered LDS word, one broadcast read after the barrier (no
       // second reduction stage); the other word is cleared for the next round.
-      if (lane == 0) atomicMax(&s_max[j & 1], key);
+      if (lane == 0) atomicMax(&s_max[PAR], key);
       lds_barrier();
-      key = s_max[j & 1];
-      if (t == 0) s_max[(j + 1) & 1] = 0ull;
+      key = s_max[PAR];
+      if (t == 0) s_max[1 - PAR] = 0ull;
     }
     const int tstar = (int)(key & 0xFFFFFu);  // winning thread
     if (wave == (tstar >> 6)) {               // wave-uniform
@@ -236,19 +240,19 @@ __global__ __launch_bounds__(1024) void fps_kernel(
         }
       }
       if (t == tstar) {
-        s_sel[j & 1][0] = __int_as_float(sel);
-        s_sel[j & 1][1] = sx;
-        s_sel[j & 1][2] = sy;
-        s_sel[j & 1][3] = sz;
+        s_sel[PAR][0] = __int_as_float(sel);
+        s_sel[PAR][1] = sx;
+        s_sel[PAR][2] = sy;
+        s_sel[PAR][3] = sz;
       }
     }
     lds_barrier();
-    old = __builtin_amdgcn_readfirstlane(__float_as_int(s_sel[j & 1][0]));
+    old = __builtin_amdgcn_readfirstlane(__float_as_int(s_sel[PAR][0]));
     if (!WITH_DIST) {
       if (P > 0) {
-        x1 = s_sel[j & 1][1];
-        y1 = s_sel[j & 1][2];
-        z1 = s_sel[j & 1][3];
+        x1 = s_sel[PAR][1];
+        y1 = s_sel[PAR][2];
+        z1 = s_sel[PAR][3];
       } else {
         x1 = dataset[(size_t)old * 3 + 0];
         y1 = dataset[(size_t)old * 3 + 1];
@@ -256,6 +260,14 @@ __global__ __launch_bounds__(1024) void fps_kernel(
       }
     }
     if (t == 0) idxs[j] = old;
+  };
+  {
+    int j = 1;
+    for (; j + 1 < m; j += 2) {
+      round(j, std::integral_constant<int, 1>{});
+      round(j + 1, std::integral_constant<int, 0>{});
+    }
+    if (j < m) round(j, std::integral_constant<int, 1>{});
   }
 
   if (P > 0) {
