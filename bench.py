@@ -8,19 +8,37 @@ on pred, gt = (64, 16384, 3) uniform [0,1) clouds per GPU (BASELINE.json
 metric: "point-pairs/sec CD+EMD @2048->16384 pts, batch 64").  Inputs are
 resident in HBM before the timed region.  value = B*N*M*n_gpus / time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); the batch
-dimension is sharded (every rank evaluates its own 64 clouds: weak scaling);
-the only collective is the 5-float metric all-reduce of the eval loop.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload eval|vrcnet_train]
+
+N > 1: one rank per GPU over RCCL.  Started by the driver under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+script reads RANK / LOCAL_RANK / WORLD_SIZE and refuses to run unless
+WORLD_SIZE == N; started bare (`python bench.py --gpus N`) it re-executes
+itself under torch.distributed.run with N local ranks -- and fails loudly if the
+box has fewer than N GPUs, so a "--gpus 8" line can never be a 1-GPU number.
+The batch dimension is sharded (every rank evaluates its own 64 clouds: weak
+scaling); the only collective of the eval workload is the 5-float metric
+all-reduce of the eval loop.
+
+--workload vrcnet_train is BASELINE cfg 3 (completion/train.py:122-142 with
+cfgs/vrcnet.yaml): DDP training steps of VRCNet, 32 clouds per rank (global
+batch 32*N), CD loss, Adam; its line reports samples/s, steps/s, the gradient
+all-reduce volume per step and the RCCL bus bandwidth of an all-reduce of that
+volume measured beside the timed region.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
   roofline     -- for the dominant kernel (the persistent EMD auction kernel)
   cpu_baseline -- the CPU oracle timed on a bounded sample of the same workload
-  extra        -- per-op times, FPS throughput, CD VALU figures.
+  cpu_baseline_reference_path -- the reference's own CPU path for CD
+                  (distChamfer, restated in metrics/CD/chamfer_python.py) timed
+                  with all torch threads
+  extra        -- per-op times, FPS throughput, CD figures.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,21 +49,81 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# non-packed FP32 VALU issue roof: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (MI355X_MICROARCH.md)
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("eval", "vrcnet_train"), default="eval")
+    ap.add_argument("--batch", type=int, default=None, help="clouds per GPU (eval: 64, vrcnet_train: 32)")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--eps", type=float, default=0.004)
     ap.add_argument("--iters", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="clouds in the CPU-baseline sample (0 = min(cores, 64))")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.workload == "eval" else 10
+    if args.warmup is None:
+        args.warmup = 2 if args.workload == "eval" else 3
+    if args.batch is None:
+        args.batch = 64 if args.workload == "eval" else 32
+    return args
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_or_join(args):
+    """Returns (rank, world, local_rank) of this process -- after making sure
+    that `world` really is args.gpus.  A bare `python bench.py --gpus N` (N > 1)
+    re-executes under torch.distributed.run and never returns."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1:
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                sys.exit("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to report a "
+                         "%d-GPU number from fewer devices" % (args.gpus, have, args.gpus))
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                   "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd, env=env))
+        return 0, 1, 0
+    world = int(env_world)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)"
+                 % (args.gpus, world, args.gpus))
+    return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_ranks(world, local_rank):
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit("bench.py: local rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world
+        # every rank must own a different device (RCCL-visible rank count == GPUs in use)
+        ids = [None] * world
+        dist.all_gather_object(ids, torch.cuda.current_device())
+        assert len(set(ids)) == world, "ranks share a device: %r" % (ids,)
+    return dev
 
 
 def eval_step(cd_mod, emd_mod, fscore, pred, gt, eps, iters, ev=None):
@@ -94,19 +172,50 @@ def cpu_baseline(args, n):
     }
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+def cpu_reference_path(n):
+    """The reference's only CPU path on this op layer: distChamfer
+    (utils/metrics/CD/chamfer_python.py:18-39: float64, |x|^2+|y|^2-2 bmm, two
+    full-matrix mins), in-tree restatement (bit-identical to the imported
+    reference on the golden fixtures, tests/test_host.py), all torch threads.
+    cfg 1 = (4, 2048, 2048) whole batch, best of 5; headline CD shape =
+    (., n, n) one cloud per chunk, a bounded sample of clouds."""
+    from mvp_benchmark_amd.metrics.CD.chamfer_python import distChamfer
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.rand(4, 2048, 3, generator=g), torch.rand(4, 2048, 3, generator=g)
+    distChamfer(a, b)
+    best = min(_timeit(lambda: distChamfer(a, b)) for _ in range(5))
+    out = {"kind": "reference (in-tree restatement of distChamfer, fp64 bmm)", "cores": cores,
+           "torch_threads": torch.get_num_threads(), "unit": "point-pairs/s",
+           "cfg1_4x2048x2048": {"seconds": best, "value": 4 * 2048 * 2048 / best}}
+    clouds = 2
+    a, b = torch.rand(clouds, n, 3, generator=g), torch.rand(clouds, n, 3, generator=g)
+    t = _timeit(lambda: distChamfer(a, b, chunk=1))
+    out["headline_cd_%dx%d" % (n, n)] = {"seconds": t, "clouds": clouds, "chunk": 1,
+                                         "value": clouds * float(n) * n / t}
+    return out
 
+
+def _timeit(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
+def committed_counters(B, n, eps, iters):
+    """Per-launch counters of emd_auction_kernel from the committed rocprofv3
+    --pmc passes (profiles/traffic.json), only if they were taken on this shape."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["emd_auction_kernel"]
+        if (tr["batch"], tr["points"], tr["eps"], tr["iters"]) == (B, n, eps, iters):
+            return tr
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def run_eval(args, rank, world, dev):
     from mvp_benchmark_amd.metrics import cd, emd, fscore
     from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample, gather_points
     from mvp_benchmark_amd import _lib
@@ -145,11 +254,8 @@ def main():
 
     cd_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
     emd_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
-
     if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
+        return None
 
     # ---- rank 0 only: side measurements (outside the timed region) ----
     # auction statistics of one EMD launch (rounds, bids) via the C ABI
@@ -184,13 +290,19 @@ def main():
     value = pairs * world / (elapsed / args.steps)
     emd_bytes = 32.0 * B * n  # xyz1+xyz2 in (24 B/pt) + dist+assignment out (8 B/pt)
     achieved = emd_bytes / (emd_ms * 1e-3) / 1e9
-    traffic = None  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["emd_auction_kernel"]
-        if (tr["batch"], tr["points"], tr["eps"], tr["iters"]) == (B, n, args.eps, args.iters):
-            traffic = (tr["FETCH_SIZE_KB"] + tr["WRITE_SIZE_KB"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        pass
+    ctr = committed_counters(B, n, args.eps, args.iters)
+    traffic = (ctr["FETCH_SIZE_KB"] + ctr["WRITE_SIZE_KB"]) * 1024.0 if ctr else None
+    # second roof: the kernel is a chain of dependent bids, not a stream.  VALU issue
+    # fraction = wave-level VALU instructions per launch (PMC, committed) x 64 lanes /
+    # (kernel time x the chip's lane-op rate); instructions per bid from the same pass.
+    issue = None
+    if ctr and "SQ_INSTS_VALU" in ctr:
+        total_bids = bids * B
+        issue = {"valu_insts_per_launch": ctr["SQ_INSTS_VALU"], "salu_insts_per_launch": ctr.get("SQ_INSTS_SALU"),
+                 "valu_insts_per_bid": ctr["SQ_INSTS_VALU"] / total_bids,
+                 "salu_insts_per_bid": (ctr.get("SQ_INSTS_SALU") or 0) / total_bids,
+                 "valu_issue_frac": ctr["SQ_INSTS_VALU"] * 64 / (emd_ms * 1e-3 * VALU_LANE_OPS_PER_S),
+                 "wait_any_frac": ctr.get("wait_any_frac"), "source": ctr.get("source")}
     line = {
         "metric": "point-pairs/sec CD+EMD @2048->16384 pts, batch 64",
         "value": value,
@@ -207,15 +319,20 @@ def main():
         "config": {"workload": "completion eval CD+F1+EMD, pred/gt (%d,%d,3) per GPU, "
                                "EMD eps=%g iters=%d" % (B, n, args.eps, args.iters),
                    "batch_per_gpu": B, "points": n, "parallelism": "batch-sharded x%d" % world},
-        "roofline": {"kernel": "emd_auction_kernel", "bound": "hbm", "achieved": achieved,
+        # the HBM figures are what the contract asks for; the kernel itself is bound by the
+        # latency of its dependent bid chain, hence bound = "latency" and the
+        # issue-side roof next to it
+        "roofline": {"kernel": "emd_auction_kernel", "bound": "latency", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic},
+                     "traffic": traffic, "issue": issue,
+                     "us_per_round": emd_ms * 1e3 / max(rounds, 1)},
         "extra": {
             "cd_f1_ms": cd_ms, "emd_ms": emd_ms,
             "emd_rounds_max": rounds, "emd_bids_per_cloud": bids,
             "emd_reference_pair_evals_per_s": bids * n * B / (emd_ms * 1e-3),
-            "cd_pair_evals_per_s": 2 * pairs / (cd_ms * 1e-3),
-            "cd_valu_tflops_16flop_per_pair": 16 * pairs / (cd_ms * 1e-3) / 1e12,
+            # brute-force-EQUIVALENT rates (all B*N*M pairs / time): the Morton-sorted kernel
+            # evaluates only ~9 % of them, so these are not hardware rates
+            "cd_bruteforce_equivalent_pairs_per_s": 2 * pairs / (cd_ms * 1e-3),
             "cd_hbm_GBs_20B_per_point": 20.0 * B * 2 * n / (cd_ms * 1e-3) / 1e9,
             "metrics": {"cd_p": float(sums[0] / sums[4]), "cd_t": float(sums[1] / sums[4]),
                         "f1": float(sums[2] / sums[4]), "emd": float(sums[3] / sums[4])},
@@ -224,7 +341,104 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, n)
-    print(json.dumps(line))
+        line["cpu_baseline_reference_path"] = cpu_reference_path(n)
+    return line
+
+
+def run_vrcnet_train(args, rank, world, dev):
+    """BASELINE cfg 3: VRCNet DDP training, batch 32 per rank (256 on 8 GPUs)."""
+    sys.path.insert(0, os.path.join(ROOT, "completion"))
+    import importlib
+    import train
+    from train_utils import unwrap
+
+    cfg = train.load_config(os.path.join(ROOT, "completion", "cfgs", "vrcnet.yaml"))
+    cfg.load_model = None
+    B = args.batch
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    net = importlib.import_module("models.vrcnet").Model(cfg).to(dev)
+    net = train.wrap_ddp(net, dev, world)
+    torch.manual_seed(1000 * (rank + 1))      # per-rank dropout / rsample streams
+    opt = torch.optim.Adam(unwrap(net).parameters(), lr=cfg.lr, betas=(0.9, 0.999))
+    g = torch.Generator().manual_seed(1000 + rank)
+    gt = torch.rand(B, cfg.num_points, 3, generator=g).to(dev)
+    partial = torch.rand(B, 2048, 3, generator=g).to(dev).transpose(2, 1).contiguous()
+    scale = train.loss_scale(cfg, world)
+
+    def step():
+        opt.zero_grad()
+        _, _, loss = net(partial, gt, alpha=0.5)
+        (loss.mean() * scale).backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # gradient all-reduce volume = every parameter that receives a gradient, fp32
+    grad_bytes = sum(p.numel() for p in unwrap(net).parameters() if p.grad is not None) * 4
+    bus = None
+    if world > 1:
+        buf = torch.empty(grad_bytes // 4, device=dev)
+        for _ in range(2):
+            torch.distributed.all_reduce(buf)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            torch.distributed.all_reduce(buf)
+        barrier()
+        ar = (time.perf_counter() - t0) / reps
+        bus = {"allreduce_ms": ar * 1e3, "algbw_GBs": grad_bytes / ar / 1e9,
+               "busbw_GBs": grad_bytes / ar / 1e9 * 2 * (world - 1) / world}
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    return {
+        "metric": "VRCNet train samples/sec (cfgs/vrcnet.yaml, DDP, batch 32 per GPU)",
+        "value": B * world / (ms * 1e-3),
+        "unit": "samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms,
+        "steps_per_s": 1e3 / ms,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "VRCNet DDP train step (forward, CD losses + KLD, backward, Adam), "
+                               "%d clouds of 2048 pts per GPU" % B,
+                   "global_batch": B * world, "batch_per_gpu": B, "parallelism": "ddp x%d" % world},
+        "grad_allreduce_bytes_per_step": grad_bytes,
+        "rccl": bus,
+        "final_loss": float(loss.mean()),
+    }
+
+
+def main():
+    args = parse()
+    rank, world, local_rank = launch_or_join(args)
+    dev = init_ranks(world, local_rank)
+    line = (run_eval if args.workload == "eval" else run_vrcnet_train)(args, rank, world, dev)
+    if line is not None:
+        print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -3,12 +3,15 @@ completion/dataset.py:8-46.
 
 On-disk format (completion/README.md:21-32): HDF5 with `incomplete_pcds`
 (62400, 2048, 3), `complete_pcds` (2400, 2048, 3) and `labels`; partial cloud i
-pairs with complete cloud i // 26.  `MVP_CP` reads those files when both the
-file and h5py are available.  `SyntheticMVP` yields the same sample tuples from
-a seeded generator (no dataset or network exists in the build environment):
-every "shape" is a uniform cloud in [0,1)^3 and its 26 partial views are
-half-space cuts re-sampled to 2048 points.
+pairs with complete cloud i // 26.  `MVP_CP` reads those files with h5py when it
+is installed and with the in-tree reader (h5lite.py) otherwise.
+`SyntheticMVP` yields the same sample tuples from a seeded generator (no dataset
+or network exists in the build environment): every "shape" is a uniform cloud
+in [0,1)^3 and its 26 partial views are half-space cuts re-sampled to 2048
+points.  It is used ONLY when the cfg says `synthetic: True`; a missing .h5
+file is an error, as in the reference.
 """
+import logging
 import os
 
 import numpy as np
@@ -20,14 +23,23 @@ _FILES = {"train": './data/MVP_Train_CP.h5', "val": './data/MVP_Test_CP.h5',
           "test": './data/MVP_ExtraTest_Shuffled_CP.h5'}
 
 
+def h5_module():
+    """h5py when installed, else the in-tree reader / writer with the same calls."""
+    try:
+        import h5py
+        return h5py
+    except ImportError:
+        import h5lite
+        return h5lite
+
+
 class MVP_CP(data.Dataset):
-    def __init__(self, prefix="train"):
+    def __init__(self, prefix="train", file_path=None):
         if prefix not in _FILES:
             raise ValueError("ValueError prefix should be [train/val/test] ")
-        import h5py  # optional dependency; SyntheticMVP is the fallback
         self.prefix = prefix
-        self.file_path = _FILES[prefix]
-        with h5py.File(self.file_path, 'r') as f:
+        self.file_path = file_path or _FILES[prefix]
+        with h5_module().File(self.file_path, 'r') as f:
             self.input_data = np.array(f['incomplete_pcds'][()])
             if prefix != "test":
                 self.gt_data = np.array(f['complete_pcds'][()])
@@ -80,13 +92,20 @@ class SyntheticMVP(data.Dataset):
 
 
 def build_dataset(args, prefix):
-    """MVP_CP when the .h5 file and h5py are present and `synthetic` is not
-    requested; SyntheticMVP otherwise."""
-    if not args.get("synthetic") and os.path.exists(_FILES[prefix]):
-        try:
-            return MVP_CP(prefix)
-        except ImportError:
-            pass
+    """MVP_CP on ./data/*.h5 (or the cfg's `data_dir`); SyntheticMVP only when the
+    cfg sets `synthetic: True`.  A missing file raises -- training on noise because
+    of a wrong working directory must not happen silently."""
+    if not args.get("synthetic"):
+        path = _FILES[prefix]
+        if args.get("data_dir"):
+            path = os.path.join(args.get("data_dir"), os.path.basename(path))
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                "%s not found (run from completion/ with the MVP files under ./data, set `data_dir`, "
+                "or set `synthetic: True` in the cfg to use the generated stand-in)" % path)
+        return MVP_CP(prefix, path)
+    logging.warning("build_dataset(%s): cfg has synthetic=True -- using generated stand-in clouds, "
+                    "NOT the MVP dataset", prefix)
     shapes = args.get("synthetic_%s_shapes" % ("train" if prefix == "train" else "val")) or 4
     return SyntheticMVP(prefix, num_shapes=int(shapes), num_points=int(args.get("num_points") or 2048),
                         seed=int(args.get("manual_seed") or 0))

@@ -5,22 +5,25 @@ the checkpoint and zip it as `submission.zip`.
 
 One process per GPU: the test set is sharded in order, every rank writes its
 predictions to `results.rank<r>.npy` and rank 0 concatenates them in rank
-order (no collective on the data path).  h5py is optional: without it the
-results are stored as `results.npy` with the same array.
+order (no collective on the data path).  `results.h5` is written with h5py when
+it is installed, else with the in-tree writer (h5lite.py: same contiguous
+float32 dataset `results`, readable by h5py / libhdf5).
 """
 import argparse
 import logging
 import os
+import shutil
 import subprocess
 import sys
 import warnings
+import zipfile
 
 import numpy as np
 import torch
 import torch.distributed as dist
 import yaml
 
-from dataset import build_dataset
+from dataset import build_dataset, h5_module
 from train_utils import AttrDict, init_distributed, is_distributed, load_model, shard_indices, unwrap
 from train import build_model
 
@@ -60,16 +63,15 @@ def test(args, log_dir):
     all_results = np.concatenate(parts, axis=0)[:n]
     for r in range(world):
         os.remove(os.path.join(log_dir, 'results.rank%d.npy' % r))
-    try:
-        import h5py
-        with h5py.File(os.path.join(log_dir, 'results.h5'), 'w') as f:
-            f.create_dataset('results', data=all_results)
-        out_name = 'results.h5'
-    except ImportError:
-        np.save(os.path.join(log_dir, 'results.npy'), all_results)
-        out_name = 'results.npy'
-    subprocess.run(["zip", "-r", "submission.zip", out_name], cwd=log_dir,
-                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    out_name = 'results.h5'
+    with h5_module().File(os.path.join(log_dir, out_name), 'w') as f:
+        f.create_dataset('results', data=all_results)
+    if shutil.which("zip"):
+        subprocess.run(["zip", "-r", "submission.zip", out_name], cwd=log_dir,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    else:
+        with zipfile.ZipFile(os.path.join(log_dir, "submission.zip"), "w", zipfile.ZIP_DEFLATED) as z:
+            z.write(os.path.join(log_dir, out_name), out_name)
     print("Submission file has been saved to %s/submission.zip" % log_dir)
     return all_results
 

@@ -84,18 +84,45 @@ def make_loader(dataset, args, rank, world, shuffle, epoch=0, seed=0):
     return loader, valid
 
 
+def wrap_ddp(net, device, world):
+    """DistributedDataParallel around `net` when world > 1.
+
+    find_unused_parameters=True: the shipped cfgs leave whole branches without a
+    gradient (cfgs/vrcnet.yaml has num_fps == num_coarse == num_points, so
+    MSAP_SKN_decoder never runs conv_s1..3 / expansion2 / conv_f1..2); the
+    reference's nn.DataParallel (train.py:49) tolerates that, a plain DDP raises
+    "Expected to have finished reduction in the prior iteration" in the second
+    step.  The per-step graph walk costs well under a millisecond here."""
+    if world > 1:
+        ids = [device.index] if device.type == "cuda" else None
+        net = torch.nn.parallel.DistributedDataParallel(net, device_ids=ids, find_unused_parameters=True)
+    return net
+
+
+def loss_scale(args, world):
+    """Factor applied to the rank's scalar loss before backward().
+
+    The reference back-propagates the SUM of the per-replica mean losses
+    (`net_loss.backward(ones(ngpu))`, train.py:141): its gradient is ngpu times
+    the gradient of the global-batch mean.  DDP averages over ranks, so the same
+    gradient needs loss * world -- the default (`ddp_grad_scale: sum`, matters
+    for Adam's eps and for weight_decay).  `ddp_grad_scale: mean` keeps DDP's
+    own convention (gradient of the global-batch mean)."""
+    mode = args.get("ddp_grad_scale") or "sum"
+    if mode not in ("sum", "mean"):
+        raise ValueError("ddp_grad_scale must be 'sum' or 'mean'")
+    return float(world) if mode == "sum" else 1.0
+
+
 def build_model(args, device, world):
     model_module = importlib.import_module('.%s' % args.model_name, 'models')
     net = model_module.Model(args).to(device)
     if hasattr(model_module, 'weights_init'):
         net.apply(model_module.weights_init)
-    if world > 1:
-        ids = [device.index] if device.type == "cuda" else None
-        net = torch.nn.parallel.DistributedDataParallel(net, device_ids=ids)
-    return net
+    return wrap_ddp(net, device, world)
 
 
-def train_one_epoch(net, optimizer, loader, device, alpha, meter, log_fn=None):
+def train_one_epoch(net, optimizer, loader, device, alpha, meter, log_fn=None, scale=1.0):
     unwrap(net).train()
     for i, data in enumerate(loader):
         optimizer.zero_grad()
@@ -104,7 +131,9 @@ def train_one_epoch(net, optimizer, loader, device, alpha, meter, log_fn=None):
         gt = gt.float().to(device)
         out2, loss2, net_loss = net(inputs, gt, alpha=alpha)
         net_loss = net_loss.mean()
-        net_loss.backward()          # DDP all-reduces (averages) the gradients
+        # DDP all-reduces (averages) the gradients; `scale` = loss_scale() restores the
+        # reference's sum-over-replicas gradient
+        (net_loss * scale if scale != 1.0 else net_loss).backward()
         optimizer.step()
         meter.update(net_loss.item())
         if log_fn:
@@ -160,6 +189,7 @@ def val(net, curr_epoch_num, val_loss_meters, loader, valid, best_epoch_losses, 
 
 def train(args, log_dir, exp_name):
     rank, world, device = init_distributed()
+    scale = loss_scale(args, world)
     logging.info(str(args))
     metrics = ['cd_p', 'cd_t', 'emd', 'f1'] if args.eval_emd else ['cd_p', 'cd_t', 'f1']
     best_epoch_losses = {m: (0, 0) if m == 'f1' else (0, math.inf) for m in metrics}
@@ -207,7 +237,7 @@ def train(args, log_dir, exp_name):
                              % (_epoch, i, len(dataset) / args.batch_size, args.loss, fine, total, _lr)
                              + ' alpha: ' + str(_alpha))
 
-        train_one_epoch(net, optimizer, loader, device, alpha, train_loss_meter, log_fn)
+        train_one_epoch(net, optimizer, loader, device, alpha, train_loss_meter, log_fn, scale)
 
         if epoch % args.epoch_interval_to_save == 0:
             save_model('%s/network.pth' % log_dir, net)
@@ -227,7 +257,13 @@ def main():
     arg = parser.parse_args()
     args = load_config(arg.config)
 
-    time = datetime.datetime.now().isoformat()[:19]
+    # one experiment name for the whole job: rank 0's clock, broadcast (ranks started
+    # across a second boundary would otherwise create different log directories)
+    rank, world, _ = init_distributed()
+    stamp = [datetime.datetime.now().isoformat()[:19]]
+    if world > 1:
+        torch.distributed.broadcast_object_list(stamp, src=0)
+    time = stamp[0]
     if args.load_model:
         exp_name = os.path.basename(os.path.dirname(args.load_model))
         log_dir = os.path.dirname(args.load_model)
@@ -236,10 +272,9 @@ def main():
         log_dir = os.path.join(args.work_dir, exp_name)
     os.makedirs(log_dir, exist_ok=True)
     handlers = [logging.StreamHandler(sys.stdout)]
-    if int(os.environ.get("RANK", "0")) == 0:
+    if rank == 0:
         handlers.append(logging.FileHandler(os.path.join(log_dir, 'train.log')))
-    logging.basicConfig(level=logging.INFO if int(os.environ.get("RANK", "0")) == 0 else logging.WARNING,
-                        handlers=handlers)
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, handlers=handlers)
     train(args, log_dir, exp_name)
 
 

@@ -40,7 +40,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 5
+#define MVP_ABI_VERSION 6
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -103,12 +103,29 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * iters >= 1; eps > 0 (-> MVP_EBADARG: the auction needs strictly positive bid
  * increments, and the search prunes on prices that never fall).  Deterministic: GetMax's racy last-writer (emd_cuda.cu:188-191)
  * is pinned to the highest qualifying bidder index.
- * One persistent (cooperative) launch; up to 8 workgroups share a cloud when
- * b leaves CUs free (b*W <= CU count; MVP_EMD_CLUSTER=1|2|4|8 caps W).  The
- * call enqueues one small memset (barrier words, statistics) ahead of it. */
+ * Two launches: a persistent cooperative kernel in which up to 8 workgroups
+ * share a cloud when b leaves CUs free (b*W <= CU count), and -- for n <= 16384
+ * -- a single-workgroup kernel that takes a cloud over once at most 256 persons
+ * are unassigned (prices in LDS, exact per-person candidate caches; exits at
+ * once for clouds that were finished before).  The call enqueues one small
+ * memset (barrier words, hand-over records, statistics) ahead of them.
+ * If a cluster wait is abandoned (members not co-resident for tens of seconds;
+ * never seen) dist is filled with NaN, assignment with -1 and the statistics
+ * word `rounds` is negative: the host wrapper checks for NaN lazily, and
+ * mvp_emd_backward skips negative indices. */
 int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
                     float *dist, int *assignment, float eps, int iters,
                     void *scratch, long long scratch_bytes, void *stream);
+
+/* Tuning / A-B knobs of mvp_emd_forward, process-wide (defaults: environment
+ * variables MVP_EMD_CLUSTER / _SAME_XCD / _TAIL / _TAIL_DELTA read once at
+ * first use).  A negative argument leaves that knob unchanged.
+ *   cluster     0 = automatic, or 1|2|4|8: cap of the workgroups per cloud
+ *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
+ *   tail        0: no hand-over to the single-workgroup tail kernel
+ *   tail_delta  width of the candidate caches in units of eps (0: no caches)
+ * Results never depend on these (every variant is bit-identical). */
+int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail_delta);
 
 /* Replaces emd.backward = emd_backward (emd.cpp:22-25,30) ->
  * emd_cuda_backward (emd_cuda.cu:302-316) -> NmDistanceGradKernel (:284-300).

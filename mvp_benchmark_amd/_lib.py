@@ -47,7 +47,7 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 5   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 6   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 _lib = None
 
@@ -72,6 +72,8 @@ def load():
     lib.mvp_last_hip_error.restype = ctypes.c_char_p
     lib.mvp_emd_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_emd_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.mvp_emd_configure.restype = ctypes.c_int
+    lib.mvp_emd_configure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
     lib.mvp_fps_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_fps_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_chamfer_scratch_bytes.restype = ctypes.c_longlong
@@ -128,6 +130,14 @@ def emd_scratch_bytes(b, n):
     return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
 
 
+def emd_configure(cluster=-1, same_xcd=-1, tail=-1, tail_delta=-1.0):
+    """Process-wide tuning knobs of mvp_emd_forward (negative = unchanged;
+    cluster=0 = automatic).  Results do not depend on them."""
+    rc = load().mvp_emd_configure(int(cluster), int(same_xcd), int(tail), float(tail_delta))
+    if rc != MVP_OK:
+        raise MvpOpsError("mvp_emd_configure: %s" % _ERR.get(rc, rc))
+
+
 def fps_scratch_bytes(b, n):
     return int(load().mvp_fps_scratch_bytes(int(b), int(n)))
 
@@ -148,6 +158,6 @@ def pointwise_wgrad_scratch_bytes(b, cin, cout, length):
 
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
-    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes",
+    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes",
             "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes"] \
         + list(SIGNATURES)

@@ -59,208 +59,9 @@
 //     different increment within that band was bid on the same object, and
 //     only rounds where that happened (a few per 10^5 bids) run the explicit
 //     GetMax pass and its extra barrier.
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "common.h"
+#include "emd_common.h"
 
 namespace mvp {
-
-constexpr int kEmdThreads = 1024;
-constexpr int kEmdWaves = kEmdThreads / kWave;
-constexpr int kMaxG = 12;
-constexpr int kMaxCells = kMaxG * kMaxG * kMaxG;  // 1728
-constexpr int kBidCache = 1024;  // list positions whose bid is cached in LDS
-constexpr int kRecCap = 512;     // list positions whose person record is cached in LDS
-#ifndef MVP_EMD_ROWMIN
-#define MVP_EMD_ROWMIN 96
-#endif
-constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 bidders share a wave
-constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
-constexpr int kMaxCluster = 8;   // workgroups per cloud (W)
-constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
-constexpr int kSoloMax = 16;     // unassigned persons below which one workgroup finishes the auction alone
-constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens of seconds), then abort
-
-// Filter slack.  An object is skipped only if
-//   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
-// which implies sqrtf(s) + price > (3 - B2) + kMargin - 7e-7, hence the exact
-// value  float(3.0 - sqrtf(s) - price) <= (3 - sqrtf(s) - price) + 1.3e-7
-// < B2: the object can change neither best, second best nor (being strictly
-// below B2 <= B1) the tie-broken best index.  A cell is skipped with the same
-// test on (squared distance to its bounding box, price lower bound); because
-// float subtraction/multiply/fma are monotone, every member's own test value
-// is >= the cell's, so a skipped cell contains only skippable objects.
-constexpr float kMargin = 1e-5f;
-
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-typedef unsigned long long u64;
-
-// Per-person record (32 B): two 16-byte halves.
-//   lo = {qx, qy, qz, -}                         the person's point (xyz1)
-//   hi = {bid, prev1, prev2, bits(bidinc)}       slot it last bid on, best /
-//        second-best slot of that bid (seed hints), increment of that bid
-// Per-object auction state (16 B), next to the object's float4 {x,y,z,price}:
-//   {key lo, key hi, owner (-1 = free), -}
-//   key = ord(max bid increment this round) << 32 | (winning bidder + 1); 0 = no bid
-struct EmdScratch {
-  float4 *obj;     // (n) cell-sorted x, y, z, price of xyz2
-  int4 *ostate;    // (n) per slot
-  float4 *person;  // (2n) per person: lo, hi
-  int *perm;       // (n) slot -> original object index
-  int *ulist;      // (W x 2n) ping-pong unassigned lists, one pair per workgroup
-  u64 *chg;        // (W x kChgCap) {cell, bits(price bound)} broadcast per round
-};
-
-__host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
-  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg
-  return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8;
-}
-// After the per-cloud areas: 256 B of barrier granules per cloud, then the
-// per-cloud statistics {rounds, bids}.  Zeroed by the host before the launch.
-constexpr size_t kEmdTailPerCloud = 256 + 16;
-
-__device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
-  EmdScratch s;
-  s.obj = reinterpret_cast<float4 *>(base);
-  s.ostate = reinterpret_cast<int4 *>(base + (size_t)n * 16);
-  s.person = reinterpret_cast<float4 *>(base + (size_t)n * 32);
-  s.perm = reinterpret_cast<int *>(base + (size_t)n * 64);
-  s.ulist = reinterpret_cast<int *>(base + (size_t)n * 68);
-  s.chg = reinterpret_cast<u64 *>(base + (size_t)n * (68 + 8 * kMaxCluster));
-  return s;
-}
-
-// Order-preserving map float -> unsigned (and back); never 0 for a non-NaN.
-__device__ __forceinline__ unsigned emd_f2ord(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float emd_ord2f(unsigned o) {
-  return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
-}
-// A bidder with increment bi competes for an object whose maximal increment
-// is mi (emd_cuda.cu:188).
-__device__ __forceinline__ bool emd_in_band(float bi, float mi) {
-  return (double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6;
-}
-// `old` = the object's key before this bidder's atomic max.  True if a
-// DIFFERENT increment close enough to compete was already bid (the test is
-// wider than the band: false alarms only cost the explicit GetMax pass).
-__device__ __forceinline__ bool emd_band_alarm(u64 old, float inc) {
-  if (old == 0ull) return false;
-  const float mo = emd_ord2f((unsigned)(old >> 32));
-  const double d = (double)mo - (double)inc;
-  return mo != inc && d <= 2e-6 && d >= -2e-6;
-}
-
-// Reference merge order between two candidates (ORIGINAL object indices) of
-// equal value: lexicographically smaller (thread_in_unass, tile, k) wins.
-__device__ __forceinline__ bool emd_precedes(int ka, int kb, int n, int tpu) {
-  const int tile_a = ka >> 11, tile_b = kb >> 11;
-  const int kka = ka & 2047, kkb = kb & 2047;
-  const int end_a = min(n - (tile_a << 11), 2048);
-  const int end_b = min(n - (tile_b << 11), 2048);
-  const int ta = kka / ((end_a + tpu - 1) / tpu);
-  const int tb = kkb / ((end_b + tpu - 1) / tpu);
-  if (ta != tb) return ta < tb;
-  if (tile_a != tile_b) return tile_a < tile_b;
-  return kka < kkb;
-}
-
-__device__ __forceinline__ float emd_value(float s, float p) {
-  return (float)(3.0 - (double)__builtin_sqrtf(s) - (double)p);
-}
-
-// Wave-uniform running state of one bid.
-struct BidState {
-  float b1, b2;  // best / second-best value
-  int bk, b2k;   // their slots (b2k is only a seed hint)
-  float tm;      // filter threshold: <= fl(fl(3 - b2) + kMargin)
-};
-
-// Fold the candidates flagged in `mask` (exact value v and slot k per lane)
-// into the uniform state, lowest lane first.
-__device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
-                                         float v, int k, int n, int tpu,
-                                         const int *__restrict__ perm) {
-  while (mask) {
-    const int l = __builtin_ctzll(mask);
-    mask &= mask - 1;
-    const float vl =
-        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-    const int kl = __builtin_amdgcn_readlane(k, l);
-    if (vl > st.b1) {
-      st.b2 = st.b1;
-      st.b2k = st.bk;
-      st.b1 = vl;
-      st.bk = kl;
-    } else if (vl == st.b1) {
-      st.b2 = st.b1;
-      if (emd_precedes(perm[kl], perm[st.bk], n, tpu)) {
-        st.b2k = st.bk;
-        st.bk = kl;
-      } else {
-        st.b2k = kl;
-      }
-    } else if (vl > st.b2) {
-      st.b2 = vl;
-      st.b2k = kl;
-    }
-  }
-  // thresholds only ever tighten (the seed may already be tighter)
-  st.tm = __builtin_fminf(st.tm, (3.0f - st.b2) + kMargin);
-}
-
-__device__ __forceinline__ void top2_insert(float &a1, float &a2, float v) {
-  const float lo = __builtin_fminf(a1, v);
-  a1 = __builtin_fmaxf(a1, v);
-  a2 = __builtin_fmaxf(a2, lo);
-}
-
-// DPP move with an identity fill for lanes the control/row mask does not write.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f32(float identity, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v),
-                                                    CTRL, ROW_MASK, 0xF, false));
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void top2_dpp_step(float &a1, float &a2) {
-  const float o1 = dpp_f32<CTRL, ROW_MASK>(-1e9f, a1);
-  const float o2 = dpp_f32<CTRL, ROW_MASK>(-1e9f, a2);
-  const float lo = __builtin_fminf(a1, o1);
-  a1 = __builtin_fmaxf(a1, o1);
-  a2 = __builtin_fmaxf(lo, __builtin_fmaxf(a2, o2));
-}
-
-// Second-largest value (with multiplicity) over the wave's per-lane (a1, a2)
-// top-2 pairs, using DPP row operations only; every step merges disjoint lane
-// sets, masked-out lanes merge with the identity (-1e9, -1e9).  Valid in lane
-// 63, returned wave-uniform.
-__device__ __forceinline__ float wave_second_largest(float a1, float a2) {
-  top2_dpp_step<0xB1, 0xF>(a1, a2);   // quad_perm [1,0,3,2]
-  top2_dpp_step<0x4E, 0xF>(a1, a2);   // quad_perm [2,3,0,1]
-  top2_dpp_step<0x141, 0xF>(a1, a2);  // row_half_mirror
-  top2_dpp_step<0x140, 0xF>(a1, a2);  // row_mirror
-  top2_dpp_step<0x142, 0xA>(a1, a2);  // row_bcast15 -> rows 1, 3
-  top2_dpp_step<0x143, 0xC>(a1, a2);  // row_bcast31 -> rows 2, 3
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 63));
-}
-
-struct GridGeom {
-  float lox, loy, loz, invh;
-  int g;
-};
-
-__device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
-                                        float z) {
-  const int ix = min(gg.g - 1, max(0, (int)((x - gg.lox) * gg.invh)));
-  const int iy = min(gg.g - 1, max(0, (int)((y - gg.loy) * gg.invh)));
-  const int iz = min(gg.g - 1, max(0, (int)((z - gg.loz) * gg.invh)));
-  return (iz * gg.g + iy) * gg.g + ix;
-}
 
 // All-gather of two 32-bit payloads among the W workgroups of a cluster; also
 // the cluster's barrier.  Every global store the workgroup issued before the
@@ -305,10 +106,14 @@ __device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned 
   return *s_abort == 0;
 }
 
+// emd_tail.hip
+void emd_tail_launch(int b, int n, const float *xyz1, float *dist, int *assignment, float eps, int iters,
+                     char *scratch, float delta, hipStream_t stream);
+
 template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     int b, int bpad, int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    float *__restrict__ dist, int *assignment, float eps, int iters, char *scratch, int fast_ok) {
+    float *__restrict__ dist, int *assignment, float eps, int iters, char *scratch, int fast_ok, int tail_ok) {
   // Block -> (cloud, member): members of a cluster are bpad (a multiple of 8)
   // blocks apart, so they share an XCD under the round-robin dispatch (faster
   // L2 sharing only; nothing below depends on placement).
@@ -320,7 +125,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   u64 *slots = reinterpret_cast<u64 *>(tail + (size_t)cloud * 256);
   // per-cloud auction statistics {rounds executed, bids made} (read by
   // bench.py; not part of the op's result)
-  long long *stats = reinterpret_cast<long long *>(tail + (size_t)b * 256) + 2 * (size_t)cloud;
+  EmdResume *resume = reinterpret_cast<EmdResume *>(tail + (size_t)b * 256) + cloud;
+  long long *stats = reinterpret_cast<long long *>(tail + (size_t)b * (256 + sizeof(EmdResume))) + 2 * (size_t)cloud;
   const int t = threadIdx.x;
   const int lane = t & (kWave - 1);
   const int wave = t >> 6;
@@ -536,6 +342,17 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       sc.ostate[k] = make_int4(0, 0, -1, 0);
       sc.person[2 * k] = make_float4(xyz1[k * 3 + 0], xyz1[k * 3 + 1], xyz1[k * 3 + 2], 0.f);
       sc.person[2 * k + 1] = make_float4(__int_as_float(-1), __int_as_float(-1), __int_as_float(-1), 0.f);
+      if (tail_ok) *reinterpret_cast<int *>(sc.cache + (size_t)k * kCacheRec + 100) = 0;  // empty candidate cache
+    }
+    if (tail_ok) {  // what the tail kernel needs to rebuild the cell index
+      for (int c = t; c <= ncell; c += kEmdThreads) sc.cstart[c] = c_start[c];
+      if (t == 0) {
+        resume->g = gg.g;
+        resume->lox = gg.lox;
+        resume->loy = gg.loy;
+        resume->loz = gg.loz;
+        resume->invh = gg.invh;
+      }
     }
   }
   // every member: its own share of the persons is its first unassigned list
@@ -1302,6 +1119,24 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         Utot += cntw[w];
         if (w != wg) overflow |= (int)s_gout[2 * w + 1] > kChgCap;
       }
+      if (tail_ok && Utot > 0 && Utot <= kTailCap && it + 1 < iters) {
+        // ---- hand the cloud to the tail kernel: every member appends its list
+        // (<= kTailCap < kRecCap entries: all in LDS) to the hand-over record
+        int off = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) off += w < wg ? cntw[w] : 0;
+        if (t < cntw[wg]) resume->list[off + t] = s_ri[nxt][t].x;
+        if (t == 0) {
+          atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
+          if (s_err) resume->pad = 1;   // the tail kernel reports it
+          if (wg == 0) {
+            resume->utot = Utot;
+            resume->next_it = it + 1;
+            stats[0] = n_rounds;
+          }
+        }
+        return;
+      }
       if (Utot > 0 && Utot <= kSoloMax && it + 1 < iters) {
         // ---- hand everything to member 0 (lists of <= kSoloMax persons live
         // in LDS only: publish the person ids; their records are in memory)
@@ -1446,6 +1281,17 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     } else {
       __syncthreads();
       Utot = s_cnt[nxt];
+      if (tail_ok && Utot > 0 && Utot <= kTailCap && it + 1 < iters) {
+        if (t < Utot) resume->list[t] = s_ri[nxt][t].x;
+        if (t == 0) {
+          if (s_err) resume->pad = 1;
+          resume->utot = Utot;
+          resume->next_it = it + 1;
+          stats[0] = n_rounds;
+          atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
+        }
+        return;
+      }
     }
 #ifdef MVP_EMD_PROFILE
     const long long tp4 = __builtin_readcyclecounter();
@@ -1530,11 +1376,34 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
   const int cloud = blockIdx.y;
   const size_t a = ((size_t)cloud * n + j) * 3;
   const int j2 = idx[(size_t)cloud * n + j];
+  if (j2 < 0 || j2 >= n) return;  // -1: the forward pass was abandoned (NaN distances); no gradient
   const size_t c = ((size_t)cloud * n + j2) * 3;
   const float g = grad_dist[(size_t)cloud * n + j] * 2;
   grad_xyz[a + 0] += g * (xyz1[a + 0] - xyz2[c + 0]);
   grad_xyz[a + 1] += g * (xyz1[a + 1] - xyz2[c + 1]);
   grad_xyz[a + 2] += g * (xyz1[a + 2] - xyz2[c + 2]);
+}
+
+// Tuning / A-B knobs of the auction.  Process-wide; the defaults come from the
+// environment ONCE (first use), mvp_emd_configure() overrides them at run time:
+//   MVP_EMD_CLUSTER=1|2|4|8   cap of the workgroups per cloud
+//   MVP_EMD_SAME_XCD=0        keep the write-through stores even when a cluster shares an XCD
+//   MVP_EMD_TAIL=0            no hand-over to the tail kernel (the clustered kernel runs every round)
+//   MVP_EMD_TAIL_DELTA=<x>    candidate-cache width in units of eps (0: no caches)
+struct EmdKnobs {
+  int cluster, same_xcd, tail;
+  float tail_delta;
+};
+static EmdKnobs &emd_knobs() {
+  static EmdKnobs k = [] {
+    EmdKnobs v{kMaxCluster, 1, 1, 5.f};
+    if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
+    if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
+    if (const char *e = getenv("MVP_EMD_TAIL")) v.tail = atoi(e) != 0;
+    if (const char *e = getenv("MVP_EMD_TAIL_DELTA")) v.tail_delta = (float)atof(e);
+    return v;
+  }();
+  return k;
 }
 
 // Workgroups per cloud: as many (1, 2, 4, 8) as keep b*W workgroups co-resident,
@@ -1544,8 +1413,7 @@ static int emd_cluster_width(int b) {
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 1;
-  int want = kMaxCluster;
-  if (const char *e = getenv("MVP_EMD_CLUSTER")) want = atoi(e);
+  const int want = emd_knobs().cluster;
   int w = 1;
   while (w * 2 <= want && w * 2 <= kMaxCluster && (long long)b * w * 2 <= cus) w *= 2;
   return w;
@@ -1553,20 +1421,18 @@ static int emd_cluster_width(int b) {
 
 template <int W>
 static hipError_t emd_launch(int b, int n, const float *xyz1, const float *xyz2, float *dist,
-                             int *assignment, float eps, int iters, char *scratch,
+                             int *assignment, float eps, int iters, char *scratch, int tail_ok,
                              hipStream_t stream) {
   int bpad = W == 1 ? b : (b + 7) / 8 * 8;
   if (W == 1) {
     hipLaunchKernelGGL(emd_auction_kernel<1>, dim3(b), dim3(kEmdThreads), 0, stream, b, bpad, n,
-                       xyz1, xyz2, dist, assignment, eps, iters, scratch, 0);
+                       xyz1, xyz2, dist, assignment, eps, iters, scratch, 0, tail_ok);
     return hipSuccess;
   }
   // cluster members wait for each other: the launch must be checked against
   // the device's residency (cooperative launch does exactly that)
-  // MVP_EMD_SAME_XCD=0 keeps the write-through stores even when the members share an XCD
-  int fast_ok = 1;
-  if (const char *e = getenv("MVP_EMD_SAME_XCD")) fast_ok = atoi(e) != 0;
-  void *args[] = {&b, &bpad, &n, &xyz1, &xyz2, &dist, &assignment, &eps, &iters, &scratch, &fast_ok};
+  int fast_ok = emd_knobs().same_xcd;
+  void *args[] = {&b, &bpad, &n, &xyz1, &xyz2, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &tail_ok};
   return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_auction_kernel<W>),
                                     dim3(W * bpad), dim3(kEmdThreads), args, 0, stream);
 }
@@ -1578,6 +1444,18 @@ using namespace mvp;
 extern "C" long long mvp_emd_scratch_bytes(int b, int n) {
   if (b < 0 || n < 0) return -1;
   return (long long)b * ((long long)emd_scratch_per_cloud(n) + (long long)kEmdTailPerCloud);
+}
+
+extern "C" int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail_delta) {
+  EmdKnobs &k = emd_knobs();
+  if (cluster >= 0) {
+    if (cluster != 0 && cluster != 1 && cluster != 2 && cluster != 4 && cluster != 8) return MVP_EBADARG;
+    k.cluster = cluster == 0 ? kMaxCluster : cluster;
+  }
+  if (same_xcd >= 0) k.same_xcd = same_xcd != 0;
+  if (tail >= 0) k.tail = tail != 0;
+  if (tail_delta >= 0.f) k.tail_delta = tail_delta;
+  return MVP_OK;
 }
 
 extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
@@ -1599,14 +1477,18 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
   if (hipMemsetAsync(sbase + (size_t)b * emd_scratch_per_cloud(n), 0, (size_t)b * kEmdTailPerCloud, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
   const int w = emd_cluster_width(b);
+  // rounds after the first kTailCap-or-fewer unassigned persons run in the tail kernel
+  const int tail_ok = emd_knobs().tail && n <= kTailMaxN && iters > 1;
   hipError_t err = hipErrorUnknown;
-  if (w == 8) err = emd_launch<8>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
-  else if (w == 4) err = emd_launch<4>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
-  else if (w == 2) err = emd_launch<2>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
+  if (w == 8) err = emd_launch<8>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, tail_ok, st);
+  else if (w == 4) err = emd_launch<4>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, tail_ok, st);
+  else if (w == 2) err = emd_launch<2>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, tail_ok, st);
   if (err != hipSuccess) {  // w == 1, or the cluster does not fit this device
     (void)hipGetLastError();
-    (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, st);
+    (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, tail_ok, st);
   }
+  if (tail_ok)  // exits at once for clouds that finished in the first kernel
+    emd_tail_launch(b, n, xyz1, dist, assignment, eps, iters, sbase, emd_knobs().tail_delta * eps, st);
   return check_launch("mvp_emd_forward");
 }
 

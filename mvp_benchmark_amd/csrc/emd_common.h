@@ -1,0 +1,253 @@
+// Shared device helpers of the EMD auction kernels (emd.hip: the clustered head
+// kernel; emd_tail.hip: the single-workgroup tail kernel).  See emd.hip for the
+// design notes and the reference citations.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace mvp {
+
+constexpr int kEmdThreads = 1024;
+constexpr int kEmdWaves = kEmdThreads / kWave;
+constexpr int kMaxG = 12;
+constexpr int kMaxCells = kMaxG * kMaxG * kMaxG;  // 1728
+constexpr int kBidCache = 1024;  // list positions whose bid is cached in LDS
+constexpr int kRecCap = 512;     // list positions whose person record is cached in LDS
+#ifndef MVP_EMD_ROWMIN
+#define MVP_EMD_ROWMIN 96
+#endif
+constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 bidders share a wave
+constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
+constexpr int kMaxCluster = 8;   // workgroups per cloud (W)
+constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
+constexpr int kSoloMax = 16;     // unassigned persons below which one workgroup finishes the auction alone
+constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens of seconds), then abort
+// The tail of the auction (emd_tail.hip): once at most kTailCap persons are
+// unassigned (their number never grows) the clustered kernel hands the cloud to
+// a single-workgroup kernel that keeps the prices in LDS.  Clouds of more than
+// kTailMaxN points (prices would not fit) finish in the clustered kernel.
+constexpr int kTailCap = 256;
+constexpr int kTailMaxN = 16384;
+constexpr int kTailK = 16;        // candidates cached per person
+constexpr int kCacheRec = 128;    // bytes of a person's candidate cache in scratch
+
+// Filter slack.  An object is skipped only if
+//   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
+// which implies sqrtf(s) + price > (3 - B2) + kMargin - 7e-7, hence the exact
+// value  float(3.0 - sqrtf(s) - price) <= (3 - sqrtf(s) - price) + 1.3e-7
+// < B2: the object can change neither best, second best nor (being strictly
+// below B2 <= B1) the tie-broken best index.  A cell is skipped with the same
+// test on (squared distance to its bounding box, price lower bound); because
+// float subtraction/multiply/fma are monotone, every member's own test value
+// is >= the cell's, so a skipped cell contains only skippable objects.
+constexpr float kMargin = 1e-5f;
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+// Per-person record (32 B): two 16-byte halves.
+//   lo = {qx, qy, qz, -}                         the person's point (xyz1)
+//   hi = {bid, prev1, prev2, bits(bidinc)}       slot it last bid on, best /
+//        second-best slot of that bid (seed hints), increment of that bid
+// Per-object auction state (16 B), next to the object's float4 {x,y,z,price}:
+//   {key lo, key hi, owner (-1 = free), -}
+//   key = ord(max bid increment this round) << 32 | (winning bidder + 1); 0 = no bid
+struct EmdScratch {
+  float4 *obj;     // (n) cell-sorted x, y, z, price of xyz2
+  int4 *ostate;    // (n) per slot
+  float4 *person;  // (2n) per person: lo, hi
+  int *perm;       // (n) slot -> original object index
+  int *ulist;      // (W x 2n) ping-pong unassigned lists, one pair per workgroup
+  u64 *chg;        // (W x kChgCap) {cell, bits(price bound)} broadcast per round
+  int *cstart;     // (kMaxCells + 4) cell offsets of the cell-sorted order (for the tail kernel)
+  char *cache;     // (n x kCacheRec, n <= kTailMaxN only) candidate cache per person:
+                   //   u16 slot[16] | f32 sqrt-distance[16] | f32 tau | i32 count | pad
+};
+
+// Hand-over record of a cloud (head kernel -> tail kernel), one per cloud after
+// the barrier granules.  next_it == 0: nothing to resume.
+struct EmdResume {
+  int next_it;     // first round the tail kernel runs
+  int utot;        // persons still unassigned (= entries of `list`)
+  int g;           // grid geometry (same arithmetic in both kernels)
+  float lox, loy, loz, invh;
+  int pad;
+  int list[kTailCap];
+};
+
+__host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
+  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg + cstart (+ caches)
+  return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8 + (size_t)(kMaxCells + 4) * 4 +
+         (n <= kTailMaxN ? (size_t)n * kCacheRec : 0);
+}
+// After the per-cloud areas: 256 B of barrier granules per cloud, then the
+// hand-over records, then the per-cloud statistics {rounds, bids} (last, read by
+// bench.py).  Zeroed by the host before the launch.
+constexpr size_t kEmdTailPerCloud = 256 + sizeof(EmdResume) + 16;
+
+__device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
+  EmdScratch s;
+  s.obj = reinterpret_cast<float4 *>(base);
+  s.ostate = reinterpret_cast<int4 *>(base + (size_t)n * 16);
+  s.person = reinterpret_cast<float4 *>(base + (size_t)n * 32);
+  s.perm = reinterpret_cast<int *>(base + (size_t)n * 64);
+  s.ulist = reinterpret_cast<int *>(base + (size_t)n * 68);
+  s.chg = reinterpret_cast<u64 *>(base + (size_t)n * (68 + 8 * kMaxCluster));
+  s.cstart = reinterpret_cast<int *>(base + (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8);
+  s.cache = reinterpret_cast<char *>(s.cstart + (kMaxCells + 4));
+  return s;
+}
+
+// Order-preserving map float -> unsigned (and back); never 0 for a non-NaN.
+__device__ __forceinline__ unsigned emd_f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float emd_ord2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+// A bidder with increment bi competes for an object whose maximal increment
+// is mi (emd_cuda.cu:188).
+__device__ __forceinline__ bool emd_in_band(float bi, float mi) {
+  return (double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6;
+}
+// `old` = the object's key before this bidder's atomic max.  True if a
+// DIFFERENT increment close enough to compete was already bid (the test is
+// wider than the band: false alarms only cost the explicit GetMax pass).
+__device__ __forceinline__ bool emd_band_alarm(u64 old, float inc) {
+  if (old == 0ull) return false;
+  const float mo = emd_ord2f((unsigned)(old >> 32));
+  const double d = (double)mo - (double)inc;
+  return mo != inc && d <= 2e-6 && d >= -2e-6;
+}
+
+// Reference merge order between two candidates (ORIGINAL object indices) of
+// equal value: lexicographically smaller (thread_in_unass, tile, k) wins.
+__device__ __forceinline__ bool emd_precedes(int ka, int kb, int n, int tpu) {
+  const int tile_a = ka >> 11, tile_b = kb >> 11;
+  const int kka = ka & 2047, kkb = kb & 2047;
+  const int end_a = min(n - (tile_a << 11), 2048);
+  const int end_b = min(n - (tile_b << 11), 2048);
+  const int ta = kka / ((end_a + tpu - 1) / tpu);
+  const int tb = kkb / ((end_b + tpu - 1) / tpu);
+  if (ta != tb) return ta < tb;
+  if (tile_a != tile_b) return tile_a < tile_b;
+  return kka < kkb;
+}
+
+__device__ __forceinline__ float emd_value(float s, float p) {
+  return (float)(3.0 - (double)__builtin_sqrtf(s) - (double)p);
+}
+// the same value from the already rounded distance d = sqrtf(s)
+__device__ __forceinline__ float emd_value_d(float d, float p) {
+  return (float)(3.0 - (double)d - (double)p);
+}
+
+// Wave-uniform running state of one bid.
+struct BidState {
+  float b1, b2;  // best / second-best value
+  int bk, b2k;   // their slots (b2k is only a seed hint)
+  float tm;      // filter threshold: <= fl(fl(3 - b2) + kMargin)
+};
+
+// Fold the candidates flagged in `mask` (exact value v and slot k per lane)
+// into the uniform state, lowest lane first.
+// dl > 0 (tail kernel): the filter is kept dl looser than the second best
+// needs, so that everything within dl of it is seen (candidate cache).
+__device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
+                                         float v, int k, int n, int tpu,
+                                         const int *__restrict__ perm, float dl = 0.f) {
+  while (mask) {
+    const int l = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const float vl =
+        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    const int kl = __builtin_amdgcn_readlane(k, l);
+    if (vl > st.b1) {
+      st.b2 = st.b1;
+      st.b2k = st.bk;
+      st.b1 = vl;
+      st.bk = kl;
+    } else if (vl == st.b1) {
+      st.b2 = st.b1;
+      if (emd_precedes(perm[kl], perm[st.bk], n, tpu)) {
+        st.b2k = st.bk;
+        st.bk = kl;
+      } else {
+        st.b2k = kl;
+      }
+    } else if (vl > st.b2) {
+      st.b2 = vl;
+      st.b2k = kl;
+    }
+  }
+  // thresholds only ever tighten (the seed may already be tighter)
+  st.tm = __builtin_fminf(st.tm, (3.0f - (st.b2 - dl)) + kMargin);
+}
+
+__device__ __forceinline__ void top2_insert(float &a1, float &a2, float v) {
+  const float lo = __builtin_fminf(a1, v);
+  a1 = __builtin_fmaxf(a1, v);
+  a2 = __builtin_fmaxf(a2, lo);
+}
+
+// DPP move with an identity fill for lanes the control/row mask does not write.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float identity, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v),
+                                                    CTRL, ROW_MASK, 0xF, false));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void top2_dpp_step(float &a1, float &a2) {
+  const float o1 = dpp_f32<CTRL, ROW_MASK>(-1e9f, a1);
+  const float o2 = dpp_f32<CTRL, ROW_MASK>(-1e9f, a2);
+  const float lo = __builtin_fminf(a1, o1);
+  a1 = __builtin_fmaxf(a1, o1);
+  a2 = __builtin_fmaxf(lo, __builtin_fmaxf(a2, o2));
+}
+
+// Second-largest value (with multiplicity) over the wave's per-lane (a1, a2)
+// top-2 pairs, using DPP row operations only; every step merges disjoint lane
+// sets, masked-out lanes merge with the identity (-1e9, -1e9).  Valid in lane
+// 63, returned wave-uniform.
+__device__ __forceinline__ float wave_second_largest(float a1, float a2) {
+  top2_dpp_step<0xB1, 0xF>(a1, a2);   // quad_perm [1,0,3,2]
+  top2_dpp_step<0x4E, 0xF>(a1, a2);   // quad_perm [2,3,0,1]
+  top2_dpp_step<0x141, 0xF>(a1, a2);  // row_half_mirror
+  top2_dpp_step<0x140, 0xF>(a1, a2);  // row_mirror
+  top2_dpp_step<0x142, 0xA>(a1, a2);  // row_bcast15 -> rows 1, 3
+  top2_dpp_step<0x143, 0xC>(a1, a2);  // row_bcast31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 63));
+}
+
+// Largest and second-largest (with multiplicity) of the wave's per-lane values.
+__device__ __forceinline__ void wave_top2(float v, float &b1, float &b2) {
+  float a1 = v, a2 = -1e9f;
+  top2_dpp_step<0xB1, 0xF>(a1, a2);
+  top2_dpp_step<0x4E, 0xF>(a1, a2);
+  top2_dpp_step<0x141, 0xF>(a1, a2);
+  top2_dpp_step<0x140, 0xF>(a1, a2);
+  top2_dpp_step<0x142, 0xA>(a1, a2);
+  top2_dpp_step<0x143, 0xC>(a1, a2);
+  b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), 63));
+  b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 63));
+}
+
+struct GridGeom {
+  float lox, loy, loz, invh;
+  int g;
+};
+
+__device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
+                                        float z) {
+  const int ix = min(gg.g - 1, max(0, (int)((x - gg.lox) * gg.invh)));
+  const int iy = min(gg.g - 1, max(0, (int)((y - gg.loy) * gg.invh)));
+  const int iz = min(gg.g - 1, max(0, (int)((z - gg.loz) * gg.invh)));
+  return (iz * gg.g + iy) * gg.g + ix;
+}
+
+}  // namespace mvp

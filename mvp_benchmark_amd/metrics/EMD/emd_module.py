@@ -11,12 +11,24 @@ Gradient flows to xyz1 only (emd_module.py:73-81).
 The reference allocates 11 scratch tensors per call (:54-65); here one byte
 buffer of mvp_emd_scratch_bytes(B, n) is enough and its initial contents do
 not matter.  Shape guards raise instead of printf + ignored return code.
+
+Failure contract: if the kernel abandons a cluster wait (never observed; needs
+the workgroups of one cloud not to be co-resident for tens of seconds) the
+cloud's `dist` is NaN and its `assignment` -1, so every metric derived from it
+is NaN instead of silently wrong; backward skips such entries (zero gradient).
+Set `emd_module.CHECK_STATUS = True` to have every forward read the per-cloud
+status words back (one host synchronisation) and raise MvpOpsError instead.
 """
 import torch
 from torch import nn
 from torch.autograd import Function
 
-from ..._lib import call, emd_scratch_bytes
+from ..._lib import MvpOpsError, call, emd_scratch_bytes
+
+# True: every forward reads the kernel's per-cloud status words back (a host
+# synchronisation) and raises MvpOpsError on an abandoned cloud.  Off by default:
+# the failure is visible anyway (NaN distances, see the module docstring).
+CHECK_STATUS = False
 
 
 class emdFunction(Function):
@@ -43,6 +55,12 @@ class emdFunction(Function):
 
         call("mvp_emd_forward", device, batchsize, n, xyz1, xyz2, dist,
              assignment, eps, iters, scratch, nbytes)
+
+        if CHECK_STATUS:   # debug aid: one device->host read per call
+            rounds = scratch[nbytes - batchsize * 16:].view(torch.int64).view(batchsize, 2)[:, 0]
+            if bool((rounds < 0).any()):
+                raise MvpOpsError("mvp_emd_forward abandoned %d cloud(s) (status %s)"
+                                  % (int((rounds < 0).sum()), rounds[rounds < 0].tolist()))
 
         ctx.save_for_backward(xyz1, xyz2, assignment)
         ctx.mark_non_differentiable(assignment)

@@ -126,6 +126,26 @@ def emd_forward(xyz1, xyz2, eps, iters, return_stats=False):
     return dist, assignment
 
 
+def emd_forward_ex(xyz1, xyz2, eps, iters, getmax_lowest=False):
+    """emd_forward with the GetMax schedule choice exposed and the number of
+    unassigned persons at the start of every round -> (dist, assignment,
+    stats (b,2), trace (b,iters))."""
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, _ = xyz1.shape
+    assert xyz2.shape[1] == n and xyz2.shape[0] == b
+    dist = np.zeros((b, n), np.float32)
+    assignment = np.zeros((b, n), np.int32) - 1
+    stats = np.zeros((b, 2), np.int64)
+    trace = np.zeros((b, int(iters)), np.int32)
+    fn = lib().orc_emd_forward_ex
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p,
+                   ctypes.c_float, ctypes.c_int, _i64p, ctypes.c_int, _i32p]
+    _check(fn(b, n, _pf(xyz1), _pf(xyz2), _pf(dist), _pi(assignment),
+              ctypes.c_float(eps), int(iters), stats.ctypes.data_as(_i64p),
+              int(bool(getmax_lowest)), _pi(trace)), "emd_forward_ex")
+    return dist, assignment, stats, trace
+
+
 def emd_backward(xyz1, xyz2, graddist, assignment):
     """emdFunction.backward, emd_module.py:73-81 (gradient to xyz1 only)."""
     xyz1, xyz2, g, a = _f(xyz1), _f(xyz2), _f(graddist), _i(assignment)

@@ -166,11 +166,20 @@ def test_emd_matches_oracle_bit_exact(oracle, b, n, eps, iters):
 
 
 @pytest.fixture
-def cluster_width(monkeypatch):
-    """Pins how many workgroups own one cloud (MVP_EMD_CLUSTER, read per call)."""
-    def pin(w):
-        monkeypatch.setenv("MVP_EMD_CLUSTER", str(w))
-    return pin
+def cluster_width():
+    """Pins how many workgroups own one cloud (mvp_emd_configure; automatic again afterwards)."""
+    from mvp_benchmark_amd import _lib
+    yield lambda w: _lib.emd_configure(cluster=w)
+    _lib.emd_configure(cluster=0)
+
+
+@pytest.fixture
+def emd_variant():
+    """Selects the auction variant: tail kernel on / off, candidate-cache width
+    (mvp_emd_configure); defaults restored afterwards."""
+    from mvp_benchmark_amd import _lib
+    yield lambda tail, delta: _lib.emd_configure(tail=tail, tail_delta=delta)
+    _lib.emd_configure(tail=1, tail_delta=5.0)
 
 
 @pytest.mark.parametrize("width", [1, 2, 4, 8])
@@ -192,6 +201,56 @@ def test_emd_every_cluster_width_matches_oracle(oracle, cluster_width, width, ki
         x2, eps, iters = np.tile(rand_clouds(16, 1, 256, 3), (1, 8, 1)), 0.005, 300
     dist, ass = emd()(dev(x1), dev(x2), eps, iters)
     od, oa = oracle.emd_forward(x1, x2, eps, iters)
+    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
+@pytest.mark.parametrize("variant", ["no_tail", "tail_no_cache", "tail_cache_narrow", "tail_cache_default", "tail_cache_wide"])
+@pytest.mark.parametrize("kind", ["uniform", "duplicates", "few_rounds_left", "last_round_forced"])
+def test_emd_tail_kernel_variants_match_oracle(oracle, emd_variant, cluster_width, variant, kind):
+    """The rounds after <= 256 persons are unassigned run in emd_tail_kernel
+    (prices in LDS, exact per-person candidate caches).  Every variant -- no
+    hand-over at all, hand-over without caches, narrow / default / wide caches
+    (hit rates from ~30 % to ~75 %) -- must give the oracle's bits: assignment
+    and distances.  `duplicates` forces value ties inside the caches (tie order
+    on original indices); `few_rounds_left` hands over two rounds before the end;
+    `last_round_forced` ends with persons still unassigned (forced assignment,
+    emd_cuda.cu:201)."""
+    from mvp_benchmark_amd.metrics import emd
+    tail, delta = {"no_tail": (0, 5.0), "tail_no_cache": (1, 0.0), "tail_cache_narrow": (1, 1.0),
+                   "tail_cache_default": (1, 5.0), "tail_cache_wide": (1, 20.0)}[variant]
+    emd_variant(tail, delta)
+    if kind == "uniform":
+        x1, x2, eps, iters = rand_clouds(31, 3, 4096, 3), rand_clouds(32, 3, 4096, 3), 0.004, 3000
+    elif kind == "duplicates":
+        x1 = np.tile(rand_clouds(33, 2, 512, 3), (1, 4, 1))
+        x2, eps, iters = np.tile(rand_clouds(34, 2, 256, 3), (1, 8, 1)), 0.005, 1500
+    elif kind == "few_rounds_left":
+        x1, x2, eps, iters = rand_clouds(35, 2, 2048, 3), rand_clouds(36, 2, 2048, 3), 0.004, 0
+    else:
+        x1, x2, eps, iters = rand_clouds(37, 2, 2048, 3), rand_clouds(38, 2, 2048, 3), 0.002, 400
+    if kind == "few_rounds_left":
+        # hand-over = first round that starts with <= 256 unassigned persons (oracle trace)
+        trace = oracle.emd_forward_ex(x1, x2, eps, 3000)[3]
+        handover = max(int(np.argmax(row <= 256)) for row in trace)
+        assert 0 < handover < 2900
+        iters = handover + 2
+    if kind == "last_round_forced":
+        assert oracle.emd_forward_ex(x1, x2, eps, iters)[3][:, -1].min() > 0   # persons left for the forced round
+    dist, ass = emd()(dev(x1), dev(x2), eps, iters)
+    od, oa = oracle.emd_forward(x1, x2, eps, iters)
+    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
+def test_emd_headline_cloud_matches_oracle(oracle):
+    """One cloud pair of the headline shape (16384 points, eps 0.004, 3000
+    rounds) against the exhaustive oracle, bit for bit: clustered kernel for the
+    first ~150 rounds, tail kernel for the rest.  (~70 s of CPU per cloud.)"""
+    from mvp_benchmark_amd.metrics import emd
+    x1, x2 = rand_clouds(41, 2, 16384, 3), rand_clouds(42, 2, 16384, 3)
+    dist, ass = emd()(dev(x1), dev(x2), 0.004, 3000)
+    od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
     np.testing.assert_array_equal(ass.cpu().numpy(), oa)
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
 

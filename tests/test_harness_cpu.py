@@ -211,6 +211,142 @@ def test_two_rank_gloo_val_and_ddp_step(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "best_cd_t_network.pth"))   # rank 0 wrote it
 
 
+class _BranchyNet(torch.nn.Module):
+    """A model with a branch that never contributes to the loss -- the shape of
+    MSAP_SKN_decoder at cfgs/vrcnet.yaml (num_fps == num_coarse == num_points:
+    conv_s1..3, expansion2, conv_f1..2 get no gradient)."""
+
+    def __init__(self):
+        super().__init__()
+        self.used = torch.nn.Linear(3, 3)
+        self.unused = torch.nn.Linear(3, 3)
+
+    def forward(self, x, gt=None, prefix="train", alpha=None):
+        pred = self.used(x.transpose(2, 1))
+        loss = ((pred - gt[:, :pred.shape[1]]) ** 2).mean(dim=(1, 2))
+        return pred, loss, loss.mean()
+
+
+def _worker_unused(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, COMPLETION)
+    import train
+    from dataset import SyntheticMVP
+    from train_utils import AttrDict, AverageValueMeter, init_distributed, unwrap
+    torch.manual_seed(0)
+    r, w, device = init_distributed("gloo")
+    net = train.wrap_ddp(_BranchyNet(), device, w)
+    assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+    opt = torch.optim.SGD(unwrap(net).parameters(), lr=0.05)
+    ds = SyntheticMVP("train", num_shapes=1, num_points=2048)
+    args = AttrDict(batch_size=8, workers=0)
+    scale = train.loss_scale(args, w)
+    assert scale == 2.0 and train.loss_scale(AttrDict(ddp_grad_scale="mean"), w) == 1.0
+    loader, _ = train.make_loader(ds, args, r, w, shuffle=False)          # 13 samples per rank -> 4 steps
+    train.train_one_epoch(net, opt, loader, device, 1.0, AverageValueMeter(), scale=scale)
+    q.put((rank, [p.detach().numpy().tolist() for p in unwrap(net).parameters()]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_ddp_with_unused_parameters_and_sum_gradient():
+    """a plain DDP wrapper dies in the second step when a branch gets
+    no gradient (cfgs/vrcnet.yaml does that); train.wrap_ddp must survive several
+    steps.  Also pins the gradient convention: loss * world under DDP's average ==
+    the reference's sum over replicas (train.py:141 backward(ones(ngpu)))."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_unused, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(out[0][1], out[1][1]):
+        assert a == b
+    # single-process replay of the reference's rule: per step, sum over the two replicas'
+    # mean losses (each replica = one rank's batch of 4)
+    import train
+    from dataset import SyntheticMVP
+    from train_utils import AttrDict
+    torch.manual_seed(0)
+    net = _BranchyNet()
+    unused_before = [p.detach().clone() for p in net.unused.parameters()]
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    ds = SyntheticMVP("train", num_shapes=1, num_points=2048)
+    loaders = [train.make_loader(ds, AttrDict(batch_size=8, workers=0), r, 2, shuffle=False)[0] for r in range(2)]
+    for (_, x0, g0), (_, x1, g1) in zip(*loaders):
+        opt.zero_grad()
+        total = sum(net(x.float().transpose(2, 1).contiguous(), g.float())[2] for x, g in ((x0, g0), (x1, g1)))
+        total.backward()
+        opt.step()
+    for a, b in zip(out[0][1], net.parameters()):
+        assert torch.allclose(torch.tensor(a), b.detach(), rtol=1e-5, atol=1e-6)
+    for a, b in zip(unused_before, net.unused.parameters()):
+        assert torch.equal(a, b.detach())
+
+
+def _worker_test_entry(rank, world, port, tmp, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, COMPLETION)
+    import test as test_entry
+    import train
+    from train_utils import init_distributed
+    init_distributed("gloo")
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", "pcn.yaml"))
+    args.update(batch_size=4, data_dir=os.path.join(tmp, "data"), load_model=os.path.join(tmp, "network.pth"),
+                step_interval_to_print=1000)
+    res = test_entry.test(args, tmp)
+    q.put((rank, None if res is None else res.shape))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_test_entry_writes_results_h5_in_dataset_order(tmp_path):
+    """completion/test.py:23-64 sharded over two ranks: MVP_ExtraTest_Shuffled_CP.h5
+    (written + read through the HDF5 layer) -> PCN prefix="test" -> results.h5 /
+    `results` with the clouds in dataset order, padding dropped (5 clouds over 2
+    ranks), submission.zip next to it."""
+    import zipfile
+    import h5lite
+    import train
+    from models import pcn
+    from train_utils import save_model
+    rng = np.random.default_rng(5)
+    partial = rng.random((5, 2048, 3), dtype=np.float32)
+    os.makedirs(tmp_path / "data")
+    with h5lite.File(str(tmp_path / "data" / "MVP_ExtraTest_Shuffled_CP.h5"), "w") as f:
+        f.create_dataset("incomplete_pcds", data=partial)
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", "pcn.yaml"))
+    torch.manual_seed(11)
+    net = pcn.Model(args).eval()
+    save_model(str(tmp_path / "network.pth"), net)
+    with torch.no_grad():
+        want = net(torch.from_numpy(partial).transpose(2, 1).contiguous(), prefix="test")["result"].numpy()
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_test_entry, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0] == (5, 2048, 3) and out[1] is None
+    with h5lite.File(str(tmp_path / "results.h5"), "r") as f:
+        got = f["results"][()]
+    assert got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    with zipfile.ZipFile(str(tmp_path / "submission.zip")) as z:
+        assert z.namelist() == ["results.h5"]
+
+
 def test_models_state_dict_layout_matches_reference():
     """Names and shapes of every parameter of PCN / ECG / VRCNet equal the
     reference models' (tests/golden/model_state_keys.json, recorded from the
