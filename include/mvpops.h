@@ -105,9 +105,10 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * is pinned to the highest qualifying bidder index.
  * Two launches: a persistent cooperative kernel in which up to 8 workgroups
  * share a cloud when b leaves CUs free (b*W <= CU count), and -- for n <= 16384
- * -- a single-workgroup kernel that takes a cloud over once at most 256 persons
- * are unassigned (prices in LDS, exact per-person candidate caches; exits at
- * once for clouds that were finished before).  The call enqueues one small
+ * -- a second kernel that takes a cloud over once at most 256 persons are
+ * unassigned (every workgroup of the cloud keeps the prices in LDS, exact
+ * per-person candidate caches, one all-gather per round; exits at once for
+ * clouds that were finished before).  The call enqueues one small
  * memset (barrier words, hand-over records, statistics) ahead of them.
  * If a cluster wait is abandoned (members not co-resident for tens of seconds;
  * never seen) dist is filled with NaN, assignment with -1 and the statistics
@@ -124,8 +125,11 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
  *   tail        0: no hand-over to the single-workgroup tail kernel
  *   tail_delta  width of the candidate caches in units of eps (0: no caches)
+ *   tail_cluster 0 = as the first kernel, or 1|2|4|8: cap of the tail kernel's
+ *               workgroups per cloud
  * Results never depend on these (every variant is bit-identical). */
-int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail_delta);
+int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail_delta,
+                      int tail_cluster);
 
 /* Replaces emd.backward = emd_backward (emd.cpp:22-25,30) ->
  * emd_cuda_backward (emd_cuda.cu:302-316) -> NmDistanceGradKernel (:284-300).
@@ -314,6 +318,19 @@ long long mvp_pointwise_wgrad_scratch_bytes(int b, int cin, int cout, int len);
 int mvp_pointwise_wgrad(int b, int cin, int cout, int len, const float *x,
                         const float *gy, float *gw, float *gb, void *scratch,
                         long long scratch_bytes, void *stream);
+
+/* ------------------------------------------------ registration (DCP) head */
+
+/* Replaces the per-sample loop of SVDHead.forward
+ * (registration/models/dcp.py:360-373, registration/model_utils.py:229-240):
+ *   u, s, v = torch.svd(H[i]); r = v @ u.T; if det(r) < 0: r = (v @ diag(1,1,-1)) @ u.T
+ * for all b matrices in one launch, no host synchronisation.
+ * H (b,3,3) row-major -> R (b,3,3) the rotation (reflection fix applied);
+ * optional (may be NULL): U (b,3,3), S (b,3) descending, V (b,3,3) with
+ * H = U diag(S) V^T (V WITHOUT the fix), flipped (b) = 1 where the fix applied.
+ * One-sided Jacobi in float64 per matrix, outputs rounded to float32. */
+int mvp_kabsch_svd3(int b, const float *H, float *R, float *U, float *S,
+                    float *V, int *flipped, void *stream);
 
 #ifdef __cplusplus
 }

@@ -43,11 +43,15 @@ SIGNATURES = {
     "mvp_share_weighted_sum": "iiiiippp",
     "mvp_share_weighted_sum_grad": "iiiiippppp",
     "mvp_pointwise_wgrad": "iiiipppppq",
+    "mvp_kabsch_svd3": "ipppppp",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
 ABI_VERSION = 6   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+
+# defaults of mvp_emd_configure's knobs (csrc/emd.hip: emd_knobs)
+EMD_DEFAULT_TAIL, EMD_DEFAULT_TAIL_DELTA = 0, 3.0
 
 _lib = None
 
@@ -73,7 +77,7 @@ def load():
     lib.mvp_emd_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_emd_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_emd_configure.restype = ctypes.c_int
-    lib.mvp_emd_configure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+    lib.mvp_emd_configure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
     lib.mvp_fps_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_fps_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_chamfer_scratch_bytes.restype = ctypes.c_longlong
@@ -130,10 +134,10 @@ def emd_scratch_bytes(b, n):
     return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
 
 
-def emd_configure(cluster=-1, same_xcd=-1, tail=-1, tail_delta=-1.0):
+def emd_configure(cluster=-1, same_xcd=-1, tail=-1, tail_delta=-1.0, tail_cluster=-1):
     """Process-wide tuning knobs of mvp_emd_forward (negative = unchanged;
-    cluster=0 = automatic).  Results do not depend on them."""
-    rc = load().mvp_emd_configure(int(cluster), int(same_xcd), int(tail), float(tail_delta))
+    cluster / tail_cluster = 0: automatic).  Results do not depend on them."""
+    rc = load().mvp_emd_configure(int(cluster), int(same_xcd), int(tail), float(tail_delta), int(tail_cluster))
     if rc != MVP_OK:
         raise MvpOpsError("mvp_emd_configure: %s" % _ERR.get(rc, rc))
 

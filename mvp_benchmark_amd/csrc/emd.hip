@@ -63,51 +63,8 @@
 
 namespace mvp {
 
-// All-gather of two 32-bit payloads among the W workgroups of a cluster; also
-// the cluster's barrier.  Every global store the workgroup issued before the
-// call is complete (acknowledged write-through) before its granules are
-// published.  Granule = one aligned 8-byte {epoch, payload} written by ONE
-// sc1 store and polled with sc1 loads: the data is the flag.  Slots are
-// double-buffered by epoch parity (a workgroup can be at most one epoch ahead
-// of the slowest reader).  Returns false when the wait was abandoned.
-template <int W, bool DRAIN = true>
-__device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned epoch,
-                                                   const int *p0, const int *p1,
-                                                   unsigned *s_gout, int *s_abort, bool same_xcd = false) {
-  // DRAIN = false: nothing stored since the last gather has to be visible to
-  // the other workgroups before the NEXT draining gather
-  if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x < kWave) {
-    const int lane = threadIdx.x;
-    u64 *base = slots + (size_t)(epoch & 1u) * (2 * W);
-    if (lane < 2) {
-      const unsigned pv = (unsigned)(lane == 0 ? *p0 : *p1);
-      if (same_xcd)  // the pollers share this XCD's L2: no need to write through
-        __hip_atomic_store(base + 2 * wg + lane, ((u64)epoch << 32) | pv, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
-      else
-        __hip_atomic_store(base + 2 * wg + lane, ((u64)epoch << 32) | pv, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    u64 x = (u64)epoch << 32;
-    bool done = false;
-    for (unsigned spins = 0; spins < kSpinLimit; ++spins) {
-      if (lane < 2 * W)
-        x = __hip_atomic_load(base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      done = __all((unsigned)(x >> 32) == epoch);
-      if (done) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (lane < 2 * W) s_gout[lane] = (unsigned)x;
-    if (!done && lane == 0) *s_abort = 1;
-  }
-  __syncthreads();
-  return *s_abort == 0;
-}
-
 // emd_tail.hip
-void emd_tail_launch(int b, int n, const float *xyz1, float *dist, int *assignment, float eps, int iters,
+void emd_tail_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps, int iters,
                      char *scratch, float delta, hipStream_t stream);
 
 template <int W>
@@ -122,11 +79,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   if (cloud >= b) return;
   char *cbase = scratch + (size_t)cloud * emd_scratch_per_cloud(n);
   char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
-  u64 *slots = reinterpret_cast<u64 *>(tail + (size_t)cloud * 256);
+  u64 *slots = emd_granules(tail, b, cloud, 0);
   // per-cloud auction statistics {rounds executed, bids made} (read by
   // bench.py; not part of the op's result)
-  EmdResume *resume = reinterpret_cast<EmdResume *>(tail + (size_t)b * 256) + cloud;
-  long long *stats = reinterpret_cast<long long *>(tail + (size_t)b * (256 + sizeof(EmdResume))) + 2 * (size_t)cloud;
+  EmdResume *resume = emd_resume(tail, b, cloud);
+  long long *stats = emd_stats(tail, b, cloud);
   const int t = threadIdx.x;
   const int lane = t & (kWave - 1);
   const int wave = t >> 6;
@@ -1390,17 +1347,19 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
 //   MVP_EMD_SAME_XCD=0        keep the write-through stores even when a cluster shares an XCD
 //   MVP_EMD_TAIL=0            no hand-over to the tail kernel (the clustered kernel runs every round)
 //   MVP_EMD_TAIL_DELTA=<x>    candidate-cache width in units of eps (0: no caches)
+//   MVP_EMD_TAIL_CLUSTER=1|2|4|8  cap of the tail kernel's workgroups per cloud
 struct EmdKnobs {
-  int cluster, same_xcd, tail;
+  int cluster, same_xcd, tail, tail_cluster;
   float tail_delta;
 };
 static EmdKnobs &emd_knobs() {
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 1, 5.f};
+    EmdKnobs v{kMaxCluster, 1, 0, 0, 3.f};  // tail kernel off by default: not faster yet
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
     if (const char *e = getenv("MVP_EMD_TAIL")) v.tail = atoi(e) != 0;
     if (const char *e = getenv("MVP_EMD_TAIL_DELTA")) v.tail_delta = (float)atof(e);
+    if (const char *e = getenv("MVP_EMD_TAIL_CLUSTER")) v.tail_cluster = atoi(e);
     return v;
   }();
   return k;
@@ -1416,6 +1375,16 @@ static int emd_cluster_width(int b) {
   const int want = emd_knobs().cluster;
   int w = 1;
   while (w * 2 <= want && w * 2 <= kMaxCluster && (long long)b * w * 2 <= cus) w *= 2;
+  return w;
+}
+
+// Workgroups per cloud of the tail kernel: the clustered kernel's width unless
+// MVP_EMD_TAIL_CLUSTER = 1|2|4|8 caps it.
+static int emd_tail_width(int b, int head_w) {
+  const int cap = emd_knobs().tail_cluster;
+  int w = head_w;
+  while (cap > 0 && w > cap) w /= 2;
+  (void)b;
   return w;
 }
 
@@ -1446,7 +1415,7 @@ extern "C" long long mvp_emd_scratch_bytes(int b, int n) {
   return (long long)b * ((long long)emd_scratch_per_cloud(n) + (long long)kEmdTailPerCloud);
 }
 
-extern "C" int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail_delta) {
+extern "C" int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail_delta, int tail_cluster) {
   EmdKnobs &k = emd_knobs();
   if (cluster >= 0) {
     if (cluster != 0 && cluster != 1 && cluster != 2 && cluster != 4 && cluster != 8) return MVP_EBADARG;
@@ -1455,6 +1424,11 @@ extern "C" int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail
   if (same_xcd >= 0) k.same_xcd = same_xcd != 0;
   if (tail >= 0) k.tail = tail != 0;
   if (tail_delta >= 0.f) k.tail_delta = tail_delta;
+  if (tail_cluster >= 0) {
+    if (tail_cluster != 0 && tail_cluster != 1 && tail_cluster != 2 && tail_cluster != 4 && tail_cluster != 8)
+      return MVP_EBADARG;
+    k.tail_cluster = tail_cluster;
+  }
   return MVP_OK;
 }
 
@@ -1488,7 +1462,7 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
     (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, tail_ok, st);
   }
   if (tail_ok)  // exits at once for clouds that finished in the first kernel
-    emd_tail_launch(b, n, xyz1, dist, assignment, eps, iters, sbase, emd_knobs().tail_delta * eps, st);
+    emd_tail_launch(b, n, emd_tail_width(b, w), xyz1, dist, assignment, eps, iters, sbase, emd_knobs().tail_delta * eps, st);
   return check_launch("mvp_emd_forward");
 }
 

@@ -83,10 +83,20 @@ __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
   return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8 + (size_t)(kMaxCells + 4) * 4 +
          (n <= kTailMaxN ? (size_t)n * kCacheRec : 0);
 }
-// After the per-cloud areas: 256 B of barrier granules per cloud, then the
-// hand-over records, then the per-cloud statistics {rounds, bids} (last, read by
-// bench.py).  Zeroed by the host before the launch.
-constexpr size_t kEmdTailPerCloud = 256 + sizeof(EmdResume) + 16;
+// After the per-cloud areas ("tail" of the scratch buffer, zeroed by the host
+// before the launch): 256 B of barrier granules per cloud for the clustered
+// kernel, 256 B per cloud for the tail kernel, the hand-over records, then the
+// per-cloud statistics {rounds, bids} (last: read by bench.py).
+constexpr size_t kEmdTailPerCloud = 256 + 256 + sizeof(EmdResume) + 16;
+__host__ __device__ inline unsigned long long *emd_granules(char *tail, int b, int cloud, int which) {
+  return reinterpret_cast<unsigned long long *>(tail + (size_t)which * b * 256 + (size_t)cloud * 256);
+}
+__host__ __device__ inline EmdResume *emd_resume(char *tail, int b, int cloud) {
+  return reinterpret_cast<EmdResume *>(tail + (size_t)b * 512) + cloud;
+}
+__host__ __device__ inline long long *emd_stats(char *tail, int b, int cloud) {
+  return reinterpret_cast<long long *>(tail + (size_t)b * (512 + sizeof(EmdResume))) + 2 * (size_t)cloud;
+}
 
 __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
   EmdScratch s;
@@ -248,6 +258,49 @@ __device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
   const int iy = min(gg.g - 1, max(0, (int)((y - gg.loy) * gg.invh)));
   const int iz = min(gg.g - 1, max(0, (int)((z - gg.loz) * gg.invh)));
   return (iz * gg.g + iy) * gg.g + ix;
+}
+
+// All-gather of two 32-bit payloads among the W workgroups of a cluster; also
+// the cluster's barrier.  Every global store the workgroup issued before the
+// call is complete (acknowledged write-through) before its granules are
+// published.  Granule = one aligned 8-byte {epoch, payload} written by ONE
+// sc1 store and polled with sc1 loads: the data is the flag.  Slots are
+// double-buffered by epoch parity (a workgroup can be at most one epoch ahead
+// of the slowest reader).  Returns false when the wait was abandoned.
+template <int W, bool DRAIN = true>
+__device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned epoch,
+                                                   const int *p0, const int *p1,
+                                                   unsigned *s_gout, int *s_abort, bool same_xcd = false) {
+  // DRAIN = false: nothing stored since the last gather has to be visible to
+  // the other workgroups before the NEXT draining gather
+  if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < kWave) {
+    const int lane = threadIdx.x;
+    u64 *base = slots + (size_t)(epoch & 1u) * (2 * W);
+    if (lane < 2) {
+      const unsigned pv = (unsigned)(lane == 0 ? *p0 : *p1);
+      if (same_xcd)  // the pollers share this XCD's L2: no need to write through
+        __hip_atomic_store(base + 2 * wg + lane, ((u64)epoch << 32) | pv, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+      else
+        __hip_atomic_store(base + 2 * wg + lane, ((u64)epoch << 32) | pv, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    u64 x = (u64)epoch << 32;
+    bool done = false;
+    for (unsigned spins = 0; spins < kSpinLimit; ++spins) {
+      if (lane < 2 * W)
+        x = __hip_atomic_load(base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      done = __all((unsigned)(x >> 32) == epoch);
+      if (done) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane < 2 * W) s_gout[lane] = (unsigned)x;
+    if (!done && lane == 0) *s_abort = 1;
+  }
+  __syncthreads();
+  return *s_abort == 0;
 }
 
 }  // namespace mvp

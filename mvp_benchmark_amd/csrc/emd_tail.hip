@@ -11,18 +11,26 @@
 // In the clustered kernel such a round costs ~40k cycles: every bid is two
 // dependent L2 round trips on state other CUs write, and a round is closed by
 // two cross-CU all-gathers.  Here:
-//   * one workgroup owns the cloud: barriers are s_barrier, nothing is shared
-//     with another CU, so there are no write-through stores, L1 bypasses or
-//     all-gathers on the round's critical path;
 //   * the PRICES (the only state a bid reads besides the static coordinates)
 //     live in LDS (n <= 16384 floats), together with the cell index: per cell
 //     one 16-byte record {fp16 bounding box rounded outwards, price lower
-//     bound} -- one ds_read_b128 per cell test;
+//     bound} -- one ds_read_b128 per cell test.  A bid touches no state that
+//     another CU writes;
+//   * W workgroups (1, 2, 4 or 8, as in the clustered kernel) share a cloud
+//     WITHOUT sharing that state: each keeps its own full copy of the prices
+//     and cell bounds in its LDS and bids for its own part of the unassigned
+//     persons; the round's bids (16 bytes each, <= 256 per cloud) are exchanged
+//     through memory behind ONE all-gather, and every workgroup then resolves
+//     all of them and applies all price rises to its own copy -- redundant,
+//     deterministic, identical.  One cross-CU synchronisation per round instead
+//     of two, no write-through stores or L1 bypasses on a bid's path;
 //   * the unassigned persons sit in a pool of kTailCap LDS entries {point,
 //     hints, candidate cache}.  An entry is stable: a loser keeps it, a winner
-//     hands it to the person it evicted (at most one), so the pool never grows
-//     and needs no allocation; an order list of the live entries is rebuilt by
-//     ballot each round;
+//     hands it to the person it evicted (at most one), so a member's pool never
+//     grows and needs no allocation; an order list of the live entries is
+//     rebuilt by ballot each round.  With W > 1 a pool holds <= 128 entries and
+//     the OWNER of every object is replicated in LDS too (u16), so finding the
+//     evicted person is an LDS read instead of a cross-CU round trip;
 //   * exact CANDIDATE CACHE per person.  Values v_k = 3 - d_k - price_k only
 //     fall (prices only rise).  A full search keeps its filter `delta` looser
 //     than the second-best value needs and so sees EVERY object within delta
@@ -39,15 +47,19 @@
 //     bids for its object: maximal increment, then the highest bidder inside
 //     the reference's 1e-6 band, emd_cuda.cu:181-194) -- no atomics, no alarm
 //     pass.
-// A bid that misses its cache is one wave: cell enumeration from LDS, then ONE
-// global round trip for the coordinates of the surviving cells' members (static
-// data, plain cached loads), prices from LDS.
+// Bid phase A: every bidder's cache is tried, four bidders per wave (a 16-lane
+// row each: 16 cached candidates).  Phase B: the misses, one wave each, drawn
+// from a list so that the expensive searches spread over the 16 waves: cell
+// enumeration from LDS, then ONE global round trip for the coordinates of the
+// surviving cells' members (static data, plain cached loads), prices from LDS.
+// Inside a round the phases are separated by bare s_barrier (LDS traffic only);
+// global stores are only waited for at the all-gather.
 #include "emd_common.h"
 
 namespace mvp {
 
 constexpr int kTailCells = 1331;  // 11^3: n <= 16384 objects give g <= 11 (emd.hip: (g+1)^3 * 12 <= n)
-constexpr int kStage = 64;        // candidates a search can stage for the cache (more: no cache this time)
+constexpr int kStage = 48;        // candidates a search can stage for the cache (more: no cache this time)
 
 // fp16 bounds of a float, rounded outwards (box lo down, box hi up), as bits
 __device__ __forceinline__ unsigned half_bits_down(float x) {
@@ -79,29 +91,40 @@ __device__ __forceinline__ int quad_i32(int v) {
   return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
 }
 
+// LDS-only phase boundary: this wave's LDS traffic has landed, then s_barrier.
+// Global stores are NOT waited for (they are drained at the all-gather).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
-    int b, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment, float eps,
+    int b, int bpad, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment, float eps,
     int iters, char *scratch, float delta) {
-  const int cloud = blockIdx.x;
+  constexpr int POOL = W == 1 ? kTailCap : kTailCap / 2;  // entries a member can hold (they never grow)
+  constexpr bool LOWN = W > 1;                             // owners replicated in LDS
+  // block -> (cloud, member) as in the clustered kernel: members bpad blocks apart share an XCD
+  const int cloud = W == 1 ? (int)blockIdx.x : (int)blockIdx.x % bpad;
+  const int wg = W == 1 ? 0 : (int)blockIdx.x / bpad;
+  if (cloud >= b) return;
   const size_t per_cloud = emd_scratch_per_cloud(n);
   char *cbase = scratch + (size_t)cloud * per_cloud;
   char *tail = scratch + (size_t)b * per_cloud;
-  EmdResume *resume = reinterpret_cast<EmdResume *>(tail + (size_t)b * 256) + cloud;
-  long long *stats = reinterpret_cast<long long *>(tail + (size_t)b * (256 + sizeof(EmdResume))) + 2 * (size_t)cloud;
+  EmdResume *resume = emd_resume(tail, b, cloud);
+  long long *stats = emd_stats(tail, b, cloud);
+  u64 *slots = emd_granules(tail, b, cloud, 1);
   const int it0 = resume->next_it;
-  if (it0 == 0) return;  // the cloud was finished by the first kernel (block-uniform)
+  if (it0 == 0) return;  // the cloud was finished by the first kernel (uniform over the cluster)
 
   const int t = threadIdx.x;
   const int lane = t & (kWave - 1);
   const int wave = t >> 6;
+  const int row = lane >> 4, l16 = lane & 15, rsh = row * 16;
   xyz1 += (size_t)cloud * n * 3;
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
   const EmdScratch sc = emd_carve(cbase, n);
 
-  // Mutable global state (owners, assignment, person records, caches) is read
-  // with L1-bypassing loads and written through: one workgroup is the only
-  // reader and writer, but its waves must see each other's stores.
+  // Mutable global state (assignment, person records, caches, exchanged bids; owners when
+  // W == 1) is read with L1-bypassing loads and written through.
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, (int)per_cloud, 0x00020000);
   const unsigned off_person = (unsigned)n * 32u;
   const unsigned off_cache = (unsigned)(reinterpret_cast<char *>(sc.cache) - cbase);
@@ -109,25 +132,49 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
   auto stg16 = [&](v4u v, unsigned byte_off) { __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16); };
   auto ld_i32 = [&](int *p) -> int { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto st_i32 = [&](int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // The round's bids travel through the (dead) unassigned lists of the first kernel:
+  // 16 bytes {object, bits(increment), person, second-best hint} per bid, per member, by round parity.
+  const unsigned off_xb = (unsigned)n * 68u;
+  auto xb_off = [&](int parity, int w, int i) -> unsigned {
+    return off_xb + (unsigned)((parity * kMaxCluster + w) * kTailCap + i) * 16u;
+  };
 
   __shared__ float s_price[kTailMaxN];
+  __shared__ unsigned short s_owner[LOWN ? kTailMaxN : 2];       // 0xFFFF: free
+  __shared__ unsigned s_owned[LOWN ? 2 : kTailMaxN / 32];        // W == 1: bit per object "has an owner"
   __shared__ uint4 s_cell[kTailCells + 1];  // {half2 x lo|hi, half2 y, half2 z, bits(price lower bound)}
-  __shared__ int c_start[kTailCells + 1];
+  __shared__ unsigned short c_start[kTailCells + 3];
   // the pool of unassigned persons
-  __shared__ float4 e_q[kTailCap];                              // the person's point
-  __shared__ int4 e_i[kTailCap];                                // {person, hint slot 1, hint slot 2, cached candidates}
-  __shared__ __attribute__((aligned(16))) unsigned short e_cs[kTailCap][kTailK];  // cached slots
-  __shared__ __attribute__((aligned(16))) float e_cd[kTailCap][kTailK];           // their sqrtf distances
-  __shared__ float e_tau[kTailCap];                             // >= value of every object NOT cached
-  __shared__ unsigned char e_live[kTailCap];
-  __shared__ unsigned short s_order[kTailCap];                  // live entries, ascending
-  // this round's bids by list position
-  __shared__ int s_bo[kTailCap], s_b2k[kTailCap], s_bj[kTailCap], s_be[kTailCap];
-  __shared__ float s_binc[kTailCap];
-  __shared__ unsigned short w_list[kEmdWaves][256];             // surviving cells of a search
-  __shared__ int st_slot[kEmdWaves][kStage];                    // staged candidates of a search
+  __shared__ float4 e_q[POOL];                              // the person's point
+  __shared__ int4 e_i[POOL];                                // {person, hint slot 1, hint slot 2, cached candidates}
+  __shared__ __attribute__((aligned(16))) unsigned short e_cs[POOL][kTailK];  // cached slots
+  __shared__ __attribute__((aligned(16))) float e_cd[POOL][kTailK];           // their sqrtf distances
+  __shared__ float e_tau[POOL];                             // >= value of every object NOT cached
+  __shared__ unsigned char e_live[POOL];
+  __shared__ unsigned short s_order[POOL];                  // live entries, ascending
+  __shared__ unsigned short s_miss[POOL];                   // list positions whose cache failed
+  __shared__ float s_seed[POOL];                            // ... and the seed their cache gives
+  __shared__ int s_be[POOL];                                // own bids: the bidder's entry
+  // this round's bids of the whole cloud
+  __shared__ __attribute__((aligned(16))) int s_bo[kTailCap];
+  __shared__ int s_b2k[kTailCap], s_bj[kTailCap];
+  __shared__ __attribute__((aligned(16))) float s_binc[kTailCap];
+  __shared__ unsigned char s_win[kTailCap];                 // 0 lost, 1 won a free object, 2 won an owned one
+  __shared__ unsigned short s_prevo[LOWN ? kTailCap : 2];   // owner of the bid's object before this round
+  __shared__ int s_gcnt[LOWN ? kTailCap : 2];                // bids on the object a bid represents
+  __shared__ unsigned s_gmax[LOWN ? kTailCap : 2];           // ... and their maximal increment (ordered bits)
+  __shared__ unsigned short w_list[kEmdWaves][128];         // surviving cells of a search
+  __shared__ int st_slot[kEmdWaves][kStage];                // staged candidates of a search
   __shared__ float st_v[kEmdWaves][kStage], st_d[kEmdWaves][kStage];
-  __shared__ int s_next, s_err, s_U, s_wcnt[4];
+  __shared__ int s_next, s_nmiss, s_err, s_U, s_nfree, s_abort, s_wcnt[4];
+  __shared__ unsigned s_gout[2 * kMaxCluster];
+#ifdef MVP_EMD_PROFILE
+  // [0] hits [1] misses [3] cycles in misses [4] linear scans [5] sum nsub [6] sum cells visited [8] home-cell seeds [11] visit cycles
+  __shared__ unsigned long long s_prof[16];
+  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0ull;
+  long long cyc_a = 0, cyc_b = 0, cyc_gather = 0, cyc_resolve = 0, cyc_assign = 0, cyc_compact = 0,
+            cyc_setup = __builtin_readcyclecounter();
+#endif
 
   GridGeom gg;
   gg.g = resume->g;
@@ -143,14 +190,28 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
   }
 
   // ------------------------------------------------------------ load the state
-  for (int c = t; c <= ncell; c += kEmdThreads) c_start[c] = sc.cstart[c];
-  for (int s = t; s < n; s += kEmdThreads) s_price[s] = sc.obj[s].w;
-  if (t < kTailCap) {
-    const bool live = t < U0;
+  for (int c = t; c <= ncell; c += kEmdThreads) c_start[c] = (unsigned short)sc.cstart[c];
+  for (int s = t; s < n; s += kEmdThreads) {  // n % 1024 == 0: whole waves
+    s_price[s] = sc.obj[s].w;
+    const int ow = sc.ostate[s].z;
+    if constexpr (LOWN) {
+      s_owner[s] = (unsigned short)(ow < 0 ? 0xFFFF : ow);
+    } else {
+      const unsigned long long om = __ballot(ow != -1);
+      if (lane == 0) {
+        s_owned[(s >> 6) * 2] = (unsigned)om;
+        s_owned[(s >> 6) * 2 + 1] = (unsigned)(om >> 32);
+      }
+    }
+  }
+  // member wg takes the list positions wg, wg + W, ...
+  const int myU0 = (U0 - wg + W - 1) / W;
+  if (t < POOL) {
+    const bool live = t < myU0;
     e_live[t] = live ? 1 : 0;
     s_order[t] = (unsigned short)t;
     if (live) {
-      const int j = resume->list[t];
+      const int j = resume->list[t * W + wg];
       const float4 lo = sc.person[2 * j];
       const float4 hi = sc.person[2 * j + 1];
       e_q[t] = lo;
@@ -159,8 +220,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
   }
   if (t == 0) {
     s_next = kEmdWaves;
+    s_nmiss = 0;
     s_err = resume->pad;
-    s_U = U0;
+    s_U = myU0;
+    s_abort = 0;
   }
   __syncthreads();
   // cell records: exact box of the members, rounded outwards to fp16; cheapest member
@@ -187,260 +250,307 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
   }
   __syncthreads();
 
+#ifdef MVP_EMD_PROFILE
+  cyc_setup = __builtin_readcyclecounter() - cyc_setup;
+#endif
   // ------------------------------------------------------------ the rounds
   const int block_cnt = n / 1024;
   const bool caching = delta > 0.f;
   long long n_rounds = 0, n_bids = 0;
-  int U = U0;
+  int U = myU0;      // this member's bidders
+  int Utot = U0;     // the cloud's
+  unsigned epoch = 0;
+  bool aborted = false;
   for (int it = it0; it < iters; ++it) {
-    if (U == 0) break;
+    if (Utot == 0) break;
     n_rounds += 1;
     n_bids += U;
     const bool last = it == iters - 1;
     // thread_per_unass of the reference (emd_cuda.cu:107-109): fixes the tie order only
-    const int upb = (U + block_cnt - 1) / block_cnt;
+    const int upb = (Utot + block_cnt - 1) / block_cnt;
     const int tpu = 1024 / upb;
+    // a bid of this member, list position u: W == 1 straight into the round's arrays, else to memory
+    auto record_bid = [&](int u, int bk, float inc, int j, int b2k) {
+      if constexpr (W == 1) {
+        s_bo[u] = bk;
+        s_b2k[u] = b2k;
+        s_binc[u] = inc;
+        s_bj[u] = j;
+      } else {
+        v4u r;
+        r.x = (unsigned)bk;
+        r.y = __float_as_uint(inc);
+        r.z = (unsigned)j;
+        r.w = (unsigned)b2k;
+        stg16(r, xb_off(it & 1, wg, u));
+      }
+    };
 
-    // ---------------- Bid (emd_cuda.cu:95-179): one wave per bidder, drawn from a counter
-    int u = wave;
-    for (int guard = 0; guard <= kTailCap && u < U; ++guard) {
+#ifdef MVP_EMD_PROFILE
+    const long long tp0 = __builtin_readcyclecounter();
+#endif
+    // ---------------- Bid, phase A: the cached candidates at today's prices, four bidders per
+    // wave (one per 16-lane row).  Exact when the best is > tau and the second best >= tau
+    // (every object outside the cache is worth <= tau); a tie for the best goes to the search.
+    for (int ub = 0; ub < U; ub += 4 * kEmdWaves) {
+      const int u = ub + wave * 4 + row;
+      const bool act = u < U;
+      int e = 0, cc = 0, j = -1;
+      if (act) {
+        e = s_order[u];
+        const int4 rb = e_i[e];
+        j = rb.x;
+        cc = rb.w;
+      }
+      float v = -1e9f;
+      int slot = -1;
+      const bool mine = act && l16 < cc;
+      if (mine) {
+        slot = e_cs[e][l16];
+        v = emd_value_d(e_cd[e][l16], s_price[slot]);
+      }
+      float c1 = v, c2 = -1e9f;
+      top2_dpp_step<0xB1, 0xF>(c1, c2);   // butterfly inside the row: every lane ends with
+      top2_dpp_step<0x4E, 0xF>(c1, c2);   // the row's (largest, second largest with multiplicity)
+      top2_dpp_step<0x141, 0xF>(c1, c2);
+      top2_dpp_step<0x140, 0xF>(c1, c2);
+      const float tau = act ? e_tau[e] : 0.f;
+      const unsigned rm1 = (unsigned)((__ballot(mine && v == c1) >> rsh) & 0xFFFFull);
+      const unsigned rm2a = (unsigned)((__ballot(mine && v == c2) >> rsh) & 0xFFFFull);
+      const bool hit = act && cc >= 2 && c2 >= tau && c1 > tau && __builtin_popcount(rm1) == 1;
+      const int l1 = rm1 ? __builtin_ctz(rm1) : 0;
+      const unsigned rm2 = rm2a & ~(1u << l1);
+      const int l2 = rm2 ? __builtin_ctz(rm2) : l1;
+      const int bk = __shfl(slot, rsh + l1, kWave);
+      const int k2 = __shfl(slot, rsh + l2, kWave);
+      if (act && l16 == 0) {
+        if (hit) {
+          record_bid(u, bk, c1 - c2 + eps, j, rm2 ? k2 : -1);
+          s_be[u] = e;
+        } else {
+          const int pos = atomicAdd(&s_nmiss, 1);
+          s_miss[pos] = (unsigned short)u;
+          s_seed[u] = cc >= 2 ? c2 : -1e9f;  // two distinct real objects reach it: bounds the final second best
+        }
+      }
+    }
+    lds_barrier();
+#ifdef MVP_EMD_PROFILE
+    const long long tpa = __builtin_readcyclecounter();
+#endif
+
+    // ---------------- Bid, phase B (emd_cuda.cu:95-179): the misses, one wave each, drawn from
+    // a counter so that the searches spread over the waves
+    const int nmiss = s_nmiss;
+    int mi = wave;
+    for (int guard = 0; guard <= POOL && mi < nmiss; ++guard) {
+      const int u = s_miss[mi];
       const int e = s_order[u];
       const float4 ra = e_q[e];
       const int4 rb = e_i[e];
-      const int j = rb.x, p1 = rb.y, p2 = rb.z, cc = rb.w;
+      const int j = rb.x, p1 = rb.y, p2 = rb.z;
       const float qx = ra.x, qy = ra.y, qz = ra.z;
-      float b1 = 0.f, b2 = 0.f, seed_b2 = -1e9f;
-      int bk = -1, b2k = -1;
-      bool hit = false;
-
-      // (0) the cached candidates, re-evaluated at today's prices
-      if (cc > 0) {
-        float v = -1e9f;
-        int slot = -1;
-        if (lane < cc) {
-          slot = e_cs[e][lane];
-          v = emd_value_d(e_cd[e][lane], s_price[slot]);
+      float seed_b2 = s_seed[u];
+#ifdef MVP_EMD_PROFILE
+      const long long tb0 = __builtin_readcyclecounter();
+      long long tvis = 0;
+      int pcells = 0, plin = 0, pnsub = 0, phome = 0;
+#endif
+      // (1) seed: without a usable cache, the second-largest exact value among the home
+      // cell's members and the previous best / second best
+      if (seed_b2 == -1e9f) {
+#ifdef MVP_EMD_PROFILE
+        phome = 1;
+#endif
+        const int c0 = emd_cell(gg, qx, qy, qz);
+        float a1 = -1e9f, a2 = -1e9f;
+        const int s0 = c_start[c0], s1 = c_start[c0 + 1];
+        for (int s = s0 + lane; s < s1; s += kWave) {
+          const float4 o = sc.obj[s];
+          top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), s_price[s]));
         }
-        float c1, c2;
-        wave_top2(v, c1, c2);
-        const float tau = e_tau[e];
-        if (cc >= 2) seed_b2 = c2;  // two distinct real objects reach it: a bound of the final second best
-        if (cc >= 2 && c2 >= tau && c1 > tau) {
-          // every object outside the cache is worth <= tau: best and second best are in it
-          hit = true;
-          b1 = c1;
-          b2 = c2;
-          const unsigned long long m1 = __ballot(v == c1);
-          const int l1 = __builtin_ctzll(m1);
-          bk = __builtin_amdgcn_readlane(slot, l1);
-          if (m1 & (m1 - 1)) {  // several best: the reference's order on ORIGINAL indices
-            int bo = sc.perm[bk];
-            unsigned long long mm = m1 & (m1 - 1);
-            while (mm) {
-              const int l = __builtin_ctzll(mm);
-              mm &= mm - 1;
-              const int kl = __builtin_amdgcn_readlane(slot, l);
-              const int ol = sc.perm[kl];
-              if (emd_precedes(ol, bo, n, tpu)) {
-                b2k = bk;
-                bk = kl;
-                bo = ol;
-              } else {
-                b2k = kl;
-              }
-            }
-          } else {
-            const unsigned long long m2 = __ballot(v == c2) & ~(1ull << l1);
-            b2k = m2 ? __builtin_amdgcn_readlane(slot, __builtin_ctzll(m2)) : -1;
+        bool extra = false;
+        if ((lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0)) {
+          const int ps = lane == 0 ? p1 : p2;
+          const float4 o = sc.obj[ps];
+          if (emd_cell(gg, o.x, o.y, o.z) != c0) {
+            extra = true;
+            top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), s_price[ps]));
           }
         }
+        const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
+        if (have < 2) {  // wave-uniform; rare: the first 64 slots (distinct objects)
+          const float4 o = sc.obj[lane];
+          a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), s_price[lane]);
+          a2 = -1e9f;
+        }
+        seed_b2 = wave_second_largest(a1, a2);
       }
+      BidState st;
+      st.b1 = -1e9f;
+      st.b2 = -1e9f;
+      st.bk = -1;
+      st.b2k = -1;
+      // the filter admits everything within delta of the second best (emd_common.h, kMargin,
+      // with B2 := fl(b2 - delta)): what it skips is worth < b2 - delta
+      st.tm = (3.0f - (seed_b2 - delta)) + kMargin;
+      int nst = 0;  // staged candidates (wave-uniform)
 
-      if (!hit) {
-        // (1) seed: without a usable cache, the second-largest exact value among
-        // the home cell's members and the previous best / second best
-        if (seed_b2 == -1e9f) {
-          const int c0 = emd_cell(gg, qx, qy, qz);
-          float a1 = -1e9f, a2 = -1e9f;
-          const int s0 = c_start[c0], s1 = c_start[c0 + 1];
-          for (int s = s0 + lane; s < s1; s += kWave) {
-            const float4 o = sc.obj[s];
-            top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), s_price[s]));
-          }
-          bool extra = false;
-          if ((lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0)) {
-            const int ps = lane == 0 ? p1 : p2;
-            const float4 o = sc.obj[ps];
-            if (emd_cell(gg, o.x, o.y, o.z) != c0) {
-              extra = true;
-              top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), s_price[ps]));
+      // evaluate one object per lane: filter, stage for the cache, fold what can matter
+      auto consider = [&](bool valid, int s, const float4 &o) {
+        const float p = valid ? s_price[s] : 0.f;
+        const float sd = sqdist3(o.x - qx, o.y - qy, o.z - qz);
+        const float tq = st.tm - p;
+        const bool ps = valid && tq >= 0.f && sd <= tq * tq;
+        const unsigned long long m = __ballot(ps);
+        if (m) {
+          const float d = __builtin_sqrtf(sd);
+          const float v = emd_value_d(d, p);
+          if (caching) {
+            const int pos = nst + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (ps && pos < kStage) {
+              st_slot[wave][pos] = s;
+              st_v[wave][pos] = v;
+              st_d[wave][pos] = d;
             }
+            nst += __builtin_popcountll(m);
           }
-          const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
-          if (have < 2) {  // wave-uniform; rare: the first 64 slots (distinct objects)
-            const float4 o = sc.obj[lane];
-            a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), s_price[lane]);
-            a2 = -1e9f;
-          }
-          seed_b2 = wave_second_largest(a1, a2);
+          const unsigned long long mf = __ballot(ps && v >= st.b2);
+          if (mf) emd_fold(st, mf, v, s, n, tpu, sc.perm, delta);
         }
-        BidState st;
-        st.b1 = -1e9f;
-        st.b2 = -1e9f;
-        st.bk = -1;
-        st.b2k = -1;
-        // the filter admits everything within delta of the second best (emd_common.h, kMargin,
-        // with B2 := fl(b2 - delta)): what it skips is worth < b2 - delta
-        st.tm = (3.0f - (seed_b2 - delta)) + kMargin;
-        int nst = 0;  // staged candidates (wave-uniform)
+      };
 
-        // evaluate one object per lane: filter, stage for the cache, fold what can matter
-        auto consider = [&](bool valid, int s, const float4 &o) {
-          const float p = valid ? s_price[s] : 0.f;
-          const float sd = sqdist3(o.x - qx, o.y - qy, o.z - qz);
-          const float tq = st.tm - p;
-          const bool ps = valid && tq >= 0.f && sd <= tq * tq;
-          const unsigned long long m = __ballot(ps);
-          if (m) {
-            const float d = __builtin_sqrtf(sd);
-            const float v = emd_value_d(d, p);
-            if (caching) {
-              const int pos = nst + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-              if (ps && pos < kStage) {
-                st_slot[wave][pos] = s;
-                st_v[wave][pos] = v;
-                st_d[wave][pos] = d;
-              }
-              nst += __builtin_popcountll(m);
-            }
-            const unsigned long long mf = __ballot(ps && v >= st.b2);
-            if (mf) emd_fold(st, mf, v, s, n, tpu, sc.perm, delta);
-          }
-        };
-
-        // (2) cells intersecting the cube |o - q|_inf <= tm (prices >= 0), 64 per step
-        int ix0, iy0, iz0, nx, ny, nz;
-        {
-          const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
-          const float fx = (qx - gg.lox) * gg.invh;
-          const float fy = (qy - gg.loy) * gg.invh;
-          const float fz = (qz - gg.loz) * gg.invh;
-          const float gm = (float)(gg.g - 1);
-          ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
-          iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
-          iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
-          nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
-          ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
-          nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
-          ix0 = __builtin_amdgcn_readfirstlane(ix0);
-          iy0 = __builtin_amdgcn_readfirstlane(iy0);
-          iz0 = __builtin_amdgcn_readfirstlane(iz0);
-          nx = __builtin_amdgcn_readfirstlane(nx);
-          ny = __builtin_amdgcn_readfirstlane(ny);
-          nz = __builtin_amdgcn_readfirstlane(nz);
-        }
-        const int nxy = nx * ny;
-        const int nsub = nxy * nz;
-        const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
-        const int sub = lane >> 4, sl = lane & 15;
-        unsigned short *wl = w_list[wave];
-        int nlist = 0;
-        // (3) visit listed cells, 16 per step (a 16-lane row takes 4 cells): 4 independent
-        // coordinate loads per lane in flight, prices from LDS
-        auto visit = [&]() {
-          for (int k0 = 0; k0 < nlist; k0 += 16) {
-            int s[4], s1[4];
+      // (2) cells intersecting the cube |o - q|_inf <= tm (prices >= 0), 64 per step
+      int ix0, iy0, iz0, nx, ny, nz;
+      {
+        const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
+        const float fx = (qx - gg.lox) * gg.invh;
+        const float fy = (qy - gg.loy) * gg.invh;
+        const float fz = (qz - gg.loz) * gg.invh;
+        const float gm = (float)(gg.g - 1);
+        ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
+        iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
+        iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
+        nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
+        ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
+        nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
+        ix0 = __builtin_amdgcn_readfirstlane(ix0);
+        iy0 = __builtin_amdgcn_readfirstlane(iy0);
+        iz0 = __builtin_amdgcn_readfirstlane(iz0);
+        nx = __builtin_amdgcn_readfirstlane(nx);
+        ny = __builtin_amdgcn_readfirstlane(ny);
+        nz = __builtin_amdgcn_readfirstlane(nz);
+      }
+      const int nxy = nx * ny;
+      const int nsub = nxy * nz;
+      const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
+      unsigned short *wl = w_list[wave];
+      int nlist = 0;
+      // (3) visit listed cells, 16 per step (a 16-lane row takes 4 cells): 4 independent
+      // coordinate loads per lane in flight, prices from LDS
+      auto visit = [&]() {
+#ifdef MVP_EMD_PROFILE
+        const long long tv0 = __builtin_readcyclecounter();
+        pcells += nlist;
+#endif
+        for (int k0 = 0; k0 < nlist; k0 += 16) {
+          int s[4], s1[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int k = k0 + r * 4 + sub;
-              s[r] = 0;
-              s1[r] = 0;
-              if (k < nlist) {
-                const int cc2 = wl[k];
-                s[r] = c_start[cc2] + sl;
-                s1[r] = c_start[cc2 + 1];
-              }
-            }
-            bool more = true;
-            while (more) {
-              float4 o[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = s[r] < s1[r] ? sc.obj[s[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) consider(s[r] < s1[r], s[r], o[r]);
-              bool mine = false;  // cells with more than 16 members (rare): next 16
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                s[r] += 16;
-                mine |= s[r] < s1[r];
-              }
-              more = __any(mine);
+          for (int r = 0; r < 4; ++r) {
+            const int k = k0 + r * 4 + row;
+            s[r] = 0;
+            s1[r] = 0;
+            if (k < nlist) {
+              const int cc2 = wl[k];
+              s[r] = c_start[cc2] + l16;
+              s1[r] = c_start[cc2 + 1];
             }
           }
-          nlist = 0;
-        };
-        // a search cube covering most of the grid: scan the cell-sorted objects linearly
-        const bool linear = 2 * nsub > ncell;
-        if (linear) {
-          for (int base = 0; base < n; base += 4 * kWave) {  // n % 1024 == 0
+          bool more = true;
+          while (more) {
             float4 o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = sc.obj[base + r * kWave + lane];
+            for (int r = 0; r < 4; ++r) o[r] = s[r] < s1[r] ? sc.obj[s[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) consider(true, base + r * kWave + lane, o[r]);
+            for (int r = 0; r < 4; ++r) consider(s[r] < s1[r], s[r], o[r]);
+            bool again = false;  // cells with more than 16 members (rare): next 16
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s[r] += 16;
+              again |= s[r] < s1[r];
+            }
+            more = __any(again);
           }
         }
-        for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
-          const int i = cb + lane;
-          bool cpass = false;
-          int c = 0;
-          if (i < nsub) {
-            // exact small-integer division via float (i < 1331, divisors <= 121)
-            const int kz = (int)(((float)i + 0.5f) * inv_nxy);
-            const int rem = i - kz * nxy;
-            const int ky = (int)(((float)rem + 0.5f) * inv_nx);
-            const int kx = rem - ky * nx;
-            c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
-            const uint4 cr = s_cell[c];
-            const float dx = __builtin_fmaxf(
-                __builtin_fmaxf(half_bits_to_float(cr.x & 0xFFFFu) - qx, qx - half_bits_to_float(cr.x >> 16)), 0.f);
-            const float dy = __builtin_fmaxf(
-                __builtin_fmaxf(half_bits_to_float(cr.y & 0xFFFFu) - qy, qy - half_bits_to_float(cr.y >> 16)), 0.f);
-            const float dz = __builtin_fmaxf(
-                __builtin_fmaxf(half_bits_to_float(cr.z & 0xFFFFu) - qz, qz - half_bits_to_float(cr.z >> 16)), 0.f);
-            const float tq = st.tm - __uint_as_float(cr.w);
-            cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
-          }
-          const unsigned long long cmask = __ballot(cpass);
-          if (cpass) wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
-          nlist += __builtin_popcountll(cmask);
-          if (nlist > 256 - kWave) visit();  // keep room for the next 64
+        nlist = 0;
+#ifdef MVP_EMD_PROFILE
+        tvis += __builtin_readcyclecounter() - tv0;
+#endif
+      };
+      // a search cube covering most of the grid: scan the cell-sorted objects linearly
+      const bool linear = 2 * nsub > ncell;
+#ifdef MVP_EMD_PROFILE
+      plin = linear ? 1 : 0;
+      pnsub = nsub;
+#endif
+      if (linear) {
+        for (int base = 0; base < n; base += 4 * kWave) {  // n % 1024 == 0
+          float4 o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = sc.obj[base + r * kWave + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) consider(true, base + r * kWave + lane, o[r]);
         }
-        visit();
-
-        if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
-          if (lane == 0) s_err = 1;
-          st.bk = 0;
-          st.b2k = -1;
+      }
+      for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
+        const int i = cb + lane;
+        bool cpass = false;
+        int c = 0;
+        if (i < nsub) {
+          // exact small-integer division via float (i < 1331, divisors <= 121)
+          const int kz = (int)(((float)i + 0.5f) * inv_nxy);
+          const int rem = i - kz * nxy;
+          const int ky = (int)(((float)rem + 0.5f) * inv_nx);
+          const int kx = rem - ky * nx;
+          c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
+          const uint4 cr = s_cell[c];
+          const float dx = __builtin_fmaxf(
+              __builtin_fmaxf(half_bits_to_float(cr.x & 0xFFFFu) - qx, qx - half_bits_to_float(cr.x >> 16)), 0.f);
+          const float dy = __builtin_fmaxf(
+              __builtin_fmaxf(half_bits_to_float(cr.y & 0xFFFFu) - qy, qy - half_bits_to_float(cr.y >> 16)), 0.f);
+          const float dz = __builtin_fmaxf(
+              __builtin_fmaxf(half_bits_to_float(cr.z & 0xFFFFu) - qz, qz - half_bits_to_float(cr.z >> 16)), 0.f);
+          const float tq = st.tm - __uint_as_float(cr.w);
+          cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
         }
-        bk = st.bk;
-        b2k = st.b2k;
-        b1 = st.b1;
-        b2 = st.b2;
+        const unsigned long long cmask = __ballot(cpass);
+        if (cpass) wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
+        nlist += __builtin_popcountll(cmask);
+        if (nlist > 128 - kWave) visit();  // keep room for the next 64
+      }
+      visit();
 
-        // (4) rebuild the cache from the staged candidates
-        if (caching) {
-          float tau = st.b2 - delta;  // everything the search skipped is worth less
-          int newcc = 0;
-          if (nst <= kStage) {
-            const bool have = lane < nst;
-            const float v = have ? st_v[wave][lane] : -1e9f;
-            const int slot = have ? st_slot[wave][lane] : 0;
-            const float d = have ? st_d[wave][lane] : 0.f;
-            const bool keep = have && v >= tau;
-            const unsigned long long km = __ballot(keep);
-            const int kc = __builtin_popcountll(km);
-            int rank = 0;  // position in descending value order (ties: lower lane first)
+      if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
+        if (lane == 0) s_err = 1;
+        st.bk = 0;
+        st.b2k = -1;
+      }
+
+      // (4) rebuild the cache from the staged candidates
+      if (caching) {
+        float tau = st.b2 - delta;  // everything the search skipped is worth less
+        int newcc = 0;
+        if (nst <= kStage) {
+          const bool have = lane < nst;
+          const float v = have ? st_v[wave][lane] : -1e9f;
+          const int slot = have ? st_slot[wave][lane] : 0;
+          const float d = have ? st_d[wave][lane] : 0.f;
+          const bool keep = have && v >= tau;
+          const unsigned long long km = __ballot(keep);
+          const int kc = __builtin_popcountll(km);
+          int rank = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+          if (kc > kTailK) {  // the best kTailK stay (descending order; ties: lower lane first); the next bounds the rest
+            rank = 0;
             unsigned long long mm = km;
             while (mm) {
               const int l = __builtin_ctzll(mm);
@@ -448,195 +558,373 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
               const float vl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
               rank += (vl > v || (vl == v && l < lane)) ? 1 : 0;
             }
-            if (kc > kTailK) {  // the best kTailK stay; the next one bounds the rest
-              const unsigned long long mk = __ballot(keep && rank == kTailK);
-              tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_ctzll(mk)));
-            }
-            if (keep && rank < kTailK) {
-              e_cs[e][rank] = (unsigned short)slot;
-              e_cd[e][rank] = d;
-            }
-            newcc = min(kc, kTailK);
+            const unsigned long long mk = __ballot(keep && rank == kTailK);
+            tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_ctzll(mk)));
           }
-          if (lane == 0) {
-            e_tau[e] = tau;
-            e_i[e].w = newcc;
+          if (keep && rank < kTailK) {
+            e_cs[e][rank] = (unsigned short)slot;
+            e_cd[e][rank] = d;
           }
+          newcc = min(kc, kTailK);
+        }
+        if (lane == 0) {
+          e_tau[e] = tau;
+          e_i[e].w = newcc;
         }
       }
-
+#ifdef MVP_EMD_PROFILE
+      if (lane == 0) {
+        atomicAdd(&s_prof[1], 1ull);
+        atomicAdd(&s_prof[3], (unsigned long long)(__builtin_readcyclecounter() - tb0));
+        atomicAdd(&s_prof[4], (unsigned long long)plin);
+        atomicAdd(&s_prof[5], (unsigned long long)pnsub);
+        atomicAdd(&s_prof[6], (unsigned long long)pcells);
+        atomicAdd(&s_prof[8], (unsigned long long)phome);
+        atomicAdd(&s_prof[11], (unsigned long long)tvis);
+      }
+#endif
       int drawn = 0;
       if (lane == 0) {
-        s_bo[u] = bk;
-        s_b2k[u] = b2k;
-        s_binc[u] = b1 - b2 + eps;
-        s_bj[u] = j;
+        record_bid(u, st.bk, st.b1 - st.b2 + eps, j, st.b2k);
         s_be[u] = e;
         drawn = atomicAdd(&s_next, 1);
       }
-      u = __builtin_amdgcn_readlane(drawn, 0);
+      mi = __builtin_amdgcn_readlane(drawn, 0);
     }
-    __syncthreads();
+#ifdef MVP_EMD_PROFILE
+    const long long tpg = __builtin_readcyclecounter();
+    if (t == 0) s_prof[0] += (unsigned long long)(U - nmiss);
+#endif
+    // ---------------- all bids of the round: own ones (W == 1) or everybody's, fetched after
+    // the round's only cross-CU synchronisation
+    int off_me = 0;
+    if constexpr (W > 1) {
+      if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_U, &s_err, s_gout, &s_abort)) {
+        aborted = true;
+        break;
+      }
+      int cnt[W], total = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        cnt[w] = (int)s_gout[2 * w];
+        if (w < wg) off_me += cnt[w];
+        total += cnt[w];
+        if (s_gout[2 * w + 1] != 0u && t == 0) s_err = 1;
+      }
+      if (total != Utot && t == 0) s_err = 1;  // cannot happen: every member tracks the same count
+      if (t < total) {
+        int i = t, w = 0;
+#pragma unroll
+        for (int ww = 0; ww < W - 1; ++ww)
+          if (w == ww && i >= cnt[ww]) {
+            i -= cnt[ww];
+            w = ww + 1;
+          }
+        const v4u r = ldg16(xb_off(it & 1, w, i));
+        s_bo[t] = (int)r.x;
+        s_binc[t] = __uint_as_float(r.y);
+        s_bj[t] = (int)r.z;
+        s_b2k[t] = (int)r.w;
+      }
+    }
+    if (t >= Utot && t < Utot + 4 && t < kTailCap) s_bo[t] = -2;  // padding of the GetMax scan
+    lds_barrier();
+#ifdef MVP_EMD_PROFILE
+    const long long tp1 = __builtin_readcyclecounter();
+#endif
 
-    // ---------------- GetMax + Assign (emd_cuda.cu:181-215): four threads per bidder
-    {
-      const int ub = t >> 2, q4 = t & 3;
-      const bool act = ub < U;
-      int o = -1, j = -1, e = 0;
+    // ---------------- GetMax (emd_cuda.cu:181-194), exactly, for ALL bids of the cloud.  The
+    // winner is the highest bidder inside the 1e-6 band of the object's maximal increment.
+    // W > 1: the bids of one object find each other through the object's owner word in LDS (the
+    // last of them to write its number there represents the group; count and maximal increment
+    // are two LDS atomics on the representative) -- O(1) per bid; W == 1 scans the round's bids.
+    bool r_win = true;
+    int r_prev = -1;
+    if constexpr (LOWN) {
+      const bool mine = t < Utot;
+      int o = 0;
       float inc = 0.f;
-      if (act) {
-        o = s_bo[ub];
-        inc = s_binc[ub];
-        j = s_bj[ub];
-        e = s_be[ub];
+      if (mine) {
+        o = s_bo[t];
+        inc = s_binc[t];
+        r_prev = s_owner[o];           // owner before this round (0xFFFF: free)
+        s_gcnt[t] = 0;
+        s_gmax[t] = 0u;
       }
-      // maximal increment bid on my object, then: am I the highest bidder inside its band?
-      float mi = -1e9f;
-      for (int v = q4; v < U; v += 4)
-        if (s_bo[v] == o) mi = __builtin_fmaxf(mi, s_binc[v]);
-      mi = __builtin_fmaxf(mi, __int_as_float(quad_i32<0xB1>(__float_as_int(mi))));
-      mi = __builtin_fmaxf(mi, __int_as_float(quad_i32<0x4E>(__float_as_int(mi))));
-      int beaten = 0;
-      for (int v = q4; v < U; v += 4)
-        if (s_bo[v] == o && s_bj[v] > j && emd_in_band(s_binc[v], mi)) beaten = 1;
-      beaten |= quad_i32<0xB1>(beaten);
-      beaten |= quad_i32<0x4E>(beaten);
-      const bool win = act && (last || (emd_in_band(inc, mi) && !beaten));
+      lds_barrier();
+      if (mine) s_owner[o] = (unsigned short)(0x8000u | (unsigned)t);  // person ids are < 0x8000
+      lds_barrier();
+      int rep = 0;
+      if (mine) {
+        rep = s_owner[o] & 0x7FFF;
+        atomicAdd(&s_gcnt[rep], 1);
+        atomicMax(&s_gmax[rep], emd_f2ord(inc));
+      }
+      lds_barrier();
+      if (mine) {
+        if (s_gcnt[rep] > 1) {  // rare: several bids on this object
+          const float mxi = emd_ord2f(s_gmax[rep]);
+          const int j = s_bj[t];
+          r_win = emd_in_band(inc, mxi);
+          if (r_win)
+            for (int v = 0; v < Utot; ++v)
+              if (s_bo[v] == o && s_bj[v] > j && emd_in_band(s_binc[v], mxi)) r_win = false;
+        }
+        if (last) r_win = true;
+        s_prevo[t] = (unsigned short)r_prev;
+        s_win[t] = r_win ? (r_prev != 0xFFFF ? 2 : 1) : 0;
+      }
+    } else if (t < Utot) {
+      const int o = s_bo[t], j = s_bj[t];
+      const float inc = s_binc[t];
+      // branch-free scan, four bids per LDS read (the arrays are padded with object -2)
+      float mxi = -1e9f;
+      int same = 0;
+      const int4 *bo4 = reinterpret_cast<const int4 *>(s_bo);
+      const float4 *bi4 = reinterpret_cast<const float4 *>(s_binc);
+      const int n4 = (Utot + 3) >> 2;
+#pragma unroll 4
+      for (int v = 0; v < n4; ++v) {
+        const int4 ov = bo4[v];
+        const float4 iv = bi4[v];
+        same += (ov.x == o) + (ov.y == o) + (ov.z == o) + (ov.w == o);
+        mxi = __builtin_fmaxf(mxi, ov.x == o ? iv.x : -1e9f);
+        mxi = __builtin_fmaxf(mxi, ov.y == o ? iv.y : -1e9f);
+        mxi = __builtin_fmaxf(mxi, ov.z == o ? iv.z : -1e9f);
+        mxi = __builtin_fmaxf(mxi, ov.w == o ? iv.w : -1e9f);
+      }
+      if (same > 1) {  // rare: several bids on this object
+        r_win = emd_in_band(inc, mxi);
+        if (r_win)
+          for (int v = 0; v < Utot; ++v)
+            if (s_bo[v] == o && s_bj[v] > j && emd_in_band(s_binc[v], mxi)) r_win = false;
+      }
+      if (last) r_win = true;
+      const bool owned = (s_owned[o >> 5] >> (o & 31)) & 1u;
+      s_win[t] = r_win ? (owned ? 2 : 1) : 0;
+    }
+    if (t == 0) s_nfree = 0;
+    lds_barrier();
+#ifdef MVP_EMD_PROFILE
+    const long long tpr = __builtin_readcyclecounter();
+#endif
 
-      if (win && last) {
-        if (q4 == 0) st_i32(&ass[j], o);
-      } else if (win) {
-        int prev = -1;
-        float4 oo = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q4 == 0) {
-          prev = ld_i32(&sc.ostate[o].z);
-          oo = sc.obj[o];  // coordinates only (static)
-        }
-        prev = quad_i32<0x00>(prev);  // quad_perm [0,0,0,0]
-        const bool evict = prev != -1;
-        // the winner leaves the pool: its cache goes to scratch (chunks of 16 bytes: 0-1 slots,
-        // 2-5 distances, 6 {tau, count}); the person it evicts takes the entry over
-        const unsigned myc = off_cache + (unsigned)j * kCacheRec;
-        const unsigned pvc = off_cache + (unsigned)prev * kCacheRec;
-        v4u in0 = {0u, 0u, 0u, 0u}, in1 = {0u, 0u, 0u, 0u};
-        if (caching) {
-          if (evict) {
-            in0 = ldg16(pvc + (2u * q4) * 16u);
-            if (q4 < 3) in1 = ldg16(pvc + (2u * q4 + 1u) * 16u);
-          }
-          const int cc = e_i[e].w;
-          if (q4 == 0) {
-            const v4u *src = reinterpret_cast<const v4u *>(&e_cs[e][0]);
-            stg16(src[0], myc);
-            stg16(src[1], myc + 16u);
-          } else if (q4 < 3) {
-            const v4u *src = reinterpret_cast<const v4u *>(&e_cd[e][0]);
-            stg16(src[2 * q4 - 2], myc + (2u * q4) * 16u);
-            stg16(src[2 * q4 - 1], myc + (2u * q4 + 1u) * 16u);
-          } else {
-            v4u r;
-            r.x = __float_as_uint(e_tau[e]);
-            r.y = (unsigned)cc;
-            r.z = 0u;
-            r.w = 0u;
-            stg16(r, myc + 96u);
-          }
-        }
-        float4 plo = make_float4(0.f, 0.f, 0.f, 0.f);
-        int h1 = -1, h2 = -1;
-        if (q4 == 0) {
-          if (evict) {
-            const v4u a = ldg16(off_person + (2u * (unsigned)prev) * 16u);
-            const v4u bb = ldg16(off_person + (2u * (unsigned)prev + 1u) * 16u);
-            plo = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), 0.f);
-            h1 = (int)bb.y;
-            h2 = (int)bb.z;
-            st_i32(&ass[prev], -1);
-          }
-          st_i32(&sc.ostate[o].z, j);
-          st_i32(&ass[j], o);
-          v4u hi;
-          hi.x = (unsigned)o;
-          hi.y = (unsigned)o;
-          hi.z = (unsigned)s_b2k[ub];
-          hi.w = __float_as_uint(inc);
-          stg16(hi, off_person + (2u * (unsigned)j + 1u) * 16u);
-          // the price; the cell's lower bound only when (one of) its cheapest got dearer
-          const float pold = s_price[o];
-          const float pnew = pold + inc;
-          s_price[o] = pnew;
-          const int c = emd_cell(gg, oo.x, oo.y, oo.z);
-          float *lbp = reinterpret_cast<float *>(&s_cell[c]) + 3;
-          if (pold <= *lbp) {
-            float pm = pnew;
-            const int e1 = c_start[c + 1];
-            for (int s = c_start[c]; s < e1; ++s) pm = __builtin_fminf(pm, s == o ? pm : s_price[s]);
-            *lbp = pm;
-          }
-        }
-        // the entry: handed to the evicted person, or dead
-        if (evict) {
-          if (caching) {
-            if (q4 == 0) {
-              v4u *dst = reinterpret_cast<v4u *>(&e_cs[e][0]);
-              dst[0] = in0;
-              dst[1] = in1;
-            } else if (q4 < 3) {
-              v4u *dst = reinterpret_cast<v4u *>(&e_cd[e][0]);
-              dst[2 * q4 - 2] = in0;
-              dst[2 * q4 - 1] = in1;
-            } else {
-              e_tau[e] = __uint_as_float(in0.x);
-              e_i[e].w = (int)in0.y;
-            }
-          }
-          if (q4 == 0) {
-            e_q[e] = plo;
-            e_i[e].x = prev;
-            e_i[e].y = h1;
-            e_i[e].z = h2;
-            if (!caching) e_i[e].w = 0;
-          }
-        } else if (q4 == 0) {
-          e_live[e] = 0;
-        }
-      } else if (act && q4 == 0) {
-        // lost: keeps its entry; this bid's best / second best seed the next one
-        e_i[e].y = o;
-        e_i[e].z = s_b2k[ub];
+    // ---------------- Assign (emd_cuda.cu:196-215).  This member's own bidders are handled by four
+    // threads each; the loads of an evicted person's record and cache are issued first so that they
+    // travel while part 1 runs.
+    const int ub = t >> 2, q4 = t & 3;
+    const bool act = ub < U;
+    const int vb = off_me + ub;
+    int a_o = -1, a_j = -1, a_e = 0, a_code = 0;
+    float a_inc = 0.f;
+    if (act) {
+      a_o = s_bo[vb];
+      a_inc = s_binc[vb];
+      a_j = s_bj[vb];
+      a_e = s_be[ub];
+      a_code = s_win[vb];
+    }
+    const bool a_evict = a_code == 2 && !last;
+    int a_prev = -1;
+    if constexpr (LOWN) {
+      if (a_evict) a_prev = s_prevo[vb];
+    } else {
+      if (q4 == 0 && a_evict) a_prev = ld_i32(&sc.ostate[a_o].z);
+      a_prev = quad_i32<0x00>(a_prev);  // quad_perm [0,0,0,0]
+    }
+    // cache record = chunks of 16 bytes: 0-1 slots, 2-5 distances, 6 {tau, count}; thread q4 moves 2 q4, 2 q4 + 1
+    v4u in0 = {0u, 0u, 0u, 0u}, in1 = {0u, 0u, 0u, 0u}, pa = {0u, 0u, 0u, 0u}, pb = {0u, 0u, 0u, 0u};
+    if (a_evict) {
+      const unsigned pvc = off_cache + (unsigned)a_prev * kCacheRec;
+      if (caching) {
+        in0 = ldg16(pvc + (2u * q4) * 16u);
+        if (q4 < 3) in1 = ldg16(pvc + (2u * q4 + 1u) * 16u);
+      }
+      if (q4 == 0) {
+        pa = ldg16(off_person + (2u * (unsigned)a_prev) * 16u);
+        pb = ldg16(off_person + (2u * (unsigned)a_prev + 1u) * 16u);
       }
     }
-    __syncthreads();
+
+    // part 1: every price rise (and new owner) of the round goes into this member's own copy
+    if (!last && t < Utot && s_win[t]) {
+      const int o = s_bo[t];
+      if (s_win[t] == 1) atomicAdd(&s_nfree, 1);  // a free object gets its first owner: one unassigned person fewer
+      if constexpr (LOWN) s_owner[o] = (unsigned short)s_bj[t];
+      else if (s_win[t] == 1) atomicOr(&s_owned[o >> 5], 1u << (o & 31));
+      const float pold = s_price[o];
+      const float pnew = pold + s_binc[t];
+      s_price[o] = pnew;
+      // the object's cell: the last c with c_start[c] <= o; its lower bound only when (one of)
+      // its cheapest members got dearer
+      int lo = 0, hi = ncell;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)c_start[mid] <= o) lo = mid;
+        else hi = mid;
+      }
+      float *lbp = reinterpret_cast<float *>(&s_cell[lo]) + 3;
+      if (pold <= *lbp) {
+        float pm = pnew;
+        const int e1 = c_start[lo + 1];
+        for (int s2 = c_start[lo]; s2 < e1; ++s2) pm = __builtin_fminf(pm, s2 == o ? pm : s_price[s2]);
+        *lbp = pm;
+      }
+    }
+
+    // part 2: this member's own bidders
+    if (a_code != 0 && last) {
+      if (q4 == 0) st_i32(&ass[a_j], a_o);
+    } else if (a_code != 0) {
+      // the winner leaves the pool: its cache goes to scratch; the person it evicts takes the entry over
+      const unsigned myc = off_cache + (unsigned)a_j * kCacheRec;
+      if (caching) {
+        const int cc = e_i[a_e].w;
+        if (q4 == 0) {
+          const v4u *src = reinterpret_cast<const v4u *>(&e_cs[a_e][0]);
+          stg16(src[0], myc);
+          stg16(src[1], myc + 16u);
+        } else if (q4 < 3) {
+          const v4u *src = reinterpret_cast<const v4u *>(&e_cd[a_e][0]);
+          stg16(src[2 * q4 - 2], myc + (2u * q4) * 16u);
+          stg16(src[2 * q4 - 1], myc + (2u * q4 + 1u) * 16u);
+        } else {
+          v4u r;
+          r.x = __float_as_uint(e_tau[a_e]);
+          r.y = (unsigned)cc;
+          r.z = 0u;
+          r.w = 0u;
+          stg16(r, myc + 96u);
+        }
+      }
+      if (q4 == 0) {
+        if (a_evict) st_i32(&ass[a_prev], -1);
+        if constexpr (!LOWN) st_i32(&sc.ostate[a_o].z, a_j);
+        st_i32(&ass[a_j], a_o);
+        v4u hi;
+        hi.x = (unsigned)a_o;
+        hi.y = (unsigned)a_o;
+        hi.z = (unsigned)s_b2k[vb];
+        hi.w = __float_as_uint(a_inc);
+        stg16(hi, off_person + (2u * (unsigned)a_j + 1u) * 16u);
+      }
+      // the entry: handed to the evicted person, or dead
+      if (a_evict) {
+        if (caching) {
+          if (q4 == 0) {
+            v4u *dst = reinterpret_cast<v4u *>(&e_cs[a_e][0]);
+            dst[0] = in0;
+            dst[1] = in1;
+          } else if (q4 < 3) {
+            v4u *dst = reinterpret_cast<v4u *>(&e_cd[a_e][0]);
+            dst[2 * q4 - 2] = in0;
+            dst[2 * q4 - 1] = in1;
+          } else {
+            e_tau[a_e] = __uint_as_float(in0.x);
+            e_i[a_e].w = (int)in0.y;
+          }
+        }
+        if (q4 == 0) {
+          e_q[a_e] = make_float4(__uint_as_float(pa.x), __uint_as_float(pa.y), __uint_as_float(pa.z), 0.f);
+          e_i[a_e].x = a_prev;
+          e_i[a_e].y = (int)pb.y;
+          e_i[a_e].z = (int)pb.z;
+          if (!caching) e_i[a_e].w = 0;
+        }
+      } else if (q4 == 0) {
+        e_live[a_e] = 0;
+      }
+    } else if (act && q4 == 0) {
+      // lost: keeps its entry; this bid's best / second best seed the next one
+      e_i[a_e].y = a_o;
+      e_i[a_e].z = s_b2k[vb];
+    }
+    // W == 1: later rounds re-read what this one stored (records, caches) through the same
+    // CU -- wait for the stores; W > 1: the next all-gather drains them
+    if constexpr (W == 1) __syncthreads();
+    else lds_barrier();
+#ifdef MVP_EMD_PROFILE
+    const long long tp2 = __builtin_readcyclecounter();
+#endif
 
     // ---------------- next round's order list: the live entries, by ballot
     unsigned long long lm = 0ull;
     bool live = false;
-    if (t < kTailCap) {
+    if (t < POOL) {
       live = e_live[t] != 0;
       lm = __ballot(live);
       if (lane == 0) s_wcnt[wave] = __builtin_popcountll(lm);
     }
-    __syncthreads();
-    if (t < kTailCap) {
+    lds_barrier();
+    if (t < POOL) {
       int base = 0;
       for (int w = 0; w < wave; ++w) base += s_wcnt[w];
       if (live) s_order[base + __builtin_popcountll(lm & ((1ull << lane) - 1ull))] = (unsigned short)t;
     }
     if (t == 0) {
-      s_U = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      int tot = 0;
+      for (int w = 0; w < POOL / kWave; ++w) tot += s_wcnt[w];
+      s_U = tot;
       s_next = kEmdWaves;
+      s_nmiss = 0;
     }
-    __syncthreads();
+    lds_barrier();
     U = s_U;
+    Utot -= s_nfree;
+#ifdef MVP_EMD_PROFILE
+    const long long tp3 = __builtin_readcyclecounter();
+    cyc_a += tpa - tp0;
+    cyc_b += tpg - tpa;
+    cyc_gather += tp1 - tpg;
+    cyc_resolve += tpr - tp1;
+    cyc_assign += tp2 - tpr;
+    cyc_compact += tp3 - tp2;
+#endif
   }
+#ifdef MVP_EMD_PROFILE
+  if (t == 0 && cloud < 2) {
+    printf("tail cloud %d wg %d/%d: rounds %lld own bids %lld | cycles setup %lld phaseA %lld phaseB %lld gather+fetch %lld resolve %lld assign %lld compact %lld\n",
+           cloud, wg, W, n_rounds, n_bids, cyc_setup, cyc_a, cyc_b, cyc_gather, cyc_resolve, cyc_assign, cyc_compact);
+    printf("tail cloud %d wg %d: hits %llu misses %llu (%llu cycles each, visits %llu) linear %llu mean sub-box %llu cells visited %llu home-seeds %llu\n",
+           cloud, wg, s_prof[0], s_prof[1], s_prof[3] / (s_prof[1] + 1), s_prof[11] / (s_prof[1] + 1), s_prof[4],
+           s_prof[5] / (s_prof[1] + 1), s_prof[6] / (s_prof[1] + 1), s_prof[8]);
+  }
+#endif
 
-  if (t == 0) {
-    stats[0] = s_err ? -1 : stats[0] + n_rounds;
-    stats[1] += n_bids;
+  if (aborted) {
+    // A cluster wait ran into its bound (members not co-resident for tens of seconds): fail
+    // loudly -- NaN distances, -1 assignments, negative status.
+    if (t == 0) stats[0] = -2;
+    for (int j = t; j < n; j += kEmdThreads) {
+      dist[j] = __builtin_nanf("");
+      ass[j] = -1;
+    }
+    return;
   }
-  // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
-  __syncthreads();
-  for (int j = t; j < n; j += kEmdThreads) {
+  if (t == 0) {
+    if (wg == 0) stats[0] = s_err ? -1 : stats[0] + n_rounds;
+    atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
+  }
+  // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices.  The other
+  // members' last assignments must have landed: one more all-gather.
+  if constexpr (W > 1) {
+    if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_U, &s_err, s_gout, &s_abort)) {
+      if (t == 0) stats[0] = -2;
+      for (int j = t; j < n; j += kEmdThreads) {
+        dist[j] = __builtin_nanf("");
+        ass[j] = -1;
+      }
+      return;
+    }
+    bool err = false;
+#pragma unroll
+    for (int w = 0; w < W; ++w) err |= s_gout[2 * w + 1] != 0u;
+    if (err && wg == 0 && t == 0) stats[0] = -1;
+  } else {
+    __syncthreads();
+  }
+  const int share = n / W;  // n % 1024 == 0
+  for (int j = wg * share + t; j < (wg + 1) * share; j += kEmdThreads) {
     const int s = ld_i32(&ass[j]);
     const float4 o = sc.obj[s];  // coordinates never change
     const float dx = xyz1[j * 3 + 0] - o.x;
@@ -647,10 +935,32 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
   }
 }
 
-void emd_tail_launch(int b, int n, const float *xyz1, float *dist, int *assignment, float eps, int iters,
+template <int W>
+static hipError_t emd_tail_launch_w(int b, int n, const float *xyz1, float *dist, int *assignment, float eps, int iters,
+                                    char *scratch, float delta, hipStream_t stream) {
+  int bpad = W == 1 ? b : (b + 7) / 8 * 8;
+  if (W == 1) {
+    hipLaunchKernelGGL(emd_tail_kernel<1>, dim3(b), dim3(kEmdThreads), 0, stream, b, bpad, n, xyz1, dist, assignment,
+                       eps, iters, scratch, delta);
+    return hipSuccess;
+  }
+  // members wait for each other: cooperative launch (residency is checked)
+  void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &delta};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_tail_kernel<W>), dim3(W * bpad),
+                                    dim3(kEmdThreads), args, 0, stream);
+}
+
+// w = workgroups per cloud (1, 2, 4, 8); falls back to 1 if the cluster does not fit the device
+void emd_tail_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps, int iters,
                      char *scratch, float delta, hipStream_t stream) {
-  hipLaunchKernelGGL(emd_tail_kernel, dim3(b), dim3(kEmdThreads), 0, stream, b, n, xyz1, dist, assignment, eps,
-                     iters, scratch, delta);
+  hipError_t err = hipErrorUnknown;
+  if (w == 8) err = emd_tail_launch_w<8>(b, n, xyz1, dist, assignment, eps, iters, scratch, delta, stream);
+  else if (w == 4) err = emd_tail_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, delta, stream);
+  else if (w == 2) err = emd_tail_launch_w<2>(b, n, xyz1, dist, assignment, eps, iters, scratch, delta, stream);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    (void)emd_tail_launch_w<1>(b, n, xyz1, dist, assignment, eps, iters, scratch, delta, stream);
+  }
 }
 
 }  // namespace mvp

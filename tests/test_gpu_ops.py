@@ -178,8 +178,8 @@ def emd_variant():
     """Selects the auction variant: tail kernel on / off, candidate-cache width
     (mvp_emd_configure); defaults restored afterwards."""
     from mvp_benchmark_amd import _lib
-    yield lambda tail, delta: _lib.emd_configure(tail=tail, tail_delta=delta)
-    _lib.emd_configure(tail=1, tail_delta=5.0)
+    yield lambda tail, delta, tail_cluster=0: _lib.emd_configure(tail=tail, tail_delta=delta, tail_cluster=tail_cluster)
+    _lib.emd_configure(tail=_lib.EMD_DEFAULT_TAIL, tail_delta=_lib.EMD_DEFAULT_TAIL_DELTA, tail_cluster=0)
 
 
 @pytest.mark.parametrize("width", [1, 2, 4, 8])
@@ -243,16 +243,37 @@ def test_emd_tail_kernel_variants_match_oracle(oracle, emd_variant, cluster_widt
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
-def test_emd_headline_cloud_matches_oracle(oracle):
-    """One cloud pair of the headline shape (16384 points, eps 0.004, 3000
-    rounds) against the exhaustive oracle, bit for bit: clustered kernel for the
-    first ~150 rounds, tail kernel for the rest.  (~70 s of CPU per cloud.)"""
+@pytest.mark.parametrize("tail_width", [1, 2, 4, 8])
+@pytest.mark.parametrize("kind", ["uniform", "duplicates"])
+def test_emd_tail_cluster_widths_match_oracle(oracle, emd_variant, tail_width, kind):
+    """The tail kernel with 1, 2, 4 or 8 workgroups per cloud (each with its own
+    LDS copy of the prices, bids exchanged behind one all-gather per round)."""
     from mvp_benchmark_amd.metrics import emd
-    x1, x2 = rand_clouds(41, 2, 16384, 3), rand_clouds(42, 2, 16384, 3)
-    dist, ass = emd()(dev(x1), dev(x2), 0.004, 3000)
-    od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
+    emd_variant(1, 5.0, tail_width)
+    if kind == "uniform":
+        x1, x2, eps, iters = rand_clouds(51, 3, 4096, 3), rand_clouds(52, 3, 4096, 3), 0.004, 3000
+    else:
+        x1 = np.tile(rand_clouds(53, 2, 512, 3), (1, 4, 1))
+        x2, eps, iters = np.tile(rand_clouds(54, 2, 256, 3), (1, 8, 1)), 0.005, 1500
+    dist, ass = emd()(dev(x1), dev(x2), eps, iters)
+    od, oa = oracle.emd_forward(x1, x2, eps, iters)
     np.testing.assert_array_equal(ass.cpu().numpy(), oa)
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
+def test_emd_headline_cloud_matches_oracle(oracle, emd_variant):
+    """Two cloud pairs of the headline shape (16384 points, eps 0.004, 3000
+    rounds) against the exhaustive oracle, bit for bit -- with the clustered
+    kernel alone and with the hand-over to the tail kernel (round ~150 onwards).
+    (~70 s of CPU per cloud, once.)"""
+    from mvp_benchmark_amd.metrics import emd
+    x1, x2 = rand_clouds(41, 2, 16384, 3), rand_clouds(42, 2, 16384, 3)
+    od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
+    for tail in (0, 1):
+        emd_variant(tail, 3.0)
+        dist, ass = emd()(dev(x1), dev(x2), 0.004, 3000)
+        np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+        np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
 def test_emd_cluster_widths_agree_at_full_size(cluster_width):
