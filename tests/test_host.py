@@ -26,8 +26,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.mvp_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MVP_ABI_VERSION (\d+)", header).group(1))
     # per cloud: state 132 B/pt + bound broadcast buffers + cell offsets + candidate caches 128 B/pt
     # (n <= 16384 only) + barrier granules, hand-over record, statistics
-    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * (132 + 128) + 8 * 2048 * 8 + 1732 * 4 + 256 + 1056 + 16)
-    assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 256 + 1056 + 16)
+    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * (132 + 128) + 8 * 2048 * 8 + 1732 * 4 + 512 + 1056 + 16)
+    assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 512 + 1056 + 16)
 
 
 def test_argument_guards_need_no_gpu():
