@@ -20,10 +20,13 @@
 //     WITHOUT sharing that state: each keeps its own full copy of the prices
 //     and cell bounds in its LDS and bids for its own part of the unassigned
 //     persons; the round's bids (16 bytes each, <= 256 per cloud) are exchanged
-//     through memory behind ONE all-gather, and every workgroup then resolves
-//     all of them and applies all price rises to its own copy -- redundant,
-//     deterministic, identical.  One cross-CU synchronisation per round instead
-//     of two, no write-through stores or L1 bypasses on a bid's path;
+//     through memory as self-validating records -- two 8-byte atomic stores,
+//     each carrying the round's tag, polled by the readers: the data is the
+//     flag, there is no barrier granule, no store drain and no all-gather in a
+//     round -- and every workgroup then resolves all of them and applies all
+//     price rises to its own copy: redundant, deterministic, identical.  (Every
+//     member also derives every member's bidder count from the bids it has
+//     seen, so it knows where to look.);
 //   * the unassigned persons sit in a pool of kTailCap LDS entries {point,
 //     hints, candidate cache}.  An entry is stable: a loser keeps it, a winner
 //     hands it to the person it evicted (at most one), so a member's pool never
@@ -43,23 +46,29 @@
 //     cycles and no memory round trip; otherwise the cached second best seeds
 //     the full search (no seeding round trip) and the cache is rebuilt.  Caches
 //     follow their person out of the pool (scratch, 128 B each) and back in;
-//   * GetMax is resolved exactly in LDS (every bidder scans the round's <= 256
-//     bids for its object: maximal increment, then the highest bidder inside
-//     the reference's 1e-6 band, emd_cuda.cu:181-194) -- no atomics, no alarm
-//     pass.
+//   * GetMax is resolved exactly in LDS (emd_cuda.cu:181-194: the highest bidder
+//     inside the 1e-6 band of the object's maximal increment).  The bids of one
+//     object find each other through the object's owner word: the last of them
+//     to write its number there represents the group, count and maximal
+//     increment are two LDS atomics on the representative -- O(1) per bid, no
+//     alarm pass (W == 1 has no owner words in LDS and scans the round's bids).
 // Bid phase A: every bidder's cache is tried, four bidders per wave (a 16-lane
 // row each: 16 cached candidates).  Phase B: the misses, one wave each, drawn
 // from a list so that the expensive searches spread over the 16 waves: cell
 // enumeration from LDS, then ONE global round trip for the coordinates of the
-// surviving cells' members (static data, plain cached loads), prices from LDS.
-// Inside a round the phases are separated by bare s_barrier (LDS traffic only);
-// global stores are only waited for at the all-gather.
+// surviving cells' members (static data, plain cached loads), prices from LDS;
+// every lane keeps the exact top two of the objects it evaluated, the wave
+// merges them once (DPP, reference tie order on original indices).
+// Inside a round the phases are separated by bare s_barrier (LDS traffic only),
+// except one __syncthreads after phase A that also waits for the previous
+// round's stores (records and caches of persons that left the pool) before the
+// first bid record of the round is published.
 #include "emd_common.h"
 
 namespace mvp {
 
 constexpr int kTailCells = 1331;  // 11^3: n <= 16384 objects give g <= 11 (emd.hip: (g+1)^3 * 12 <= n)
-constexpr int kStage = 48;        // candidates a search can stage for the cache (more: no cache this time)
+constexpr int kStage = 40;        // candidates a search can stage for the cache (more: no cache this time)
 
 // fp16 bounds of a float, rounded outwards (box lo down, box hi up), as bits
 __device__ __forceinline__ unsigned half_bits_down(float x) {
@@ -92,8 +101,36 @@ __device__ __forceinline__ int quad_i32(int v) {
 }
 
 // LDS-only phase boundary: this wave's LDS traffic has landed, then s_barrier.
-// Global stores are NOT waited for (they are drained at the all-gather).
+// Global stores are NOT waited for.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One step of the wave-wide merge of per-lane exact top-2 {b1, slot k1, b2, slot k2}: the two
+// lane sets are disjoint; equal best values are ordered by the reference's rule on ORIGINAL
+// object indices (perm).  Lanes the DPP control / row mask does not write merge with nothing.
+template <int CTRL, int RM>
+__device__ __forceinline__ void top2k_merge_step(float &b1, int &k1, float &b2, int &k2, int n, int tpu,
+                                                 const int *__restrict__ perm) {
+  const float ob1 = dpp_f32<CTRL, RM>(-1e9f, b1);
+  const float ob2 = dpp_f32<CTRL, RM>(-1e9f, b2);
+  const int ok1 = __builtin_amdgcn_update_dpp(-1, k1, CTRL, RM, 0xF, false);
+  const int ok2 = __builtin_amdgcn_update_dpp(-1, k2, CTRL, RM, 0xF, false);
+  const bool tie = ob1 == b1 && ok1 >= 0 && k1 >= 0;
+  bool other_first = false;
+  if (__any(tie)) {
+    if (tie) other_first = emd_precedes(perm[ok1], perm[k1], n, tpu);
+  }
+  if (ob1 > b1 || other_first) {
+    const bool fb = b1 >= ob2;
+    b2 = fb ? b1 : ob2;
+    k2 = fb ? k1 : ok2;
+    b1 = ob1;
+    k1 = ok1;
+  } else {
+    const bool fo = ob1 >= b2;
+    k2 = fo ? ok1 : k2;
+    b2 = fo ? ob1 : b2;
+  }
+}
 
 template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
@@ -132,12 +169,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
   auto stg16 = [&](v4u v, unsigned byte_off) { __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16); };
   auto ld_i32 = [&](int *p) -> int { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto st_i32 = [&](int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  // The round's bids travel through the (dead) unassigned lists of the first kernel:
-  // 16 bytes {object, bits(increment), person, second-best hint} per bid, per member, by round parity.
-  const unsigned off_xb = (unsigned)n * 68u;
-  auto xb_off = [&](int parity, int w, int i) -> unsigned {
-    return off_xb + (unsigned)((parity * kMaxCluster + w) * kTailCap + i) * 16u;
-  };
+  // The round's bids travel through the (dead) unassigned lists of the first kernel, per member
+  // and round parity: two 8-byte words {object | person << 16, tag} and {bits(increment),
+  // (second-best hint + 1) | tag << 16}, tag = round + 1.
+  u64 *xb = reinterpret_cast<u64 *>(cbase + (size_t)n * 68);
+  auto xb_at = [&](int parity, int w, int i) -> u64 * { return xb + (size_t)((parity * kMaxCluster + w) * kTailCap + i) * 2; };
 
   __shared__ float s_price[kTailMaxN];
   __shared__ unsigned short s_owner[LOWN ? kTailMaxN : 2];       // 0xFFFF: free
@@ -154,25 +190,26 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
   __shared__ unsigned short s_order[POOL];                  // live entries, ascending
   __shared__ unsigned short s_miss[POOL];                   // list positions whose cache failed
   __shared__ float s_seed[POOL];                            // ... and the seed their cache gives
-  __shared__ int s_be[POOL];                                // own bids: the bidder's entry
-  // this round's bids of the whole cloud
+  __shared__ unsigned short s_be[POOL];                     // own bids: the bidder's entry
+  // this round's bids: first this member's own (phase A), then the whole cloud's
   __shared__ __attribute__((aligned(16))) int s_bo[kTailCap];
   __shared__ int s_b2k[kTailCap], s_bj[kTailCap];
   __shared__ __attribute__((aligned(16))) float s_binc[kTailCap];
-  __shared__ unsigned char s_win[kTailCap];                 // 0 lost, 1 won a free object, 2 won an owned one
-  __shared__ unsigned short s_prevo[LOWN ? kTailCap : 2];   // owner of the bid's object before this round
-  __shared__ int s_gcnt[LOWN ? kTailCap : 2];                // bids on the object a bid represents
-  __shared__ unsigned s_gmax[LOWN ? kTailCap : 2];           // ... and their maximal increment (ordered bits)
+  __shared__ unsigned char s_flag[kTailCap];                // phase A: own bid u was a cache hit
+  __shared__ unsigned char s_bm[kTailCap];                  // member a bid came from
+  __shared__ int s_gcnt[LOWN ? kTailCap : 2];               // bids on the object a bid represents
+  __shared__ unsigned s_gmax[LOWN ? kTailCap : 2];          // ... and their maximal increment (ordered bits)
   __shared__ unsigned short w_list[kEmdWaves][128];         // surviving cells of a search
   __shared__ int st_slot[kEmdWaves][kStage];                // staged candidates of a search
   __shared__ float st_v[kEmdWaves][kStage], st_d[kEmdWaves][kStage];
-  __shared__ int s_next, s_nmiss, s_err, s_U, s_nfree, s_abort, s_wcnt[4];
+  __shared__ int s_mcnt[kMaxCluster];                       // bidders per member (tracked identically by everybody)
+  __shared__ int s_next, s_nmiss, s_err, s_U, s_nfree, s_abort;
   __shared__ unsigned s_gout[2 * kMaxCluster];
 #ifdef MVP_EMD_PROFILE
   // [0] hits [1] misses [3] cycles in misses [4] linear scans [5] sum nsub [6] sum cells visited [8] home-cell seeds [11] visit cycles
   __shared__ unsigned long long s_prof[16];
   if (threadIdx.x < 16) s_prof[threadIdx.x] = 0ull;
-  long long cyc_a = 0, cyc_b = 0, cyc_gather = 0, cyc_resolve = 0, cyc_assign = 0, cyc_compact = 0,
+  long long cyc_a = 0, cyc_b = 0, cyc_fetch = 0, cyc_resolve = 0, cyc_assign = 0, cyc_compact = 0,
             cyc_setup = __builtin_readcyclecounter();
 #endif
 
@@ -218,14 +255,35 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
       e_i[t] = make_int4(j, __float_as_int(hi.y), __float_as_int(hi.z), 0);  // caches start empty
     }
   }
+  if (t < W) s_mcnt[t] = (U0 - t + W - 1) / W;
   if (t == 0) {
     s_next = kEmdWaves;
     s_nmiss = 0;
     s_err = resume->pad;
     s_U = myU0;
+    s_nfree = 0;
     s_abort = 0;
   }
-  __syncthreads();
+  unsigned epoch = 0;
+  if constexpr (W > 1) {
+    // no stale word of the exchange area may look like a record: clear this member's slices,
+    // then meet the others once
+    for (int i = t; i < 2 * kTailCap; i += kEmdThreads) {
+      u64 *p = xb_at(i / kTailCap, wg, i % kTailCap);
+      __hip_atomic_store(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_U, &s_err, s_gout, &s_abort)) {
+      if (t == 0) stats[0] = -2;
+      for (int j = t; j < n; j += kEmdThreads) {
+        dist[j] = __builtin_nanf("");
+        ass[j] = -1;
+      }
+      return;
+    }
+  } else {
+    __syncthreads();
+  }
   // cell records: exact box of the members, rounded outwards to fp16; cheapest member
   for (int c = t; c < ncell; c += kEmdThreads) {
     float bx0 = __builtin_inff(), by0 = __builtin_inff(), bz0 = __builtin_inff();
@@ -259,31 +317,24 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
   long long n_rounds = 0, n_bids = 0;
   int U = myU0;      // this member's bidders
   int Utot = U0;     // the cloud's
-  unsigned epoch = 0;
   bool aborted = false;
   for (int it = it0; it < iters; ++it) {
     if (Utot == 0) break;
     n_rounds += 1;
     n_bids += U;
     const bool last = it == iters - 1;
+    const unsigned tag = (unsigned)(it + 1);
     // thread_per_unass of the reference (emd_cuda.cu:107-109): fixes the tie order only
     const int upb = (Utot + block_cnt - 1) / block_cnt;
     const int tpu = 1024 / upb;
-    // a bid of this member, list position u: W == 1 straight into the round's arrays, else to memory
-    auto record_bid = [&](int u, int bk, float inc, int j, int b2k) {
-      if constexpr (W == 1) {
-        s_bo[u] = bk;
-        s_b2k[u] = b2k;
-        s_binc[u] = inc;
-        s_bj[u] = j;
-      } else {
-        v4u r;
-        r.x = (unsigned)bk;
-        r.y = __float_as_uint(inc);
-        r.z = (unsigned)j;
-        r.w = (unsigned)b2k;
-        stg16(r, xb_off(it & 1, wg, u));
-      }
+    // publish a bid of this member (list position u) to the others
+    auto publish = [&](int u, int bk, float inc, int j, int b2k) {
+      u64 *p = xb_at(it & 1, wg, u);
+      __hip_atomic_store(p, ((u64)tag << 32) | (u64)((unsigned)bk | ((unsigned)j << 16)), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p + 1,
+                         ((u64)(((tag & 0xFFFFu) << 16) | ((unsigned)(b2k + 1) & 0xFFFFu)) << 32) | (u64)__float_as_uint(inc),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
 #ifdef MVP_EMD_PROFILE
@@ -324,9 +375,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
       const int bk = __shfl(slot, rsh + l1, kWave);
       const int k2 = __shfl(slot, rsh + l2, kWave);
       if (act && l16 == 0) {
+        s_be[u] = (unsigned short)e;
+        s_flag[u] = hit ? 1 : 0;
         if (hit) {
-          record_bid(u, bk, c1 - c2 + eps, j, rm2 ? k2 : -1);
-          s_be[u] = e;
+          s_bo[u] = bk;
+          s_binc[u] = c1 - c2 + eps;
+          s_bj[u] = j;
+          s_b2k[u] = rm2 ? k2 : -1;
         } else {
           const int pos = atomicAdd(&s_nmiss, 1);
           s_miss[pos] = (unsigned short)u;
@@ -334,7 +389,17 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
         }
       }
     }
-    lds_barrier();
+    // W > 1: everything this member stored in the previous round (records and caches of the
+    // persons that left its pool) has landed before its first bid of this round is visible
+    if constexpr (W > 1) __syncthreads();
+    else lds_barrier();
+    if constexpr (W > 1) {
+      if (t < U && s_flag[t]) publish(t, s_bo[t], s_binc[t], s_bj[t], s_b2k[t]);
+      // heartbeat (record kTailCap - 1; a pool holds <= kTailCap / 2 bids): also a member without
+      // bidders tells the others that its stores of the previous round have landed
+      if (t == kEmdThreads - 1)
+        __hip_atomic_store(xb_at(it & 1, wg, kTailCap - 1), (u64)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef MVP_EMD_PROFILE
     const long long tpa = __builtin_readcyclecounter();
 #endif
@@ -345,7 +410,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
     int mi = wave;
     for (int guard = 0; guard <= POOL && mi < nmiss; ++guard) {
       const int u = s_miss[mi];
-      const int e = s_order[u];
+      const int e = s_be[u];
       const float4 ra = e_q[e];
       const int4 rb = e_i[e];
       const int j = rb.x, p1 = rb.y, p2 = rb.z;
@@ -386,21 +451,19 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
         }
         seed_b2 = wave_second_largest(a1, a2);
       }
-      BidState st;
-      st.b1 = -1e9f;
-      st.b2 = -1e9f;
-      st.bk = -1;
-      st.b2k = -1;
-      // the filter admits everything within delta of the second best (emd_common.h, kMargin,
-      // with B2 := fl(b2 - delta)): what it skips is worth < b2 - delta
-      st.tm = (3.0f - (seed_b2 - delta)) + kMargin;
-      int nst = 0;  // staged candidates (wave-uniform)
+      // The filter admits everything within delta of the seed (emd_common.h, kMargin, with
+      // B2 := fl(seed - delta)): what it skips is worth < seed - delta <= (final second best) - delta.
+      // It is not tightened during the search: a bid visits its surviving cells in one or two steps.
+      const float tm = (3.0f - (seed_b2 - delta)) + kMargin;
+      int nst = 0;                              // staged candidates (wave-uniform)
+      float lb1 = -1e9f, lb2 = -1e9f;           // exact top two of the objects THIS LANE evaluates
+      int lbk = -1, lb2k = -1;
 
-      // evaluate one object per lane: filter, stage for the cache, fold what can matter
+      // evaluate one object per lane: filter, stage for the cache, lane-local top two
       auto consider = [&](bool valid, int s, const float4 &o) {
         const float p = valid ? s_price[s] : 0.f;
         const float sd = sqdist3(o.x - qx, o.y - qy, o.z - qz);
-        const float tq = st.tm - p;
+        const float tq = tm - p;
         const bool ps = valid && tq >= 0.f && sd <= tq * tq;
         const unsigned long long m = __ballot(ps);
         if (m) {
@@ -415,15 +478,27 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
             }
             nst += __builtin_popcountll(m);
           }
-          const unsigned long long mf = __ballot(ps && v >= st.b2);
-          if (mf) emd_fold(st, mf, v, s, n, tpu, sc.perm, delta);
+          if (ps) {
+            if (v > lb1) {
+              lb2 = lb1; lb2k = lbk; lb1 = v; lbk = s;
+            } else if (v == lb1) {   // rare: reference order on ORIGINAL indices
+              lb2 = v;
+              if (emd_precedes(sc.perm[s], sc.perm[lbk], n, tpu)) {
+                lb2k = lbk; lbk = s;
+              } else {
+                lb2k = s;
+              }
+            } else if (v > lb2) {
+              lb2 = v; lb2k = s;
+            }
+          }
         }
       };
 
       // (2) cells intersecting the cube |o - q|_inf <= tm (prices >= 0), 64 per step
       int ix0, iy0, iz0, nx, ny, nz;
       {
-        const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
+        const float r = tm * gg.invh + 1e-3f;  // slack covers index rounding
         const float fx = (qx - gg.lox) * gg.invh;
         const float fy = (qy - gg.loy) * gg.invh;
         const float fz = (qz - gg.loz) * gg.invh;
@@ -446,9 +521,51 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
       const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
       unsigned short *wl = w_list[wave];
       int nlist = 0;
-      // (3) visit listed cells, 16 per step (a 16-lane row takes 4 cells): 4 independent
-      // coordinate loads per lane in flight, prices from LDS
-      auto visit = [&]() {
+      // a search cube covering most of the grid: scan the cell-sorted objects linearly
+      const bool linear = 2 * nsub > ncell;
+#ifdef MVP_EMD_PROFILE
+      plin = linear ? 1 : 0;
+      pnsub = nsub;
+#endif
+      if (linear) {
+        for (int base = 0; base < n; base += kWave) {  // n % 1024 == 0
+          const float4 o = sc.obj[base + lane];
+          consider(true, base + lane, o);
+        }
+      }
+      int cb = 0;
+      bool enum_done = linear;
+      for (;;) {
+        // enumerate until the list holds at least 64 cells or the sub-box is exhausted
+        while (!enum_done && nlist <= 128 - kWave) {
+          const int i = cb + lane;
+          bool cpass = false;
+          int c = 0;
+          if (i < nsub) {
+            // exact small-integer division via float (i < 1331, divisors <= 121)
+            const int kz = (int)(((float)i + 0.5f) * inv_nxy);
+            const int rem = i - kz * nxy;
+            const int ky = (int)(((float)rem + 0.5f) * inv_nx);
+            const int kx = rem - ky * nx;
+            c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
+            const uint4 cr = s_cell[c];
+            const float dx = __builtin_fmaxf(
+                __builtin_fmaxf(half_bits_to_float(cr.x & 0xFFFFu) - qx, qx - half_bits_to_float(cr.x >> 16)), 0.f);
+            const float dy = __builtin_fmaxf(
+                __builtin_fmaxf(half_bits_to_float(cr.y & 0xFFFFu) - qy, qy - half_bits_to_float(cr.y >> 16)), 0.f);
+            const float dz = __builtin_fmaxf(
+                __builtin_fmaxf(half_bits_to_float(cr.z & 0xFFFFu) - qz, qz - half_bits_to_float(cr.z >> 16)), 0.f);
+            const float tq = tm - __uint_as_float(cr.w);
+            cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
+          }
+          const unsigned long long cmask = __ballot(cpass);
+          if (cpass) wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
+          nlist += __builtin_popcountll(cmask);
+          cb += kWave;
+          enum_done = cb >= nsub;
+        }
+        // (3) visit the listed cells, 16 per step (a 16-lane row takes 4 cells): 4 independent
+        // coordinate loads per lane in flight, prices from LDS
 #ifdef MVP_EMD_PROFILE
         const long long tv0 = __builtin_readcyclecounter();
         pcells += nlist;
@@ -486,59 +603,29 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
 #ifdef MVP_EMD_PROFILE
         tvis += __builtin_readcyclecounter() - tv0;
 #endif
-      };
-      // a search cube covering most of the grid: scan the cell-sorted objects linearly
-      const bool linear = 2 * nsub > ncell;
-#ifdef MVP_EMD_PROFILE
-      plin = linear ? 1 : 0;
-      pnsub = nsub;
-#endif
-      if (linear) {
-        for (int base = 0; base < n; base += 4 * kWave) {  // n % 1024 == 0
-          float4 o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = sc.obj[base + r * kWave + lane];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) consider(true, base + r * kWave + lane, o[r]);
-        }
+        if (enum_done) break;
       }
-      for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
-        const int i = cb + lane;
-        bool cpass = false;
-        int c = 0;
-        if (i < nsub) {
-          // exact small-integer division via float (i < 1331, divisors <= 121)
-          const int kz = (int)(((float)i + 0.5f) * inv_nxy);
-          const int rem = i - kz * nxy;
-          const int ky = (int)(((float)rem + 0.5f) * inv_nx);
-          const int kx = rem - ky * nx;
-          c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
-          const uint4 cr = s_cell[c];
-          const float dx = __builtin_fmaxf(
-              __builtin_fmaxf(half_bits_to_float(cr.x & 0xFFFFu) - qx, qx - half_bits_to_float(cr.x >> 16)), 0.f);
-          const float dy = __builtin_fmaxf(
-              __builtin_fmaxf(half_bits_to_float(cr.y & 0xFFFFu) - qy, qy - half_bits_to_float(cr.y >> 16)), 0.f);
-          const float dz = __builtin_fmaxf(
-              __builtin_fmaxf(half_bits_to_float(cr.z & 0xFFFFu) - qz, qz - half_bits_to_float(cr.z >> 16)), 0.f);
-          const float tq = st.tm - __uint_as_float(cr.w);
-          cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
-        }
-        const unsigned long long cmask = __ballot(cpass);
-        if (cpass) wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
-        nlist += __builtin_popcountll(cmask);
-        if (nlist > 128 - kWave) visit();  // keep room for the next 64
-      }
-      visit();
 
-      if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
+      // (4) merge the lanes: exact best / second best with the reference's tie order
+      top2k_merge_step<0xB1, 0xF>(lb1, lbk, lb2, lb2k, n, tpu, sc.perm);
+      top2k_merge_step<0x4E, 0xF>(lb1, lbk, lb2, lb2k, n, tpu, sc.perm);
+      top2k_merge_step<0x141, 0xF>(lb1, lbk, lb2, lb2k, n, tpu, sc.perm);
+      top2k_merge_step<0x140, 0xF>(lb1, lbk, lb2, lb2k, n, tpu, sc.perm);
+      top2k_merge_step<0x142, 0xA>(lb1, lbk, lb2, lb2k, n, tpu, sc.perm);
+      top2k_merge_step<0x143, 0xC>(lb1, lbk, lb2, lb2k, n, tpu, sc.perm);
+      const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb1), 63));
+      const float b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb2), 63));
+      int bk = __builtin_amdgcn_readlane(lbk, 63);
+      int b2k = __builtin_amdgcn_readlane(lb2k, 63);
+      if (bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
         if (lane == 0) s_err = 1;
-        st.bk = 0;
-        st.b2k = -1;
+        bk = 0;
+        b2k = -1;
       }
 
-      // (4) rebuild the cache from the staged candidates
+      // (5) rebuild the cache from the staged candidates
       if (caching) {
-        float tau = st.b2 - delta;  // everything the search skipped is worth less
+        float tau = b2 - delta;  // everything the search skipped is worth less (seed <= b2)
         int newcc = 0;
         if (nst <= kStage) {
           const bool have = lane < nst;
@@ -585,8 +672,15 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
 #endif
       int drawn = 0;
       if (lane == 0) {
-        record_bid(u, st.bk, st.b1 - st.b2 + eps, j, st.b2k);
-        s_be[u] = e;
+        const float inc = b1 - b2 + eps;
+        if constexpr (W > 1) {
+          publish(u, bk, inc, j, b2k);
+        } else {
+          s_bo[u] = bk;
+          s_binc[u] = inc;
+          s_bj[u] = j;
+          s_b2k[u] = b2k;
+        }
         drawn = atomicAdd(&s_next, 1);
       }
       mi = __builtin_amdgcn_readlane(drawn, 0);
@@ -595,296 +689,281 @@ __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
     const long long tpg = __builtin_readcyclecounter();
     if (t == 0) s_prof[0] += (unsigned long long)(U - nmiss);
 #endif
-    // ---------------- all bids of the round: own ones (W == 1) or everybody's, fetched after
-    // the round's only cross-CU synchronisation
+
+    // ---------------- all bids of the round.  W > 1: thread v polls record v of the cloud-wide
+    // list (member by member, in the order everybody derives from the tracked counts) until both
+    // words carry this round's tag.
     int off_me = 0;
+    int r_o = 0, r_j = -1, r_prev = -1, r_w = 0;
+    float r_inc = 0.f;
+    const bool r_mine = t < Utot;
     if constexpr (W > 1) {
-      if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_U, &s_err, s_gout, &s_abort)) {
-        aborted = true;
-        break;
-      }
-      int cnt[W], total = 0;
+      int cnt[W];
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        cnt[w] = (int)s_gout[2 * w];
+        cnt[w] = s_mcnt[w];
         if (w < wg) off_me += cnt[w];
-        total += cnt[w];
-        if (s_gout[2 * w + 1] != 0u && t == 0) s_err = 1;
       }
-      if (total != Utot && t == 0) s_err = 1;  // cannot happen: every member tracks the same count
-      if (t < total) {
-        int i = t, w = 0;
+      if (r_mine) {
+        int i = t;
 #pragma unroll
         for (int ww = 0; ww < W - 1; ++ww)
-          if (w == ww && i >= cnt[ww]) {
+          if (r_w == ww && i >= cnt[ww]) {
             i -= cnt[ww];
-            w = ww + 1;
+            r_w = ww + 1;
           }
-        const v4u r = ldg16(xb_off(it & 1, w, i));
-        s_bo[t] = (int)r.x;
-        s_binc[t] = __uint_as_float(r.y);
-        s_bj[t] = (int)r.z;
-        s_b2k[t] = (int)r.w;
+        const u64 *p = xb_at(it & 1, r_w, i);
+        u64 a = 0ull, bb = 0ull;
+        bool ok = false;
+        for (unsigned spins = 0; spins < kSpinLimit; ++spins) {
+          a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bb = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (unsigned)(a >> 32) == tag && (unsigned)(bb >> 48) == (tag & 0xFFFFu);
+          if (ok) break;
+          __builtin_amdgcn_s_sleep(8);   // ~0.5k cycles: hundreds of pollers must not crowd the searches' loads out of L2
+        }
+        if (!ok) s_abort = 1;
+        r_o = (int)((unsigned)a & 0xFFFFu);
+        r_j = (int)(((unsigned)a >> 16) & 0xFFFFu);
+        r_inc = __uint_as_float((unsigned)bb);
+        s_bo[t] = r_o;
+        s_bj[t] = r_j;
+        s_binc[t] = r_inc;
+        s_b2k[t] = (int)((unsigned)(bb >> 32) & 0xFFFFu) - 1;
+        s_bm[t] = (unsigned char)r_w;
+      } else if (t >= kEmdThreads - W) {  // the last W threads wait for the members' heartbeats
+        const u64 *p = xb_at(it & 1, kEmdThreads - 1 - t, kTailCap - 1);
+        bool ok = false;
+        for (unsigned spins = 0; spins < kSpinLimit; ++spins) {
+          ok = (unsigned)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
+          if (ok) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) s_abort = 1;
+      }
+    } else {
+      lds_barrier();  // the phase B bids are in the LDS arrays
+      if (r_mine) {
+        r_o = s_bo[t];
+        r_j = s_bj[t];
+        r_inc = s_binc[t];
       }
     }
-    if (t >= Utot && t < Utot + 4 && t < kTailCap) s_bo[t] = -2;  // padding of the GetMax scan
-    lds_barrier();
-#ifdef MVP_EMD_PROFILE
-    const long long tp1 = __builtin_readcyclecounter();
-#endif
-
-    // ---------------- GetMax (emd_cuda.cu:181-194), exactly, for ALL bids of the cloud.  The
-    // winner is the highest bidder inside the 1e-6 band of the object's maximal increment.
-    // W > 1: the bids of one object find each other through the object's owner word in LDS (the
-    // last of them to write its number there represents the group; count and maximal increment
-    // are two LDS atomics on the representative) -- O(1) per bid; W == 1 scans the round's bids.
+    // ---------------- GetMax (emd_cuda.cu:181-194), exactly, for ALL bids of the cloud
     bool r_win = true;
-    int r_prev = -1;
     if constexpr (LOWN) {
-      const bool mine = t < Utot;
-      int o = 0;
-      float inc = 0.f;
-      if (mine) {
-        o = s_bo[t];
-        inc = s_binc[t];
-        r_prev = s_owner[o];           // owner before this round (0xFFFF: free)
+      if (r_mine) {
+        r_prev = s_owner[r_o];           // owner before this round (0xFFFF: free)
         s_gcnt[t] = 0;
         s_gmax[t] = 0u;
       }
       lds_barrier();
-      if (mine) s_owner[o] = (unsigned short)(0x8000u | (unsigned)t);  // person ids are < 0x8000
+      if (s_abort) {  // a member stopped publishing (tens of seconds): give up, loudly
+        aborted = true;
+        break;
+      }
+#ifdef MVP_EMD_PROFILE
+      const long long tp1 = __builtin_readcyclecounter();
+      cyc_fetch += tp1 - tpg;
+#endif
+      if (r_mine) s_owner[r_o] = (unsigned short)(0x8000u | (unsigned)t);  // person ids are < 0x8000
       lds_barrier();
       int rep = 0;
-      if (mine) {
-        rep = s_owner[o] & 0x7FFF;
+      if (r_mine) {
+        rep = s_owner[r_o] & 0x7FFF;
         atomicAdd(&s_gcnt[rep], 1);
-        atomicMax(&s_gmax[rep], emd_f2ord(inc));
+        atomicMax(&s_gmax[rep], emd_f2ord(r_inc));
       }
       lds_barrier();
-      if (mine) {
-        if (s_gcnt[rep] > 1) {  // rare: several bids on this object
-          const float mxi = emd_ord2f(s_gmax[rep]);
-          const int j = s_bj[t];
-          r_win = emd_in_band(inc, mxi);
-          if (r_win)
-            for (int v = 0; v < Utot; ++v)
-              if (s_bo[v] == o && s_bj[v] > j && emd_in_band(s_binc[v], mxi)) r_win = false;
-        }
-        if (last) r_win = true;
-        s_prevo[t] = (unsigned short)r_prev;
-        s_win[t] = r_win ? (r_prev != 0xFFFF ? 2 : 1) : 0;
-      }
-    } else if (t < Utot) {
-      const int o = s_bo[t], j = s_bj[t];
-      const float inc = s_binc[t];
-      // branch-free scan, four bids per LDS read (the arrays are padded with object -2)
-      float mxi = -1e9f;
-      int same = 0;
-      const int4 *bo4 = reinterpret_cast<const int4 *>(s_bo);
-      const float4 *bi4 = reinterpret_cast<const float4 *>(s_binc);
-      const int n4 = (Utot + 3) >> 2;
-#pragma unroll 4
-      for (int v = 0; v < n4; ++v) {
-        const int4 ov = bo4[v];
-        const float4 iv = bi4[v];
-        same += (ov.x == o) + (ov.y == o) + (ov.z == o) + (ov.w == o);
-        mxi = __builtin_fmaxf(mxi, ov.x == o ? iv.x : -1e9f);
-        mxi = __builtin_fmaxf(mxi, ov.y == o ? iv.y : -1e9f);
-        mxi = __builtin_fmaxf(mxi, ov.z == o ? iv.z : -1e9f);
-        mxi = __builtin_fmaxf(mxi, ov.w == o ? iv.w : -1e9f);
-      }
-      if (same > 1) {  // rare: several bids on this object
-        r_win = emd_in_band(inc, mxi);
+      if (r_mine && s_gcnt[rep] > 1) {  // rare: several bids on this object
+        const float mxi = emd_ord2f(s_gmax[rep]);
+        r_win = emd_in_band(r_inc, mxi);
         if (r_win)
           for (int v = 0; v < Utot; ++v)
-            if (s_bo[v] == o && s_bj[v] > j && emd_in_band(s_binc[v], mxi)) r_win = false;
+            if (s_bo[v] == r_o && s_bj[v] > r_j && emd_in_band(s_binc[v], mxi)) r_win = false;
       }
-      if (last) r_win = true;
-      const bool owned = (s_owned[o >> 5] >> (o & 31)) & 1u;
-      s_win[t] = r_win ? (owned ? 2 : 1) : 0;
+#ifdef MVP_EMD_PROFILE
+      cyc_resolve += __builtin_readcyclecounter() - tp1;
+#endif
+    } else {
+      if (t >= Utot && t < Utot + 4 && t < kTailCap) s_bo[t] = -2;  // padding of the scan
+      lds_barrier();
+      if (r_mine) {
+        // branch-free scan, four bids per LDS read
+        float mxi = -1e9f;
+        int same = 0;
+        const int4 *bo4 = reinterpret_cast<const int4 *>(s_bo);
+        const float4 *bi4 = reinterpret_cast<const float4 *>(s_binc);
+        const int n4 = (Utot + 3) >> 2;
+#pragma unroll 4
+        for (int v = 0; v < n4; ++v) {
+          const int4 ov = bo4[v];
+          const float4 iv = bi4[v];
+          same += (ov.x == r_o) + (ov.y == r_o) + (ov.z == r_o) + (ov.w == r_o);
+          mxi = __builtin_fmaxf(mxi, ov.x == r_o ? iv.x : -1e9f);
+          mxi = __builtin_fmaxf(mxi, ov.y == r_o ? iv.y : -1e9f);
+          mxi = __builtin_fmaxf(mxi, ov.z == r_o ? iv.z : -1e9f);
+          mxi = __builtin_fmaxf(mxi, ov.w == r_o ? iv.w : -1e9f);
+        }
+        if (same > 1) {  // rare: several bids on this object
+          r_win = emd_in_band(r_inc, mxi);
+          if (r_win)
+            for (int v = 0; v < Utot; ++v)
+              if (s_bo[v] == r_o && s_bj[v] > r_j && emd_in_band(s_binc[v], mxi)) r_win = false;
+        }
+        r_prev = ((s_owned[r_o >> 5] >> (r_o & 31)) & 1u) ? 0 : 0xFFFF;  // W == 1: only "owned or free" is known here
+      }
+      lds_barrier();  // (every scan is done before owner bits / prices change)
     }
-    if (t == 0) s_nfree = 0;
-    lds_barrier();
+    if (last) r_win = true;
+    const bool r_evict = r_mine && r_win && !last && r_prev != 0xFFFF;
 #ifdef MVP_EMD_PROFILE
     const long long tpr = __builtin_readcyclecounter();
 #endif
 
-    // ---------------- Assign (emd_cuda.cu:196-215).  This member's own bidders are handled by four
-    // threads each; the loads of an evicted person's record and cache are issued first so that they
-    // travel while part 1 runs.
-    const int ub = t >> 2, q4 = t & 3;
-    const bool act = ub < U;
-    const int vb = off_me + ub;
-    int a_o = -1, a_j = -1, a_e = 0, a_code = 0;
-    float a_inc = 0.f;
-    if (act) {
-      a_o = s_bo[vb];
-      a_inc = s_binc[vb];
-      a_j = s_bj[vb];
-      a_e = s_be[ub];
-      a_code = s_win[vb];
-    }
-    const bool a_evict = a_code == 2 && !last;
-    int a_prev = -1;
-    if constexpr (LOWN) {
-      if (a_evict) a_prev = s_prevo[vb];
-    } else {
-      if (q4 == 0 && a_evict) a_prev = ld_i32(&sc.ostate[a_o].z);
-      a_prev = quad_i32<0x00>(a_prev);  // quad_perm [0,0,0,0]
-    }
-    // cache record = chunks of 16 bytes: 0-1 slots, 2-5 distances, 6 {tau, count}; thread q4 moves 2 q4, 2 q4 + 1
-    v4u in0 = {0u, 0u, 0u, 0u}, in1 = {0u, 0u, 0u, 0u}, pa = {0u, 0u, 0u, 0u}, pb = {0u, 0u, 0u, 0u};
-    if (a_evict) {
-      const unsigned pvc = off_cache + (unsigned)a_prev * kCacheRec;
-      if (caching) {
-        in0 = ldg16(pvc + (2u * q4) * 16u);
-        if (q4 < 3) in1 = ldg16(pvc + (2u * q4 + 1u) * 16u);
-      }
-      if (q4 == 0) {
+    // ---------------- Assign (emd_cuda.cu:196-215), by the bid's own thread.  A bid of this
+    // member also moves its pool entry; the loads of an evicted person's record and cache are
+    // issued first so that they travel while the prices are updated.
+    const bool a_own = r_mine && r_w == wg;
+    const int a_u = t - off_me;
+    int a_e = 0, a_prev = -1;
+    v4u ch[7] = {}, pa = {0u, 0u, 0u, 0u}, pb = {0u, 0u, 0u, 0u};
+    if (a_own) {
+      a_e = s_be[a_u];
+      if (r_evict) {
+        if constexpr (LOWN) a_prev = r_prev;
+        else a_prev = ld_i32(&sc.ostate[r_o].z);
+        const unsigned pvc = off_cache + (unsigned)a_prev * kCacheRec;
+        if (caching) {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) ch[c] = ldg16(pvc + (unsigned)c * 16u);  // 0-1 slots, 2-5 distances, 6 {tau, count}
+        }
         pa = ldg16(off_person + (2u * (unsigned)a_prev) * 16u);
         pb = ldg16(off_person + (2u * (unsigned)a_prev + 1u) * 16u);
       }
     }
-
-    // part 1: every price rise (and new owner) of the round goes into this member's own copy
-    if (!last && t < Utot && s_win[t]) {
-      const int o = s_bo[t];
-      if (s_win[t] == 1) atomicAdd(&s_nfree, 1);  // a free object gets its first owner: one unassigned person fewer
-      if constexpr (LOWN) s_owner[o] = (unsigned short)s_bj[t];
-      else if (s_win[t] == 1) atomicOr(&s_owned[o >> 5], 1u << (o & 31));
-      const float pold = s_price[o];
-      const float pnew = pold + s_binc[t];
-      s_price[o] = pnew;
+    // every price rise (and new owner) of the round goes into this member's own copy
+    if (r_mine && r_win && !last) {
+      if (r_prev == 0xFFFF) {  // a free object gets its first owner: one unassigned person fewer
+        atomicAdd(&s_nfree, 1);
+        atomicSub(&s_mcnt[r_w], 1);
+        if constexpr (!LOWN) atomicOr(&s_owned[r_o >> 5], 1u << (r_o & 31));
+      }
+      if constexpr (LOWN) s_owner[r_o] = (unsigned short)r_j;
+      const float pold = s_price[r_o];
+      const float pnew = pold + r_inc;
+      s_price[r_o] = pnew;
       // the object's cell: the last c with c_start[c] <= o; its lower bound only when (one of)
       // its cheapest members got dearer
       int lo = 0, hi = ncell;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if ((int)c_start[mid] <= o) lo = mid;
+        if ((int)c_start[mid] <= r_o) lo = mid;
         else hi = mid;
       }
       float *lbp = reinterpret_cast<float *>(&s_cell[lo]) + 3;
       if (pold <= *lbp) {
         float pm = pnew;
         const int e1 = c_start[lo + 1];
-        for (int s2 = c_start[lo]; s2 < e1; ++s2) pm = __builtin_fminf(pm, s2 == o ? pm : s_price[s2]);
+        for (int s2 = c_start[lo]; s2 < e1; ++s2) pm = __builtin_fminf(pm, s2 == r_o ? pm : s_price[s2]);
         *lbp = pm;
       }
     }
-
-    // part 2: this member's own bidders
-    if (a_code != 0 && last) {
-      if (q4 == 0) st_i32(&ass[a_j], a_o);
-    } else if (a_code != 0) {
-      // the winner leaves the pool: its cache goes to scratch; the person it evicts takes the entry over
-      const unsigned myc = off_cache + (unsigned)a_j * kCacheRec;
-      if (caching) {
-        const int cc = e_i[a_e].w;
-        if (q4 == 0) {
-          const v4u *src = reinterpret_cast<const v4u *>(&e_cs[a_e][0]);
-          stg16(src[0], myc);
-          stg16(src[1], myc + 16u);
-        } else if (q4 < 3) {
-          const v4u *src = reinterpret_cast<const v4u *>(&e_cd[a_e][0]);
-          stg16(src[2 * q4 - 2], myc + (2u * q4) * 16u);
-          stg16(src[2 * q4 - 1], myc + (2u * q4 + 1u) * 16u);
-        } else {
+    if (a_own) {
+      if (last) {
+        st_i32(&ass[r_j], r_o);
+      } else if (r_win) {
+        // the winner leaves the pool: its cache and hints go to scratch
+        const unsigned myc = off_cache + (unsigned)r_j * kCacheRec;
+        if (caching) {
+          const v4u *cs = reinterpret_cast<const v4u *>(&e_cs[a_e][0]);
+          const v4u *cd = reinterpret_cast<const v4u *>(&e_cd[a_e][0]);
+          stg16(cs[0], myc);
+          stg16(cs[1], myc + 16u);
+          stg16(cd[0], myc + 32u);
+          stg16(cd[1], myc + 48u);
+          stg16(cd[2], myc + 64u);
+          stg16(cd[3], myc + 80u);
           v4u r;
           r.x = __float_as_uint(e_tau[a_e]);
-          r.y = (unsigned)cc;
+          r.y = (unsigned)e_i[a_e].w;
           r.z = 0u;
           r.w = 0u;
           stg16(r, myc + 96u);
         }
-      }
-      if (q4 == 0) {
-        if (a_evict) st_i32(&ass[a_prev], -1);
-        if constexpr (!LOWN) st_i32(&sc.ostate[a_o].z, a_j);
-        st_i32(&ass[a_j], a_o);
+        if (r_evict) st_i32(&ass[a_prev], -1);
+        if constexpr (!LOWN) st_i32(&sc.ostate[r_o].z, r_j);
+        st_i32(&ass[r_j], r_o);
         v4u hi;
-        hi.x = (unsigned)a_o;
-        hi.y = (unsigned)a_o;
-        hi.z = (unsigned)s_b2k[vb];
-        hi.w = __float_as_uint(a_inc);
-        stg16(hi, off_person + (2u * (unsigned)a_j + 1u) * 16u);
-      }
-      // the entry: handed to the evicted person, or dead
-      if (a_evict) {
-        if (caching) {
-          if (q4 == 0) {
-            v4u *dst = reinterpret_cast<v4u *>(&e_cs[a_e][0]);
-            dst[0] = in0;
-            dst[1] = in1;
-          } else if (q4 < 3) {
-            v4u *dst = reinterpret_cast<v4u *>(&e_cd[a_e][0]);
-            dst[2 * q4 - 2] = in0;
-            dst[2 * q4 - 1] = in1;
-          } else {
-            e_tau[a_e] = __uint_as_float(in0.x);
-            e_i[a_e].w = (int)in0.y;
+        hi.x = (unsigned)r_o;
+        hi.y = (unsigned)r_o;
+        hi.z = (unsigned)s_b2k[t];
+        hi.w = __float_as_uint(r_inc);
+        stg16(hi, off_person + (2u * (unsigned)r_j + 1u) * 16u);
+        // the entry: handed to the evicted person, or dead
+        if (r_evict) {
+          if (caching) {
+            v4u *cs = reinterpret_cast<v4u *>(&e_cs[a_e][0]);
+            v4u *cd = reinterpret_cast<v4u *>(&e_cd[a_e][0]);
+            cs[0] = ch[0];
+            cs[1] = ch[1];
+            cd[0] = ch[2];
+            cd[1] = ch[3];
+            cd[2] = ch[4];
+            cd[3] = ch[5];
+            e_tau[a_e] = __uint_as_float(ch[6].x);
           }
-        }
-        if (q4 == 0) {
           e_q[a_e] = make_float4(__uint_as_float(pa.x), __uint_as_float(pa.y), __uint_as_float(pa.z), 0.f);
-          e_i[a_e].x = a_prev;
-          e_i[a_e].y = (int)pb.y;
-          e_i[a_e].z = (int)pb.z;
-          if (!caching) e_i[a_e].w = 0;
+          e_i[a_e] = make_int4(a_prev, (int)pb.y, (int)pb.z, caching ? (int)ch[6].y : 0);
+        } else {
+          e_live[a_e] = 0;
         }
-      } else if (q4 == 0) {
-        e_live[a_e] = 0;
+      } else {
+        // lost: keeps its entry; this bid's best / second best seed the next one
+        e_i[a_e].y = r_o;
+        e_i[a_e].z = s_b2k[t];
       }
-    } else if (act && q4 == 0) {
-      // lost: keeps its entry; this bid's best / second best seed the next one
-      e_i[a_e].y = a_o;
-      e_i[a_e].z = s_b2k[vb];
     }
     // W == 1: later rounds re-read what this one stored (records, caches) through the same
-    // CU -- wait for the stores; W > 1: the next all-gather drains them
+    // CU -- wait for the stores; W > 1: the __syncthreads after the next phase A does
     if constexpr (W == 1) __syncthreads();
     else lds_barrier();
 #ifdef MVP_EMD_PROFILE
     const long long tp2 = __builtin_readcyclecounter();
 #endif
 
-    // ---------------- next round's order list: the live entries, by ballot
-    unsigned long long lm = 0ull;
-    bool live = false;
-    if (t < POOL) {
-      live = e_live[t] != 0;
-      lm = __ballot(live);
-      if (lane == 0) s_wcnt[wave] = __builtin_popcountll(lm);
-    }
-    lds_barrier();
-    if (t < POOL) {
+    // ---------------- next round's order list: the live entries, by wave 0
+    if (wave == 0) {
       int base = 0;
-      for (int w = 0; w < wave; ++w) base += s_wcnt[w];
-      if (live) s_order[base + __builtin_popcountll(lm & ((1ull << lane) - 1ull))] = (unsigned short)t;
-    }
-    if (t == 0) {
-      int tot = 0;
-      for (int w = 0; w < POOL / kWave; ++w) tot += s_wcnt[w];
-      s_U = tot;
-      s_next = kEmdWaves;
-      s_nmiss = 0;
+#pragma unroll
+      for (int h = 0; h < POOL / kWave; ++h) {
+        const bool live = e_live[h * kWave + lane] != 0;
+        const unsigned long long lm = __ballot(live);
+        if (live) s_order[base + __builtin_popcountll(lm & ((1ull << lane) - 1ull))] = (unsigned short)(h * kWave + lane);
+        base += __builtin_popcountll(lm);
+      }
+      if (lane == 0) {
+        s_U = base;
+        s_next = kEmdWaves;
+        s_nmiss = 0;
+        if (base != s_mcnt[wg]) s_err = 1;  // cannot happen: the tracked count is this member's pool
+      }
     }
     lds_barrier();
     U = s_U;
-    Utot -= s_nfree;
+    Utot = U0 - s_nfree;   // (cumulative)
 #ifdef MVP_EMD_PROFILE
     const long long tp3 = __builtin_readcyclecounter();
     cyc_a += tpa - tp0;
     cyc_b += tpg - tpa;
-    cyc_gather += tp1 - tpg;
-    cyc_resolve += tpr - tp1;
     cyc_assign += tp2 - tpr;
     cyc_compact += tp3 - tp2;
 #endif
   }
 #ifdef MVP_EMD_PROFILE
   if (t == 0 && cloud < 2) {
-    printf("tail cloud %d wg %d/%d: rounds %lld own bids %lld | cycles setup %lld phaseA %lld phaseB %lld gather+fetch %lld resolve %lld assign %lld compact %lld\n",
-           cloud, wg, W, n_rounds, n_bids, cyc_setup, cyc_a, cyc_b, cyc_gather, cyc_resolve, cyc_assign, cyc_compact);
+    printf("tail cloud %d wg %d/%d: rounds %lld own bids %lld | cycles setup %lld phaseA %lld phaseB %lld fetch %lld resolve %lld assign %lld compact %lld\n",
+           cloud, wg, W, n_rounds, n_bids, cyc_setup, cyc_a, cyc_b, cyc_fetch, cyc_resolve, cyc_assign, cyc_compact);
     printf("tail cloud %d wg %d: hits %llu misses %llu (%llu cycles each, visits %llu) linear %llu mean sub-box %llu cells visited %llu home-seeds %llu\n",
            cloud, wg, s_prof[0], s_prof[1], s_prof[3] / (s_prof[1] + 1), s_prof[11] / (s_prof[1] + 1), s_prof[4],
            s_prof[5] / (s_prof[1] + 1), s_prof[6] / (s_prof[1] + 1), s_prof[8]);
