@@ -33,10 +33,10 @@ class PCN_encoder(nn.Module):
         # x (B, 3, N) -> per-point features (B, 256, N) -> global max (B, 256, 1), tiled back and
         # concatenated (B, 512, N) -> second per-point MLP (B, output_size, N) -> global max (B, output_size)
         num_points = x.size(2)
-        local = self.conv2(F.relu(self.conv1(x)))
+        local = self.conv2(self.conv1(x, relu=True))
         pooled = local.max(dim=2, keepdim=True)[0]
         local = torch.cat((local, pooled.expand(-1, -1, num_points)), 1)
-        return self.conv4(F.relu(self.conv3(local))).max(dim=2)[0]
+        return self.conv4(self.conv3(local, relu=True)).max(dim=2)[0]
 
 
 class PCN_decoder(nn.Module):
@@ -75,7 +75,7 @@ class PCN_decoder(nn.Module):
         global_feat = x.unsqueeze(2).expand(-1, -1, self.num_fine)
 
         feat = torch.cat((grid_feat, center, global_feat), 1)
-        fine = self.conv3(F.relu(self.conv2(F.relu(self.conv1(feat))))) + center
+        fine = self.conv3(self.conv2(self.conv1(feat, relu=True), relu=True)) + center
         return coarse, fine
 
 

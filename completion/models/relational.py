@@ -165,8 +165,8 @@ class SA_SKN_Res_encoder(nn.Module):
         g = self.dropout(self.af(self.fc2(self.dropout(self.af(self.fc1(g))))))
         g = g.unsqueeze(2).expand(-1, -1, self.pts_num[3]).unsqueeze(2)
 
-        x = self.af(self.conv6(torch.cat([g, skips[3]], 1)))
+        x = self.conv6(torch.cat([g, skips[3]], 1), relu=True)
         for level, conv in ((2, self.conv7), (1, self.conv8), (0, self.conv9)):
             x = self._edge_unpooling(x, pts[level + 1], pts[level])
-            x = self.af(conv(torch.cat([x, skips[level]], 1)))
+            x = conv(torch.cat([x, skips[level]], 1), relu=True)
         return self.conv_out(x).squeeze(2)

@@ -44,7 +44,7 @@ class Folding(nn.Module):
         global_feat = global_feat.unsqueeze(2).expand(-1, -1, total).repeat(self.num_models, 1, 1)
         grid_feat = self.grid.to(point_feat.device).unsqueeze(0).repeat(batch_size, num_points, 1).transpose(1, 2)
         features = torch.cat([global_feat, point_feat, grid_feat], dim=1)
-        return F.relu(self.conv(features))
+        return self.conv(features.contiguous(), relu=True)
 
 
 class Linear_ResBlock(nn.Module):
@@ -125,7 +125,7 @@ class MSAP_SKN_decoder(nn.Module):
         if self.up_scale >= 2:
             dense_feat = self.expansion1(dense_feat)
 
-        coarse_features = self.af(self.conv_cup1(dense_feat))
+        coarse_features = self.conv_cup1(dense_feat, relu=True)
         coarse_high = self.conv_cup2(coarse_features)
 
         if coarse_high.size(2) > self.num_fps:
@@ -148,9 +148,9 @@ class MSAP_SKN_decoder(nn.Module):
                 up_features = self.expansion2(coarse_features, global_feat)
                 ratio = self.num_fine // self.num_coarse
                 center = coarse.unsqueeze(3).expand(-1, -1, -1, ratio).reshape(batch_size, 3, self.num_fine)
-                fine = self.conv_f2(self.af(self.conv_f1(up_features))) + center
+                fine = self.conv_f2(self.conv_f1(up_features, relu=True)) + center
             else:
-                fine = self.conv_f2(self.af(self.conv_f1(self.expansion2(coarse_features))))
+                fine = self.conv_f2(self.conv_f1(self.expansion2(coarse_features), relu=True))
         else:
             assert coarse.size(2) == self.num_fine
             fine = coarse

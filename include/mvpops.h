@@ -271,21 +271,29 @@ int mvp_group_points_grad(int b, int c, int n, int npoints, int nsample,
  * npoints*nsample, or three_interpolate's n) and r index entries per column
  * (1, or 3 for three_interpolate); 0 = shape not covered (n_dst > 8192).  With
  * scratch == NULL, scratch_bytes too small or a shape that is not covered the
- * _ws entry points run the plain ones. */
+ * _ws entry points run the plain ones.
+ * mode: bit 0 MVP_SCATTER_OVERWRITE -- grad_points is WRITTEN (every element;
+ * it need not be zero on entry and is not read), saving the caller's zero fill
+ * and the read-modify-write; bit 1 MVP_SCATTER_INDEX_READY -- `scratch` still
+ * holds the inverted index a previous call built for exactly this idx (and
+ * weight): the sort is skipped (the same neighbour graph is differentiated
+ * through several gathers per step). */
+#define MVP_SCATTER_OVERWRITE 1
+#define MVP_SCATTER_INDEX_READY 2
 long long mvp_scatter_scratch_bytes(int b, int n_dst, int m_src, int r);
 int mvp_gather_points_grad_ws(int b, int c, int n, int npoints,
                               const float *grad_out, const int *idx,
                               float *grad_points, void *scratch,
-                              long long scratch_bytes, void *stream);
+                              long long scratch_bytes, int mode, void *stream);
 int mvp_group_points_grad_ws(int b, int c, int n, int npoints, int nsample,
                              const float *grad_out, const int *idx,
                              float *grad_points, void *scratch,
-                             long long scratch_bytes, void *stream);
+                             long long scratch_bytes, int mode, void *stream);
 int mvp_three_interpolate_grad_ws(int b, int c, int n, int m,
                                   const float *grad_out, const int *idx,
                                   const float *weight, float *grad_points,
                                   void *scratch, long long scratch_bytes,
-                                  void *stream);
+                                  int mode, void *stream);
 
 /* Shared-weight neighbourhood aggregation of VRCNet's point self-attention (no
  * native counterpart in the reference: completion/models/vrcnet.py:52-55
@@ -318,6 +326,46 @@ long long mvp_pointwise_wgrad_scratch_bytes(int b, int cin, int cout, int len);
 int mvp_pointwise_wgrad(int b, int cin, int cout, int len, const float *x,
                         const float *gy, float *gw, float *gb, void *scratch,
                         long long scratch_bytes, void *stream);
+
+/* ------------------------------------------- grouped-feature MLP on MFMA */
+
+/* 1x1 convolution / per-point linear map with a fused epilogue, on the matrix
+ * cores (v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate -- the result is
+ * a k-ordered fmaf chain, no reduced precision).  No native counterpart in the
+ * reference, which calls cuDNN through nn.Conv1d / nn.Conv2d(kernel_size=1) and
+ * separate bias / ReLU / add / max kernels (completion/model_utils.py:26-55,
+ * completion/models/vrcnet.py:21-57, ecg.py:36-65, pcn.py).
+ *   x (b, cin, len), w (cout, cin) [w_kmajor = 0] or (cin, cout) [w_kmajor = 1]
+ *   xmask (b, cin, len) or NULL: x is taken as 0 where xmask <= 0 (the data
+ *         gradient of a fused ReLU: x = grad_out, xmask = the layer's output)
+ *   t[b,co,l] = sum_ci w(co,ci) x[b,ci,l] + bias[co]        (bias may be NULL)
+ *   t = max(t, 0)                                           if relu
+ *   u[b,co,g] = max_{l in group g} t[b,co,l]                groups of `group`
+ *                                                            consecutive columns
+ *                                                            (1, 2, 4, ..., 32)
+ *   y[b,co,g] = u + residual[b,co,g]                        (residual may be NULL)
+ * y, residual: (b, cout, len / group).  len % 4 == 0, len % group == 0, x 16-byte
+ * aligned.  The data gradient of the plain map is the same call with the forward
+ * weight, cin and cout swapped and w_kmajor = 1. */
+int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float *x,
+                       const float *xmask, const float *w, int w_kmajor,
+                       const float *bias, const float *residual, int relu,
+                       int group, float *y, void *stream);
+
+/* Weight (and bias) gradient of the same map on the matrix cores:
+ *   gw[co,ci] = sum_b sum_l g[b,co,l] x[b,ci,l],  gb[co] = sum_b sum_l g[b,co,l]
+ * with g = gy, or gy where gymask > 0 and 0 elsewhere (fused ReLU).  gb may be
+ * NULL.  The b*len positions are split over workgroups that write partial
+ * tiles into `scratch` (mvp_pointwise_wgrad_mfma_scratch_bytes(...) bytes; 0 =
+ * shape not covered), a second kernel adds them in a fixed order: no float
+ * atomics, bit-reproducible.  gw, gb are overwritten.  len % 4 == 0, operands
+ * 16-byte aligned. */
+long long mvp_pointwise_wgrad_mfma_scratch_bytes(int b, int cin, int cout,
+                                                 int len, int with_bias);
+int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const float *x,
+                             const float *gy, const float *gymask, float *gw,
+                             float *gb, void *scratch, long long scratch_bytes,
+                             void *stream);
 
 /* ------------------------------------------------ registration (DCP) head */
 

@@ -37,13 +37,15 @@ SIGNATURES = {
     "mvp_gather_points_grad": "iiiippp",
     "mvp_group_points": "iiiiippp",
     "mvp_group_points_grad": "iiiiippp",
-    "mvp_gather_points_grad_ws": "iiiippppq",
-    "mvp_group_points_grad_ws": "iiiiippppq",
-    "mvp_three_interpolate_grad_ws": "iiiipppppq",
+    "mvp_gather_points_grad_ws": "iiiippppqi",
+    "mvp_group_points_grad_ws": "iiiiippppqi",
+    "mvp_three_interpolate_grad_ws": "iiiipppppqi",
     "mvp_share_weighted_sum": "iiiiippp",
     "mvp_share_weighted_sum_grad": "iiiiippppp",
     "mvp_pointwise_wgrad": "iiiipppppq",
     "mvp_kabsch_svd3": "ipppppp",
+    "mvp_pointwise_mfma": "iiiipppippiip",
+    "mvp_pointwise_wgrad_mfma": "iiiippppppq",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
@@ -86,6 +88,8 @@ def load():
     lib.mvp_scatter_scratch_bytes.argtypes = [ctypes.c_int] * 4
     lib.mvp_pointwise_wgrad_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_pointwise_wgrad_scratch_bytes.argtypes = [ctypes.c_int] * 4
+    lib.mvp_pointwise_wgrad_mfma_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_pointwise_wgrad_mfma_scratch_bytes.argtypes = [ctypes.c_int] * 5
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
@@ -160,8 +164,13 @@ def pointwise_wgrad_scratch_bytes(b, cin, cout, length):
     return int(load().mvp_pointwise_wgrad_scratch_bytes(int(b), int(cin), int(cout), int(length)))
 
 
+def pointwise_wgrad_mfma_scratch_bytes(b, cin, cout, length, with_bias):
+    """Scratch of mvp_pointwise_wgrad_mfma (0: shape not covered)."""
+    return int(load().mvp_pointwise_wgrad_mfma_scratch_bytes(int(b), int(cin), int(cout), int(length), int(with_bias)))
+
+
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
     return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes",
-            "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes"] \
+            "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes", "mvp_pointwise_wgrad_mfma_scratch_bytes"] \
         + list(SIGNATURES)

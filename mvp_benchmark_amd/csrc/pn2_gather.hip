@@ -296,7 +296,9 @@ __global__ __launch_bounds__(kScThreads) void transpose_index_kernel(
 
 // grid (channel strips of CH rows, clouds).  D = destinations per thread,
 // CHUNK = columns staged per step (CH * CHUNK floats of LDS).
-template <bool WEIGHTED, int D, int CH, int CHUNK>
+// OVERWRITE: grad_points is written (every element), not accumulated into -- no zero fill by
+// the caller, no read of the destination.
+template <bool WEIGHTED, int D, int CH, int CHUNK, bool OVERWRITE>
 __global__ __launch_bounds__(kScThreads) __attribute__((amdgpu_waves_per_eu(D == 8 ? 4 : 8, 8))) void transposed_reduce_kernel(
     int c, int n_dst, int m_src, const float *__restrict__ grad_out, const int *__restrict__ offsets,
     const int *__restrict__ list, float *__restrict__ grad_points) {
@@ -394,7 +396,10 @@ __global__ __launch_bounds__(kScThreads) __attribute__((amdgpu_waves_per_eu(D ==
     if (j < n_dst) {
 #pragma unroll
       for (int k = 0; k < CH; ++k)
-        if (k < cn) dst[(size_t)k * n_dst + j] += acc[d][k];
+        if (k < cn) {
+          if constexpr (OVERWRITE) dst[(size_t)k * n_dst + j] = acc[d][k];
+          else dst[(size_t)k * n_dst + j] += acc[d][k];
+        }
     }
   }
 }
@@ -409,18 +414,27 @@ static long long transposed_scratch_bytes(int b, int n_dst, int m_src, int r) {
   return (long long)b * per_cloud;
 }
 
+// mode bit 0 (MVP_SCATTER_OVERWRITE): write instead of accumulate; bit 1 (MVP_SCATTER_INDEX_READY):
+// the scratch already holds the transposed index of exactly this (idx, weight) -- skip the sort.
 template <bool WEIGHTED>
 static void transposed_scatter(int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx,
-                               const float *weight, float *grad_points, void *scratch, hipStream_t stream) {
+                               const float *weight, float *grad_points, void *scratch, int mode, hipStream_t stream) {
   const int chunk = tr_chunk(n_dst);
   const int nq = (m_src + chunk - 1) / chunk;
   int *offsets = static_cast<int *>(scratch);
   int *list = offsets + (size_t)b * nq * (n_dst + 1);
-  hipLaunchKernelGGL(transpose_index_kernel<WEIGHTED>, dim3(nq, b), dim3(kScThreads), 0, stream, n_dst, m_src, chunk,
-                     idx, weight, offsets, list);
+  if (!(mode & MVP_SCATTER_INDEX_READY))
+    hipLaunchKernelGGL(transpose_index_kernel<WEIGHTED>, dim3(nq, b), dim3(kScThreads), 0, stream, n_dst, m_src, chunk,
+                       idx, weight, offsets, list);
 #define MVP_TR_LAUNCH(DD, CH, CHUNK)                                                                              \
-  hipLaunchKernelGGL((transposed_reduce_kernel<WEIGHTED, DD, CH, CHUNK>), dim3((c + CH - 1) / CH, b),             \
-                     dim3(kScThreads), 0, stream, c, n_dst, m_src, grad_out, offsets, list, grad_points)
+  do {                                                                                                            \
+    if (mode & MVP_SCATTER_OVERWRITE)                                                                             \
+      hipLaunchKernelGGL((transposed_reduce_kernel<WEIGHTED, DD, CH, CHUNK, true>), dim3((c + CH - 1) / CH, b),   \
+                         dim3(kScThreads), 0, stream, c, n_dst, m_src, grad_out, offsets, list, grad_points);     \
+    else                                                                                                          \
+      hipLaunchKernelGGL((transposed_reduce_kernel<WEIGHTED, DD, CH, CHUNK, false>), dim3((c + CH - 1) / CH, b),  \
+                         dim3(kScThreads), 0, stream, c, n_dst, m_src, grad_out, offsets, list, grad_points);     \
+  } while (0)
   if (n_dst <= kScThreads) MVP_TR_LAUNCH(1, 8, 1536);
   else if (n_dst <= 2 * kScThreads) MVP_TR_LAUNCH(2, 8, 1536);
   else if (n_dst <= 4 * kScThreads) MVP_TR_LAUNCH(4, 4, 3072);
@@ -558,35 +572,49 @@ extern "C" long long mvp_scatter_scratch_bytes(int b, int n_dst, int m_src, int 
   return transposed_scratch_bytes(b, n_dst, m_src, r);
 }
 
+// The plain kernels accumulate: an overwrite request that falls back to them zero-fills first.
+static int zero_for_overwrite(int mode, float *grad_points, long long count, void *stream) {
+  if (!(mode & MVP_SCATTER_OVERWRITE) || count <= 0) return MVP_OK;
+  if (!grad_points) return MVP_EBADARG;
+  if (hipMemsetAsync(grad_points, 0, (size_t)count * sizeof(float), as_stream(stream)) != hipSuccess)
+    return check_launch("mvp_*_grad_ws (zero fill)");
+  return MVP_OK;
+}
+
 extern "C" int mvp_gather_points_grad_ws(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
-                                         float *grad_points, void *scratch, long long scratch_bytes,
+                                         float *grad_points, void *scratch, long long scratch_bytes, int mode,
                                          void *stream) {
   if (b < 0 || c < 0 || n < 0 || npoints < 0) return MVP_EBADSHAPE;
   const long long need = transposed_scratch_bytes(b, n, npoints, 1);
-  if (c == 0 || !scratch || need == 0 || scratch_bytes < need)
+  if (c == 0 || npoints == 0 || !scratch || need == 0 || scratch_bytes < need) {
+    if (const int rc = zero_for_overwrite(mode, grad_points, (long long)b * c * n, stream)) return rc;
     return mvp_gather_points_grad(b, c, n, npoints, grad_out, idx, grad_points, stream);
+  }
   if (!grad_out || !idx || !grad_points) return MVP_EBADARG;
-  transposed_scatter<false>(b, c, n, npoints, grad_out, idx, nullptr, grad_points, scratch, as_stream(stream));
+  transposed_scatter<false>(b, c, n, npoints, grad_out, idx, nullptr, grad_points, scratch, mode, as_stream(stream));
   return check_launch("mvp_gather_points_grad_ws");
 }
 
 extern "C" int mvp_group_points_grad_ws(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                                         const int *idx, float *grad_points, void *scratch,
-                                        long long scratch_bytes, void *stream) {
+                                        long long scratch_bytes, int mode, void *stream) {
   if (npoints < 0 || nsample < 0) return MVP_EBADSHAPE;
   const long long flat = (long long)npoints * nsample;
   if (flat > 2147483647LL) return MVP_EBADSHAPE;
-  return mvp_gather_points_grad_ws(b, c, n, (int)flat, grad_out, idx, grad_points, scratch, scratch_bytes, stream);
+  return mvp_gather_points_grad_ws(b, c, n, (int)flat, grad_out, idx, grad_points, scratch, scratch_bytes, mode,
+                                   stream);
 }
 
 extern "C" int mvp_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                              const float *weight, float *grad_points, void *scratch,
-                                             long long scratch_bytes, void *stream) {
+                                             long long scratch_bytes, int mode, void *stream) {
   if (b < 0 || c < 0 || m < 0 || n < 0) return MVP_EBADSHAPE;
   const long long need = transposed_scratch_bytes(b, m, n, 3);
-  if (c == 0 || !scratch || need == 0 || scratch_bytes < need)
+  if (c == 0 || n == 0 || !scratch || need == 0 || scratch_bytes < need) {
+    if (const int rc = zero_for_overwrite(mode, grad_points, (long long)b * c * m, stream)) return rc;
     return mvp_three_interpolate_grad(b, c, n, m, grad_out, idx, weight, grad_points, stream);
+  }
   if (!grad_out || !idx || !weight || !grad_points) return MVP_EBADARG;
-  transposed_scatter<true>(b, c, m, n, grad_out, idx, weight, grad_points, scratch, as_stream(stream));
+  transposed_scatter<true>(b, c, m, n, grad_out, idx, weight, grad_points, scratch, mode, as_stream(stream));
   return check_launch("mvp_three_interpolate_grad_ws");
 }

@@ -29,12 +29,36 @@ def _new(ref, *shape, dtype=torch.float32, zero=False):
     return make(*shape, dtype=dtype, device=ref.device)
 
 
-def _scatter_scratch(ref, b, n_dst, m_src, r):
-    """Workspace of the scatter-add gradients (the transposed index list);
-    0 bytes when the shape is not covered -- the entry point then runs the
-    plain kernels."""
+SCATTER_OVERWRITE, SCATTER_INDEX_READY = 1, 2      # mode bits of the *_grad_ws entry points (mvpops.h)
+
+# Inverted index lists of the scatter-add gradients, kept per index tensor: the same
+# neighbour graph is differentiated through several gathers per step (keys and values of
+# SA_module, centre + neighbour features, xyz and features of edge_preserve_sampling), and a
+# retained graph may be differentiated repeatedly.  An entry holds a reference to its index
+# (and weight) tensor, so the storage it describes cannot be recycled while the entry lives;
+# `_version` detects in-place edits.  Small LRU: the lists are a few MB each.
+_TRANSPOSED = []
+_TRANSPOSED_CAP = 12
+
+
+def _scatter_scratch(idx, weight, b, n_dst, m_src, r):
+    """Workspace of the scatter-add gradients -> (scratch, nbytes, mode bits).
+    0 bytes when the shape is not covered: the entry point then runs the plain
+    kernels (zero-filling first, since OVERWRITE is always requested)."""
     nbytes = scatter_scratch_bytes(b, n_dst, m_src, r)
-    return (torch.empty(nbytes, dtype=torch.uint8, device=ref.device) if nbytes else None), nbytes
+    if not nbytes:
+        return None, 0, SCATTER_OVERWRITE
+    key = (idx.data_ptr(), idx._version, tuple(idx.shape), n_dst,
+           None if weight is None else (weight.data_ptr(), weight._version))
+    for i, (k, _, _, scratch) in enumerate(_TRANSPOSED):
+        if k == key:
+            _TRANSPOSED.append(_TRANSPOSED.pop(i))
+            return scratch, nbytes, SCATTER_OVERWRITE | SCATTER_INDEX_READY
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=idx.device)
+    _TRANSPOSED.append((key, idx, weight, scratch))
+    if len(_TRANSPOSED) > _TRANSPOSED_CAP:
+        _TRANSPOSED.pop(0)
+    return scratch, nbytes, SCATTER_OVERWRITE
 
 
 # ------------------------------------------------------------------ sampling
@@ -175,10 +199,10 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.shape
-        grad_features = _new(grad_out, B, c, m, zero=True)
-        scratch, nbytes = _scatter_scratch(grad_out, B, m, n, 3)
+        grad_features = _new(grad_out, B, c, m)          # written, not accumulated into (OVERWRITE)
+        scratch, nbytes, mode = _scatter_scratch(idx, weight, B, m, n, 3)
         call("mvp_three_interpolate_grad_ws", grad_out.device, B, c, n, m, grad_out.data.contiguous(), idx, weight,
-             grad_features, scratch, nbytes)
+             grad_features, scratch, nbytes, mode)
         return grad_features, None, None
 
 
@@ -202,10 +226,10 @@ class GatherPoints(Function):
     def backward(ctx, grad_out):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.shape
-        grad_features = _new(grad_out, B, C, N, zero=True)
-        scratch, nbytes = _scatter_scratch(grad_out, B, N, npoint, 1)
+        grad_features = _new(grad_out, B, C, N)
+        scratch, nbytes, mode = _scatter_scratch(idx, None, B, N, npoint, 1)
         call("mvp_gather_points_grad_ws", grad_out.device, B, C, N, npoint, grad_out.data.contiguous(), idx,
-             grad_features, scratch, nbytes)
+             grad_features, scratch, nbytes, mode)
         return grad_features, None
 
 
@@ -228,10 +252,10 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.shape
-        grad_features = _new(grad_out, B, C, N, zero=True)
-        scratch, nbytes = _scatter_scratch(grad_out, B, N, npoint * nsample, 1)
+        grad_features = _new(grad_out, B, C, N)
+        scratch, nbytes, mode = _scatter_scratch(idx, None, B, N, npoint * nsample, 1)
         call("mvp_group_points_grad_ws", grad_out.device, B, C, N, npoint, nsample, grad_out.data.contiguous(), idx,
-             grad_features, scratch, nbytes)
+             grad_features, scratch, nbytes, mode)
         return grad_features, None
 
 

@@ -1,21 +1,86 @@
 """Per-point / per-edge linear maps (1x1 convolutions) of the completion
-networks.  Forward and data gradient are the library convolution (MIOpen runs
-them at 1.3-2.7 TB/s of their operands); the weight gradient of layers with few
-output channels -- a GEMM with a tiny output and everything else as its
-reduction dimension, which MIOpen runs at 0.4-1.0 TB/s -- goes through
-`mvp_pointwise_wgrad` (include/mvpops.h).  Same parameters and state_dict layout
-as nn.Conv1d / nn.Conv2d(kernel_size=1); the reference builds these layers with
-nn.Conv1d / nn.Conv2d directly (completion/models/pcn.py, ecg.py, vrcnet.py).
+networks.  Same parameters and state_dict layout as nn.Conv1d /
+nn.Conv2d(kernel_size=1); the reference builds these layers with nn.Conv1d /
+nn.Conv2d directly (completion/models/pcn.py, ecg.py, vrcnet.py).
+
+Routing on float32 CUDA tensors (include/mvpops.h):
+  * forward and data gradient of layers with >= 32 input and output channels:
+    `mvp_pointwise_mfma`, an LDS-tiled GEMM on the float32 MFMA instruction with
+    bias / ReLU / residual / max-over-neighbours fused into its epilogue;
+  * weight gradient of layers with <= 64 x 64 channels -- a GEMM with a tiny
+    output and everything else as its reduction dimension, which the library
+    runs at 0.4-1.0 TB/s of its operands -- `mvp_pointwise_wgrad`;
+  * everything else (and every non-CUDA / non-float32 tensor): the library
+    convolution.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from ._lib import call, pointwise_wgrad_scratch_bytes
+from ._lib import call, pointwise_wgrad_mfma_scratch_bytes, pointwise_wgrad_scratch_bytes
 
-MAX_COUT = 64   # the kernel's limit
+MAX_COUT = 64   # mvp_pointwise_wgrad's limit
 MAX_CIN = 64    # beyond this MIOpen's weight gradient is as fast or faster (tools/bench_conv_parts.py)
+MFMA_MIN_CH = 32  # mvp_pointwise_mfma: below this many channels a 32-wide MFMA block is mostly padding
+USE_MFMA = True   # A-B switch (tools/bench_models.py)
+# Measured on the 1x1-convolution shapes of PCN / VRCNet (tools/bench_pointwise_mfma.py,
+# profiles/r2_bench_pointwise_mfma.txt): the forward GEMM with its fused epilogue beats the library
+# convolution + separate ReLU by 1.0-1.7x everywhere; the library's data gradient (115-124 TFLOP/s) beats
+# this kernel's (80-117); the weight gradients tie except for wide inputs (Cin > 512: 1.5x).
+MFMA_DGRAD = False
+MFMA_WGRAD_MIN_CIN = 513
+
+_WGRAD_SCRATCH = {}   # (device, stream) -> one growing workspace for the partial tiles (no allocator churn)
+
+
+def _wgrad_scratch(device, nbytes):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WGRAD_SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WGRAD_SCRATCH[key] = buf
+    return buf
+
+
+def _mfma_ok(x, cin, cout):
+    """Forward / data-gradient GEMM through mvp_pointwise_mfma?"""
+    if not (USE_MFMA and x.is_cuda and x.dtype == torch.float32 and x.dim() in (3, 4) and x.is_contiguous()):
+        return False
+    length = x[0, 0].numel() if x.numel() else 0
+    return cin >= MFMA_MIN_CH and cout >= MFMA_MIN_CH and length > 0 and length % 4 == 0 and x.size(0) <= 65535 \
+        and x.data_ptr() % 16 == 0
+
+
+def mfma_linear(x, w2d, bias=None, relu=False, residual=None, group=1, w_kmajor=False, xmask=None):
+    """y = epilogue(W x) for x (B, Cin, ...) contiguous float32 CUDA, W = w2d (Cout, Cin) -- or its
+    transpose (Cin, Cout) with w_kmajor; with xmask, x counts as 0 where xmask <= 0.  Epilogue
+    (mvp_pointwise_mfma): + bias, ReLU, max over groups of `group` consecutive positions of the
+    flattened trailing dimensions, + residual.  No autograd."""
+    B = x.size(0)
+    cin = x.size(1)
+    cout = w2d.size(1) if w_kmajor else w2d.size(0)
+    length = x[0, 0].numel()
+    if group == 1:
+        y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty(B, cout, length // group, dtype=torch.float32, device=x.device)
+    call("mvp_pointwise_mfma", x.device, B, cin, cout, length, x, xmask, w2d, int(w_kmajor), bias, residual,
+         int(relu), int(group), y)
+    return y
+
+
+def mfma_wgrad(x, gy, cout, cin, with_bias, gymask=None):
+    """(gw (Cout, Cin), gb (Cout) | None) of y = W x + b from x (B, Cin, ...) and gy (B, Cout, ...);
+    with gymask, gy counts as 0 where gymask <= 0 (mvp_pointwise_wgrad_mfma)."""
+    B = x.size(0)
+    length = x[0, 0].numel()
+    nbytes = pointwise_wgrad_mfma_scratch_bytes(B, cin, cout, length, with_bias)
+    scratch = _wgrad_scratch(x.device, nbytes)     # stream-ordered reuse: the reduce kernel has read it before the next call writes
+    gw = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
+    gb = torch.empty(cout, dtype=torch.float32, device=x.device) if with_bias else None
+    call("mvp_pointwise_wgrad_mfma", x.device, B, cin, cout, length, x, gy, gymask, gw, gb, scratch, nbytes)
+    return gw, gb
 
 
 def _covered(x, weight):
@@ -29,55 +94,100 @@ def _covered(x, weight):
 
 
 class _PointwiseConv(Function):
+    """y = [relu](W x + bias): forward and data gradient on the MFMA GEMM where the
+    shape allows, the small-channel weight gradient through mvp_pointwise_wgrad, the
+    rest through the library's convolution passes."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu):
         conv = F.conv1d if x.dim() == 3 else F.conv2d
-        ctx.save_for_backward(x, weight)
+        cout, cin = weight.shape[:2]
         ctx.has_bias = bias is not None
-        return conv(x, weight, bias)
+        ctx.relu = relu
+        if _mfma_ok(x, cin, cout):
+            y = mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
+        else:
+            y = conv(x, weight, bias)
+            if relu:
+                y = torch.relu_(y)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
         cout, cin = weight.shape[:2]
         nd = x.dim() - 2
         gy = grad_out.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gx_mfma = MFMA_DGRAD and need_x and _mfma_ok(gy, cout, cin) and cin % 4 == 0
+        gw_mfma = (need_w or need_b) and cin >= MFMA_WGRAD_MIN_CIN and _mfma_ok(x, cin, cout) and not _covered(x, weight) \
+            and pointwise_wgrad_mfma_scratch_bytes(x.size(0), cin, cout, x[0, 0].numel(), ctx.has_bias) > 0
+        # ReLU'(.): the MFMA kernels mask grad_out by the saved output on load; the other routes get
+        # the masked tensor
+        mask = y if ctx.relu else None
+        if ctx.relu and ((need_x and not gx_mfma) or ((need_w or need_b) and not gw_mfma)):
+            gy_masked = gy * (y > 0)
+        else:
+            gy_masked = gy
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1,
-                                                     [True, False, False])[0]
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            B = x.size(0)
-            length = x[0, 0].numel()
-            nbytes = pointwise_wgrad_scratch_bytes(B, cin, cout, length)
-            scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            gw = torch.empty_like(weight)
-            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            call("mvp_pointwise_wgrad", x.device, B, cin, cout, length, x, gy, gw, gb, scratch, nbytes)
-        return gx, gw, gb
+        if need_x:
+            if gx_mfma:
+                gx = mfma_linear(gy, weight.view(cout, cin), w_kmajor=True, xmask=mask)       # W^T (gy . relu')
+            else:
+                gx = torch.ops.aten.convolution_backward(gy_masked, x, weight, None, [1] * nd, [0] * nd, [1] * nd,
+                                                         False, [0] * nd, 1, [True, False, False])[0]
+        gy = gy_masked
+        if need_w or need_b:
+            if gw_mfma:
+                gw, gb = mfma_wgrad(x, grad_out.contiguous(), cout, cin, ctx.has_bias, gymask=mask)
+                gw = gw.view_as(weight)
+            elif _covered(x, weight):
+                B = x.size(0)
+                length = x[0, 0].numel()
+                nbytes = pointwise_wgrad_scratch_bytes(B, cin, cout, length)
+                scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                gw = torch.empty_like(weight)
+                gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                call("mvp_pointwise_wgrad", x.device, B, cin, cout, length, x, gy, gw, gb, scratch, nbytes)
+            else:
+                _, gw, gb = torch.ops.aten.convolution_backward(
+                    gy, x, weight, [cout] if ctx.has_bias else None, [1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1,
+                    [False, need_w, need_b])
+        return gx, gw, gb, None
 
 
-def pointwise_conv(x, weight, bias=None):
-    """y = W x + bias over the channel dimension of x (B,Cin,N) / (B,Cin,H,W);
-    weight (Cout,Cin,1[,1])."""
+def pointwise_conv(x, weight, bias=None, relu=False):
+    """y = W x + bias (then ReLU if `relu`) over the channel dimension of x
+    (B,Cin,N) / (B,Cin,H,W); weight (Cout,Cin,1[,1])."""
     conv = F.conv1d if x.dim() == 3 else F.conv2d
-    if torch.is_grad_enabled() and weight.requires_grad and _covered(x, weight) and x.is_contiguous() \
-            and weight.is_contiguous():
-        return _PointwiseConv.apply(x, weight, bias)
-    return conv(x, weight, bias)
+    cout, cin = weight.shape[:2]
+    routed = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() \
+        and weight.is_contiguous() and x.numel() > 0 and (_mfma_ok(x, cin, cout) or _covered(x, weight))
+    if routed and (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
+        return _PointwiseConv.apply(x, weight, bias, relu)
+    if routed and _mfma_ok(x, cin, cout):                          # inference
+        return mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
+    y = conv(x, weight, bias)
+    return torch.relu(y) if relu else y
 
 
 class PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d(kernel_size=1); `layer(x, relu=True)` = relu(layer(x)) with the
+    activation fused into the GEMM's epilogue."""
+
     def __init__(self, c_in, c_out, bias=True):
         super().__init__(c_in, c_out, kernel_size=1, bias=bias)
 
-    def forward(self, x):
-        return pointwise_conv(x, self.weight, self.bias)
+    def forward(self, x, relu=False):
+        return pointwise_conv(x, self.weight, self.bias, relu=relu)
 
 
 class PointwiseConv2d(nn.Conv2d):
     def __init__(self, c_in, c_out, bias=True):
         super().__init__(c_in, c_out, kernel_size=1, bias=bias)
 
-    def forward(self, x):
-        return pointwise_conv(x, self.weight, self.bias)
+    def forward(self, x, relu=False):
+        return pointwise_conv(x, self.weight, self.bias, relu=relu)

@@ -155,6 +155,54 @@ def test_uniform_and_repulsion_losses_run(oracle):
     assert torch.isfinite(rep)
 
 
+def test_uniform_and_repulsion_loss_values(oracle):
+    """get_uniform_loss / get_repulsion_loss (model_utils.py:181-227) against a
+    composition of the oracle's FPS / ball_query / group / knn.
+
+    The uniform loss takes the nearest-neighbour spacing inside a ball from
+    knn_point's float32 matmul formulation -|x|^2 + 2 x.y - |y|^2.  ball_query pads
+    short balls with their first hit, so 2/3 of the slots are exact duplicates whose
+    "distance" is that formulation's cancellation noise (|.| ~ 1e-7 instead of 0,
+    under sqrt(|. + 1e-8|)): the reference's value (0.031 here) is not the float64
+    value of the same formula (0.022).  The check therefore replays the reference's
+    float32 formulation (CPU torch) on the oracle-composed balls; the tolerance
+    covers the rounding-order difference between the CPU and GPU matmul on those
+    noise terms."""
+    import model_utils as mu
+    x = rand_clouds(5, 2, 1024, 3)
+    B, N, _ = x.shape
+    got = float(mu.get_uniform_loss(dev(x)))
+    seeds = oracle.furthest_point_sample(x, int(N * 0.05))
+    new_xyz = np.take_along_axis(x, seeds[..., None].astype(np.int64), 1)
+    xt = np.ascontiguousarray(x.transpose(0, 2, 1))
+    want, exact = 0.0, 0.0
+    for p in [0.004, 0.006, 0.008, 0.010, 0.012]:
+        nsample, r = int(N * p), math.sqrt(p)
+        expect_len = math.sqrt(math.pi * p / nsample)
+        idx = oracle.ball_query(0, r, nsample, x, new_xyz)
+        g = torch.tensor(oracle.grouping_operation(xt, idx).transpose(0, 2, 3, 1).reshape(-1, nsample, 3))
+        inner = -2 * torch.matmul(g, g.transpose(2, 1))                  # knn_point(2, g, g), model_utils.py:250-259
+        sq = (g ** 2).sum(2)
+        var = (-sq.unsqueeze(2) - inner - sq.unsqueeze(1)).topk(2, dim=-1)[0]
+        dis = torch.sqrt(torch.abs(-var[:, :, 1:] + 1e-8)).mean(-1)
+        want += float(((dis - expect_len) ** 2 / (expect_len + 1e-8)).mean()) * (p * 100) ** 2
+        d2 = ((g.double()[:, :, None] - g.double()[:, None]) ** 2).sum(-1).sort(-1)[0][:, :, 1]
+        dis64 = torch.sqrt(torch.abs(d2 + 1e-8)).mean(-1)
+        exact += float(((dis64 - expect_len) ** 2 / (expect_len + 1e-8)).mean()) * (p * 100) ** 2
+    want, exact = want / 5, exact / 5
+    assert got == pytest.approx(want, rel=2e-2)
+    assert abs(want - exact) > 0.2 * exact            # (documents the float32 effect described above)
+
+    y = rand_clouds(6, 2, 512, 3)
+    got = float(mu.get_repulsion_loss(dev(y)))
+    idx = oracle.knn(20, y, y).transpose(0, 2, 1)                     # (B, N, 20), self first
+    nb = np.take_along_axis(y[:, None].astype(np.float64), idx[..., None].astype(np.int64), 2) - y[:, :, None]
+    d2 = np.sort((nb ** 2).sum(-1), axis=-1)[:, :, 1:5]              # 4 nearest besides the point itself
+    d2 = np.maximum(d2, 1e-12)
+    want = np.mean(0.07 - np.sqrt(d2) * np.exp(-d2 / 0.03 ** 2))
+    assert got == pytest.approx(want, rel=1e-4)
+
+
 def _pcn_args(tmp, **kw):
     import train
     args = train.load_config(os.path.join(COMPLETION, "cfgs", "pcn.yaml"))
@@ -315,14 +363,15 @@ def test_share_weighted_sum_matches_torch(B, share, Cw, k, N):
                                              ((3, 16, 1, 300), 64, True), ((2, 512, 1, 384), 32, False),
                                              ((2, 130, 5, 44), 33, True), ((1, 1, 4), 1, True), ((2, 7, 1028), 5, True)])
 def test_pointwise_conv_weight_gradient(shape, cout, bias):
-    """Per-point / per-edge linear maps: same output as the library convolution
-    (it IS the library convolution), weight and bias gradients from
+    """Per-point / per-edge linear maps: weight and bias gradients from
     mvp_pointwise_wgrad against PyTorch's fp32 convolution_backward at 1e-4 of
-    the gradient's scale (different summation order over ~1e5..1e6 terms), input
-    gradient identical."""
+    the gradient's scale (different summation order over ~1e5..1e6 terms); output
+    and input gradient identical to the library convolution where it IS the
+    library convolution, within fp32 summation order where the MFMA GEMM runs
+    (>= 32 input and output channels)."""
     import torch.nn.functional as F
     from mvp_benchmark_amd import _lib
-    from mvp_benchmark_amd.pointwise import MAX_CIN, pointwise_conv, _PointwiseConv
+    from mvp_benchmark_amd.pointwise import MAX_CIN, MAX_COUT, MFMA_MIN_CH, pointwise_conv, _PointwiseConv
     g = torch.Generator().manual_seed(shape[1] * 131 + cout)
     x = torch.randn(*shape, generator=g).to(DEV).requires_grad_()
     w = torch.randn(cout, shape[1], *([1] * (len(shape) - 2)), generator=g).to(DEV).requires_grad_()
@@ -346,10 +395,14 @@ def test_pointwise_conv_weight_gradient(shape, cout, bias):
     assert torch.equal(gw, gw2)                                          # fixed summation order: reproducible
     # the autograd route
     y = pointwise_conv(x, w, b)
-    assert torch.equal(y, ref)
-    assert isinstance(y.grad_fn, _PointwiseConv._backward_cls) == (cin <= MAX_CIN)
+    mfma = cin >= MFMA_MIN_CH and cout >= MFMA_MIN_CH and length % 4 == 0
+    small = cin <= MAX_CIN and cout <= MAX_COUT and length % 4 == 0
+    assert isinstance(y.grad_fn, _PointwiseConv._backward_cls) == (mfma or small)
     got = torch.autograd.grad(y, params, go)
-    assert torch.equal(got[0], want[0])
+    if mfma:
+        assert close(y, ref) and close(got[0], want[0])
+    else:
+        assert torch.equal(y, ref) and torch.equal(got[0], want[0])
     for a_, b_ in zip(got[1:], want[1:]):
         assert close(a_, b_)
     # a length that is not a multiple of 4 is outside the kernel's cover: library gradient
@@ -380,3 +433,100 @@ def test_ef_expansion_on_the_op_layer():
     params = [x] + list(ef.parameters())
     for a, b in zip(torch.autograd.grad(got.square().sum(), params), torch.autograd.grad(ref.square().sum(), params)):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("B,cin,cout,L", [(2, 128, 256, 2048), (3, 256, 64, 384), (2, 515, 128, 1536), (1, 1090, 256, 2048),
+                                          (2, 64, 64, 3072), (2, 32, 48, 260), (2, 200, 300, 124), (1, 40, 33, 8)])
+def test_pointwise_mfma_matches_torch(B, cin, cout, L):
+    """mvp_pointwise_mfma (float32 MFMA, k-ordered fmaf chain) against the plain
+    PyTorch fp32 convolution: y = W x (+ bias, ReLU, residual), and the data
+    gradient W^T g through the same kernel (w_kmajor).  Tolerance: fp32 summation
+    order only -- 2e-6 * sqrt(K) relative to the operands' scale (unit normals)."""
+    import torch.nn.functional as F
+    from mvp_benchmark_amd.pointwise import mfma_linear
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(B, cin, L, generator=g).to(DEV)
+    w = torch.randn(cout, cin, generator=g).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    res = torch.randn(B, cout, L, generator=g).to(DEV)
+    tol = 4e-6 * math.sqrt(cin) * 4
+    ref = F.conv1d(x.double(), w.double().unsqueeze(2), b.double())
+    got = mfma_linear(x, w, b)
+    assert (got.double() - ref).abs().max().item() < tol
+    got = mfma_linear(x, w, b, relu=True, residual=res)
+    assert (got.double() - (torch.relu(ref) + res.double())).abs().max().item() < tol
+    got = mfma_linear(x, w)                                                     # no bias
+    assert (got.double() - F.conv1d(x.double(), w.double().unsqueeze(2))).abs().max().item() < tol
+    if cin % 4 == 0:                                                            # data gradient: W^T gy
+        gy = torch.randn(B, cout, L, generator=g).to(DEV)
+        gx = mfma_linear(gy, w, w_kmajor=True)
+        want = torch.einsum("oc,bol->bcl", w.double(), gy.double())
+        assert (gx.double() - want).abs().max().item() < 4e-6 * math.sqrt(cout) * 4
+
+
+@pytest.mark.parametrize("B,cin,cout,L,bias", [(4, 128, 256, 768, True), (64, 64, 128, 3072, False), (3, 515, 130, 388, True),
+                                               (2, 1090, 256, 2048, True), (5, 40, 33, 16, True), (1, 256, 64, 20, False)])
+def test_pointwise_wgrad_mfma_matches_torch(B, cin, cout, L, bias):
+    """mvp_pointwise_wgrad_mfma (weight + bias gradient as one MFMA GEMM over all positions, partial
+    tiles summed in a fixed order) against float64; with the ReLU mask; bit-reproducible."""
+    from mvp_benchmark_amd.pointwise import mfma_wgrad
+    g = torch.Generator().manual_seed(cin + cout + L)
+    x = torch.randn(B, cin, L, generator=g).to(DEV)
+    gy = torch.randn(B, cout, L, generator=g).to(DEV)
+    y = torch.randn(B, cout, L, generator=g).to(DEV)
+    gw, gb = mfma_wgrad(x, gy, cout, cin, bias)
+    want = torch.einsum("bol,bil->oi", gy.double(), x.double())
+    tol = 3e-6 * math.sqrt(B * L) * 4
+    assert (gw.double() - want).abs().max().item() < tol
+    if bias:
+        assert (gb.double() - gy.double().sum((0, 2))).abs().max().item() < tol
+    gw2, gb2 = mfma_wgrad(x, gy, cout, cin, bias, gymask=y)
+    gm = gy.double() * (y > 0)
+    assert (gw2.double() - torch.einsum("bol,bil->oi", gm, x.double())).abs().max().item() < tol
+    if bias:
+        assert (gb2.double() - gm.sum((0, 2))).abs().max().item() < tol
+    gw3, _ = mfma_wgrad(x, gy, cout, cin, bias)
+    assert torch.equal(gw, gw3)
+
+
+@pytest.mark.parametrize("group", [2, 4, 16, 32])
+def test_pointwise_mfma_group_max(group):
+    """The set-abstraction epilogue: conv -> ReLU -> max over the `group`
+    neighbours of a point, (B, C, P, S) never written."""
+    import torch.nn.functional as F
+    from mvp_benchmark_amd.pointwise import mfma_linear
+    g = torch.Generator().manual_seed(group)
+    B, cin, cout, P = 2, 96, 160, 200
+    x = torch.randn(B, cin, P, group, generator=g).to(DEV)
+    w = torch.randn(cout, cin, generator=g).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    got = mfma_linear(x, w, b, relu=True, group=group)
+    ref = torch.relu(F.conv2d(x.double(), w.double().view(cout, cin, 1, 1), b.double())).max(dim=3)[0]
+    assert got.shape == (B, cout, P)
+    assert (got.double() - ref).abs().max().item() < 2e-4
+
+
+def test_pointwise_conv_autograd_through_mfma():
+    """PointwiseConv1d / pointwise_conv(relu=True): outputs and all three
+    gradients against nn.Conv1d + ReLU in PyTorch fp32."""
+    import torch.nn.functional as F
+    from mvp_benchmark_amd import pointwise as pw
+    from mvp_benchmark_amd.pointwise import PointwiseConv1d, pointwise_conv
+    torch.manual_seed(0)
+    for cin, cout, L, dgrad, wmin in ((128, 256, 768, False, 513), (128, 256, 768, True, 32), (64, 64, 512, True, 32),
+                                      (256, 3, 300, False, 513), (24, 24, 256, False, 513), (515, 128, 384, True, 32),
+                                      (1090, 256, 256, False, 513), (96, 160, 1000, True, 32)):
+        pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN = dgrad, wmin          # every route of the backward pass
+        layer = PointwiseConv1d(cin, cout).to(DEV)
+        x = torch.randn(4, cin, L, device=DEV, requires_grad=True)
+        go = torch.randn(4, cout, L, device=DEV)
+        for relu in (False, True):
+            y = pointwise_conv(x, layer.weight, layer.bias, relu=relu)
+            gx, gw, gb = torch.autograd.grad(y, (x, layer.weight, layer.bias), go)
+            yr = F.conv1d(x, layer.weight, layer.bias)
+            yr = torch.relu(yr) if relu else yr
+            rx, rw, rb = torch.autograd.grad(yr, (x, layer.weight, layer.bias), go)
+            for a, r, name in ((y, yr, "y"), (gx, rx, "gx"), (gw, rw, "gw"), (gb, rb, "gb")):
+                scale = r.abs().max().item() + 1e-6
+                assert (a - r).abs().max().item() < 2e-5 * scale * math.sqrt(max(cin, L)), (cin, cout, relu, name)
+    pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN = False, 513

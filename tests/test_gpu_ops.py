@@ -81,7 +81,7 @@ def test_chamfer_sorted_variant_is_bit_identical(oracle, b, n, m):
         outs.append((d1, d2, i1, i2))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
-    if n * m <= 8192 * 2500:
+    if True:   # also at the headline size (1, 16384, 16384): ~6 s of one core
         o1, o2, j1, j2 = oracle.chamfer_forward(a, c)
         np.testing.assert_array_equal(outs[1][0].cpu().numpy(), o1)
         np.testing.assert_array_equal(outs[1][2].cpu().numpy(), j1)
@@ -381,9 +381,9 @@ def test_fps_ties_on_lattice(oracle):
 
 @pytest.mark.parametrize("b,n,m", [(3, 1025, 300), (2, 1536, 1536), (2, 1537, 100), (3, 2047, 512), (2, 3000, 1500),
                                    (2, 4096, 1024), (2, 4097, 333), (2, 6144, 2000), (2, 7000, 512), (2, 8192, 700)])
-def test_fps_fat_wave_kernel_matches_oracle(oracle, b, n, m):
-    """1024 < N <= 8192 runs on 4 (8) waves that own N / 256 (N / 512) points per
-    lane: indices equal the oracle's, the running minima left in `temp` are the
+def test_fps_mid_sizes_match_oracle_and_leave_min_distances(oracle, b, n, m):
+    """1024 < N <= 8192 (the register-resident kernel with 2..8 points per lane):
+    indices equal the oracle's, the running minima left in `temp` are the
     distances to the nearest selected point."""
     from mvp_benchmark_amd import _lib
     x = rand_clouds(n * 3 + m, b, n, 3)
@@ -398,9 +398,9 @@ def test_fps_fat_wave_kernel_matches_oracle(oracle, b, n, m):
     np.testing.assert_allclose(temp.cpu().numpy(), d, rtol=1e-5, atol=1e-7)
 
 
-def test_fps_fat_wave_kernel_ties(oracle):
-    """Lattices and duplicated points across the fat-wave size range: most rounds
-    have several points at the maximum, inside one lane and across lanes."""
+def test_fps_mid_sizes_ties(oracle):
+    """Lattices and duplicated points for 1024 < N <= 8192: most rounds have
+    several points at the maximum, inside one lane and across lanes."""
     from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample
     cases = []
     for side, m in [(11, 700), (13, 900), (16, 1200), (18, 600), (20, 500)]:
@@ -575,15 +575,58 @@ def test_scatter_gradients_hub_graph_and_plain_entry_points(oracle):
     assert nbytes > 0
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     ws = torch.zeros(b, c, n, device=DEV)
-    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, ws, scratch, nbytes)
+    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, ws, scratch, nbytes, 0)
     nows = torch.zeros(b, c, n, device=DEV)
-    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, nows, None, 0)
+    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, nows, None, 0, 0)
     for got in (plain, ws, nows):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-4)
-    # accumulate-into contract: a second call doubles the result
-    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, ws, scratch, nbytes)
+    # accumulate-into contract (mode 0): a second call doubles the result -- here on the index the
+    # first call left in the scratch (MVP_SCATTER_INDEX_READY)
+    _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, ws, scratch, nbytes, 2)
     np.testing.assert_allclose(ws.cpu().numpy(), 2 * want, rtol=2e-5, atol=4e-4)
+    # MVP_SCATTER_OVERWRITE: the destination's contents do not matter, with and without scratch
+    for sc, nb, mode in ((scratch, nbytes, 1 | 2), (scratch, nbytes, 1), (None, 0, 1)):
+        dirty = torch.full((b, c, n), 7.5, device=DEV)
+        _lib.call("mvp_group_points_grad_ws", DEV, b, c, n, p, s, tg, ti, dirty, sc, nb, mode)
+        np.testing.assert_allclose(dirty.cpu().numpy(), want, rtol=2e-5, atol=2e-4)
     assert _lib.scatter_scratch_bytes(b, 8193, 100, 1) == 0 and _lib.scatter_scratch_bytes(b, 100, 100, 2) == 0
+
+
+def test_scatter_gradient_index_cache(oracle):
+    """The autograd Functions keep the inverted index of an index tensor and reuse
+    it (several gathers through one neighbour graph; a retained graph
+    differentiated twice); an in-place edit of the index invalidates it."""
+    from mvp_benchmark_amd.mm3d_pn2 import functional as F, gather_points, three_interpolate
+    F._TRANSPOSED.clear()
+    b, c, n, m = 2, 9, 700, 2100
+    rng = np.random.default_rng(1)
+    idx = dev(rng.integers(0, n, (b, m)).astype(np.int32))
+    f1 = dev(rand_clouds(1, b, c, n)).requires_grad_()
+    f2 = dev(rand_clouds(2, b, 3, n)).requires_grad_()
+    g1, g2 = rand_clouds(3, b, c, m), rand_clouds(4, b, 3, m)
+    o1, o2 = gather_points(f1, idx), gather_points(f2, idx)
+    (o1 * dev(g1)).sum().add((o2 * dev(g2)).sum()).backward()
+    assert len(F._TRANSPOSED) == 1                                   # one index, sorted once, used twice
+    np.testing.assert_allclose(f1.grad.cpu().numpy(), oracle.gather_points_grad(g1, idx.cpu().numpy(), n), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(f2.grad.cpu().numpy(), oracle.gather_points_grad(g2, idx.cpu().numpy(), n), rtol=1e-5, atol=1e-5)
+    idx[:, :100] = 0                                                 # in-place edit: the cached lists are stale
+    f1.grad = None
+    (gather_points(f1, idx) * dev(g1)).sum().backward()
+    assert len(F._TRANSPOSED) == 2
+    np.testing.assert_allclose(f1.grad.cpu().numpy(), oracle.gather_points_grad(g1, idx.cpu().numpy(), n), rtol=1e-5, atol=1e-5)
+    # three_interpolate: the weights are part of the key
+    i3 = dev(rng.integers(0, n, (b, 900, 3)).astype(np.int32))
+    w = dev(rand_clouds(5, b, 900, 3))
+    go = rand_clouds(6, b, c, 900)
+    f1.grad = None
+    (three_interpolate(f1, i3, w) * dev(go)).sum().backward()
+    want = oracle.three_interpolate_grad(go, i3.cpu().numpy(), w.cpu().numpy(), n)
+    np.testing.assert_allclose(f1.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    w2 = w * 2
+    f1.grad = None
+    (three_interpolate(f1, i3, w2) * dev(go)).sum().backward()
+    np.testing.assert_allclose(f1.grad.cpu().numpy(), 2 * want, rtol=1e-5, atol=2e-5)
+    F._TRANSPOSED.clear()
 
 
 def test_query_and_group_composition(oracle):
@@ -606,6 +649,67 @@ def test_query_and_group_composition(oracle):
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
     ga = GroupAll()(dev(xyz), None, dev(feats))
     assert tuple(ga.shape) == (2, 9, 1, 400)
+
+
+def test_points_sampler_feature_fps_and_fs_values(oracle):
+    """F-FPS / FS (points_sampler.py:119-158): FPS on the squared distance of the
+    joint [xyz, feature] vectors (calc_square_dist, utils.py:4-31, norm=False);
+    FS = [F-FPS, D-FPS].  The distance matrix against float64 NumPy, the indices
+    against the oracle's furthest_point_sample_with_dist on that matrix."""
+    from mvp_benchmark_amd.mm3d_pn2 import Points_Sampler
+    from mvp_benchmark_amd.mm3d_pn2.modules import calc_square_dist
+    xyz, feats = rand_clouds(7, 2, 300, 3), rand_clouds(8, 2, 5, 300)
+    joint = np.concatenate([xyz, feats.transpose(0, 2, 1)], 2)
+    dmat = calc_square_dist(dev(joint), dev(joint), norm=False)
+    j64 = joint.astype(np.float64)
+    want = ((j64[:, :, None] - j64[:, None]) ** 2).sum(-1)
+    np.testing.assert_allclose(dmat.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
+    ffps = oracle.furthest_point_sample_with_dist(dmat.cpu().numpy(), 40)
+    dfps = oracle.furthest_point_sample(xyz, 40)
+    got = Points_Sampler([40], ['F-FPS'], [-1])(dev(xyz), dev(feats))
+    np.testing.assert_array_equal(got.cpu().numpy(), ffps)
+    got = Points_Sampler([40], ['FS'], [-1])(dev(xyz), dev(feats))
+    np.testing.assert_array_equal(got.cpu().numpy(), np.concatenate([ffps, dfps], 1))
+    # two ranges, F-FPS on the first 128 points, FS on the rest (indices offset by the range start)
+    got = Points_Sampler([16, 8], ['F-FPS', 'FS'], [128, -1])(dev(xyz), dev(feats)).cpu().numpy()
+    d0 = calc_square_dist(dev(joint[:, :128]), dev(joint[:, :128]), norm=False).cpu().numpy()
+    d1 = calc_square_dist(dev(joint[:, 128:]), dev(joint[:, 128:]), norm=False).cpu().numpy()
+    want = np.concatenate([oracle.furthest_point_sample_with_dist(d0, 16),
+                           oracle.furthest_point_sample_with_dist(d1, 8) + 128,
+                           oracle.furthest_point_sample(np.ascontiguousarray(xyz[:, 128:]), 8) + 128], 1)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_query_and_group_uniform_sample(oracle):
+    """uniform_sample / return_unique_cnt (group_points.py:80-92): a row keeps its
+    unique neighbours (sorted, as torch.unique returns them) and fills the other
+    slots with draws from them; the count is returned.  GroupAll values."""
+    from mvp_benchmark_amd.mm3d_pn2 import GroupAll, QueryAndGroup
+    xyz, feats = rand_clouds(2, 2, 300, 3), rand_clouds(3, 2, 4, 300)
+    ctr = np.ascontiguousarray(xyz[:, :40])
+    S = 12
+    torch.manual_seed(0)
+    out, gxyz, cnt = QueryAndGroup(0.12, S, uniform_sample=True, return_unique_cnt=True,
+                                   return_grouped_xyz=True)(dev(xyz), dev(ctr), dev(feats))
+    out, gxyz, cnt = out.cpu().numpy(), gxyz.cpu().numpy(), cnt.cpu().numpy()
+    idx = oracle.ball_query(0, 0.12, S, xyz, ctr)                     # padded with the first hit
+    assert out.shape == (2, 7, 40, S) and cnt.shape == (2, 40)
+    partial_rows = 0
+    for b in range(2):
+        for p in range(40):
+            uniq = np.unique(idx[b, p])
+            assert cnt[b, p] == len(uniq)
+            partial_rows += len(uniq) < S
+            np.testing.assert_array_equal(out[b, 3:, p, :len(uniq)], feats[b][:, uniq])
+            np.testing.assert_allclose(gxyz[b, :, p, :len(uniq)], xyz[b][uniq].T - ctr[b, p][:, None], rtol=0, atol=1e-7)
+            for sidx in range(len(uniq), S):                            # the draws: each one of the unique neighbours
+                assert (np.abs(feats[b][:, uniq] - out[b, 3:, p, sidx][:, None]).max(0) == 0).any()
+            np.testing.assert_array_equal(out[b, :3, p], gxyz[b, :, p])
+    assert partial_rows > 20                                            # the resampling branch really ran
+    ga = GroupAll()(dev(xyz), None, dev(feats)).cpu().numpy()
+    np.testing.assert_array_equal(ga[:, :3, 0], xyz.transpose(0, 2, 1))
+    np.testing.assert_array_equal(ga[:, 3:, 0], feats)
+    np.testing.assert_array_equal(GroupAll(use_xyz=False)(dev(xyz), None, dev(feats)).cpu().numpy()[:, :, 0], feats)
 
 
 def test_points_sampler(oracle):

@@ -62,8 +62,8 @@ def test_guards_and_scratch_sizes_of_the_widened_entry_points():
     assert _lib.scatter_scratch_bytes(1, 1024, 3072, 3) == 2 * ((1024 + 1) * 4 + 1536 * 3 * 8)
     assert _lib.scatter_scratch_bytes(1, 8193, 100, 1) == 0 and _lib.scatter_scratch_bytes(1, 100, 100, 2) == 0
     # ... and the _ws entry points fall back to the plain ones (which accept the empty batch)
-    assert lib.mvp_gather_points_grad_ws(0, 3, 8, 8, null, null, null, null, 0, null) == 0
-    assert lib.mvp_three_interpolate_grad_ws(1, 3, 8, 0, null, null, null, null, null, 0, null) == -1    # m == 0
+    assert lib.mvp_gather_points_grad_ws(0, 3, 8, 8, null, null, null, null, 0, 0, null) == 0
+    assert lib.mvp_three_interpolate_grad_ws(1, 3, 8, 0, null, null, null, null, null, 0, 0, null) == -1    # m == 0
     # Gram top-k
     assert lib.mvp_topk_gram(1, 8, 9, null, null, null, null) == -1        # k > n
     assert lib.mvp_topk_gram(1, 8, 0, null, null, null, null) == -1

@@ -267,3 +267,52 @@ def test_gather_group_interpolate_definitions(oracle):
             for j in range(3):
                 want[b, :, ti[b, p, j]] += go[b, :, p] * w[b, p, j]
     np.testing.assert_allclose(gp, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,eps,iters", [(1024, 0.004, 3000), (2048, 0.004, 3000), (1024, 0.005, 50)])
+def test_emd_sensitivity_to_the_getmax_schedule(n, eps, iters):
+    """GetMax (emd_cuda.cu:181-194) lets the LAST writer among the bidders within
+    1e-6 of an object's maximal increment win -- a data race in the reference.
+    The oracle (and the HIP kernel) resolve it to the highest qualifying bidder,
+    i.e. the reference executed sequentially.  Here the other extreme -- the
+    LOWEST qualifying bidder -- is run beside it.  Measured (this test,
+    tools/emd_schedule_sensitivity.py, profiles/r2_emd_schedule_sensitivity.txt):
+    most clouds never see two bidders inside one band and are bit-identical under
+    both schedules; a cloud that does diverges in 10-20 % of its assignments and
+    its mean(sqrt(dist)) moves by a few 1e-4 relative.  So the reference's own
+    run-to-run spread is ~1e-3, two orders above the north star's 1e-5 band: that
+    band can only be (and is) met per schedule -- HIP == oracle bit for bit on the
+    pinned schedule -- not across schedules."""
+    import oracle
+    rng = np.random.default_rng(n + iters)
+    x1 = rng.random((4, n, 3), dtype=np.float32)
+    x2 = rng.random((4, n, 3), dtype=np.float32)
+    d_hi, a_hi, _, _ = oracle.emd_forward_ex(x1, x2, eps, iters, getmax_lowest=False)
+    d_lo, a_lo, _, _ = oracle.emd_forward_ex(x1, x2, eps, iters, getmax_lowest=True)
+    m_hi, m_lo = np.sqrt(d_hi).mean(1), np.sqrt(d_lo).mean(1)
+    same = (a_hi == a_lo).all(1)
+    assert same.sum() >= 2                                        # most clouds: no in-band meeting at all
+    np.testing.assert_array_equal(d_hi[same], d_lo[same])
+    np.testing.assert_allclose(m_lo, m_hi, rtol=2e-3)             # the others: the reference's own spread
+    # both schedules are valid auctions: dist is the squared length of the matched pair
+    for d, a in ((d_hi, a_hi), (d_lo, a_lo)):
+        m = np.take_along_axis(x2, a[..., None].astype(np.int64), 1)
+        np.testing.assert_allclose(d, ((x1 - m) ** 2).sum(-1), rtol=1e-5, atol=1e-9)
+    d0, a0 = oracle.emd_forward(x1, x2, eps, iters)               # the default entry point is the "highest" schedule
+    np.testing.assert_array_equal(a0, a_hi)
+    np.testing.assert_array_equal(d0, d_hi)
+
+
+def test_emd_getmax_schedule_matters_when_increments_tie():
+    """The two schedules really are different programs: duplicated persons bid
+    identical increments on the same objects, and the lowest / highest bidder
+    wins respectively -- the assignments differ, the matched cost does not."""
+    import oracle
+    rng = np.random.default_rng(3)
+    base1 = rng.random((1, 512, 3), dtype=np.float32)
+    x1 = np.tile(base1, (1, 2, 1))                               # every person twice
+    x2 = rng.random((1, 1024, 3), dtype=np.float32)
+    d_hi, a_hi, _, _ = oracle.emd_forward_ex(x1, x2, 0.005, 200, getmax_lowest=False)
+    d_lo, a_lo, _, _ = oracle.emd_forward_ex(x1, x2, 0.005, 200, getmax_lowest=True)
+    assert (a_hi != a_lo).any()
+    assert np.sqrt(d_lo).mean() == pytest.approx(np.sqrt(d_hi).mean(), rel=2e-2)
