@@ -391,8 +391,16 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
   long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0, prof_a1 = 0, prof_an = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0;
 #endif
+#ifdef MVP_EMD_PROFILE
+  const long long t_loop0 = __builtin_readcyclecounter();
+#endif
   for (int it = 0; it < iters; ++it) {
     if (Utot == 0) break;
+#ifdef MVP_EMD_PROFILE
+    if (cloud == 0 && wg == 0 && t == 0 && (it == 25 || it == 50 || it == 100 || it == 150 || it == 250 || it == 500 || it == 750 ||
+                                           it == 1000 || it == 1500 || it == 2000 || it == 2500 || it == iters - 1))
+      printf("head cloud 0: round %d starts at %lld cycles, unassigned %d\n", it, __builtin_readcyclecounter() - t_loop0, Utot);
+#endif
     const int U = s_cnt[cur];  // this workgroup's bidders
     n_rounds += 1;
     n_bids += U;

@@ -204,10 +204,13 @@ __global__ __launch_bounds__(1024) void fps_kernel(
         best = gt ? d2 : best;
       }
     }
-    // best >= 0 here (every live thread owns at least point t < n), so its
-    // bit pattern orders like an unsigned integer.
-    unsigned long long key =
-        ((unsigned long long)__float_as_uint(best) << 32) | tiekey;
+    // Squared distances: best >= 0 here (every live thread owns at least point t < n), so its
+    // bit pattern orders like an unsigned integer.  A distance MATRIX (F-FPS) may hold small
+    // negative entries -- the reference builds it as |a|^2 + |b|^2 - 2ab in float32
+    // (points_sampler.py:119-158, utils.py:4-31) -- so there the order-preserving map is used.
+    unsigned bbits = __float_as_uint(best);
+    if (WITH_DIST) bbits = (bbits & 0x80000000u) ? ~bbits : (bbits | 0x80000000u);
+    unsigned long long key = ((unsigned long long)bbits << 32) | tiekey;
     if (!live) key = 0;
     key = wave_max_u64(key);
     if (nwaves > 1) {
@@ -224,7 +227,9 @@ __global__ __launch_bounds__(1024) void fps_kernel(
       // The winning lane resolves its first (lowest k) maximum -- the
       // reference's per-thread strict `>` scan (:69-70) -- and publishes the
       // selected point from its registers.
-      const float vbest = __uint_as_float((unsigned)(key >> 32));
+      unsigned vbits = (unsigned)(key >> 32);
+      if (WITH_DIST) vbits = (vbits & 0x80000000u) ? (vbits ^ 0x80000000u) : ~vbits;
+      const float vbest = __uint_as_float(vbits);
       int sel = P > 0 ? t : besti;
       float sx = 0.f, sy = 0.f, sz = 0.f;
       if (P > 0) {

@@ -464,6 +464,13 @@ def test_fps_with_dist_matches_oracle(oracle):
         d = ((x[:, :, None] - x[:, None]) ** 2).sum(-1).astype(np.float32)
         idx = furthest_point_sample_with_dist(dev(d), m)
         np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample_with_dist(d, m))
+        # the matrix the reference's F-FPS really feeds it (|a|^2 + |b|^2 - 2ab in float32) has slightly
+        # negative entries on and near the diagonal: they must order below every positive distance
+        sq = (x * x).sum(-1)
+        d2 = (sq[:, :, None] + sq[:, None] - 2 * np.einsum("bnc,bmc->bnm", x, x)).astype(np.float32)
+        d2[:, np.arange(n), np.arange(n)] = -np.abs(d2[:, np.arange(n), np.arange(n)]) - 1e-7
+        idx = furthest_point_sample_with_dist(dev(d2), m)
+        np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample_with_dist(d2, m))
 
 
 # ------------------------------------------------------- ball_query/knn/3nn
