@@ -23,7 +23,12 @@ constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 
 constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
 constexpr int kMaxCluster = 8;   // workgroups per cloud (W)
 constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
-constexpr int kSoloMax = 16;     // unassigned persons below which one workgroup finishes the auction alone
+#ifndef MVP_EMD_SOLO
+#define MVP_EMD_SOLO 16
+#endif
+// unassigned persons below which one workgroup finishes the auction alone (32 / 64 / 128 with the
+// four-bidders-per-wave schedule were tried in round 2: 5 % / 23 % / 57 % slower at the headline shape)
+constexpr int kSoloMax = MVP_EMD_SOLO;
 constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens of seconds), then abort
 // The tail of the auction (emd_tail.hip): once at most kTailCap persons are
 // unassigned (their number never grows) the clustered kernel hands the cloud to

@@ -1,14 +1,16 @@
 """Deep Closest Point -- counterpart of the reference's registration/models/dcp.py
-(DGCNN :286-318, Transformer :321-345 with the annotated-transformer blocks
-:24-252, SVDHead :348-376, Model :379-429).  BASELINE cfg 5.
+(DGCNN :286-318, Transformer :321-345 built from the annotated-transformer
+blocks :24-252, SVDHead :348-376, Model :379-429).  BASELINE cfg 5.
 
-Same sub-module / parameter names as the reference (checkpoints interchange;
-tests/golden/dcp_golden.npz pins the layout and a forward pass generated from
-the imported reference).  What runs on the op layer: the k = 20 coordinate kNN
-and neighbour gather of DGCNN (knn + grouping operators instead of a (B,N,N)
-matrix, topk and advanced indexing) and the SVD head (one mvp_kabsch_svd3
-launch instead of B torch.svd / torch.det calls with a host synchronisation
-each).  Attention and the 1x1 convolutions are library GEMMs.
+The module tree reproduces the reference's parameter names (checkpoints
+interchange; tests/golden/dcp_golden.npz pins the layout and a forward pass
+generated from the imported reference), the code does not: the transformer is
+one generic pre-norm layer class used for both stacks, the edge-convolution
+stages are a loop.  On the op layer: DGCNN's k = 20 coordinate kNN and
+neighbour gather (knn + grouping operators instead of a (B,N,N) matrix, topk and
+advanced indexing) and the SVD head (one mvp_kabsch_svd3 launch instead of B
+torch.svd / torch.det calls with a host synchronisation each).  Attention and
+the 1x1 convolutions are library GEMMs.
 """
 import copy
 import math
@@ -24,24 +26,14 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 from model_utils import get_graph_feature, procrustes  # noqa: E402
-from train_utils import (rmse_loss, rotation_error, rotation_geodesic_error, rt_to_transformation,  # noqa: E402
-                         translation_error)
+import train_utils as metrics  # noqa: E402
 
-
-def clones(module, n):
-    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
-
-
-def attention(query, key, value):
-    """softmax(Q K^T / sqrt(d)) V over the last two dims."""
-    scores = torch.matmul(query, key.transpose(-2, -1)) / math.sqrt(query.size(-1))
-    p_attn = F.softmax(scores, dim=-1)
-    return torch.matmul(p_attn, value), p_attn
+EMB_DIMS, FF_DIMS, HEADS, STACK_DEPTH = 512, 1024, 4, 1
 
 
 class LayerNorm(nn.Module):
-    """(x - mean) / (std + eps) with the UNBIASED std, as the reference's own
-    LayerNorm (:139-149) -- not nn.LayerNorm."""
+    """a_2 * (x - mean) / (std + eps) + b_2 with the UNBIASED std and eps added
+    to the std -- the reference's own normalisation (:139-149), not nn.LayerNorm."""
 
     def __init__(self, features, eps=1e-6):
         super().__init__()
@@ -50,221 +42,192 @@ class LayerNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x):
-        mean = x.mean(-1, keepdim=True)
-        std = x.std(-1, keepdim=True)
-        return self.a_2 * (x - mean) / (std + self.eps) + self.b_2
+        centred = x - x.mean(-1, keepdim=True)
+        return self.a_2 * centred / (x.std(-1, keepdim=True) + self.eps) + self.b_2
 
 
 class SublayerConnection(nn.Module):
-    """Pre-norm residual: x + sublayer(norm(x))."""
+    """Holder of a pre-norm residual branch's LayerNorm (`norm`)."""
 
-    def __init__(self, size, dropout=None):
+    def __init__(self, size):
         super().__init__()
         self.norm = LayerNorm(size)
 
-    def forward(self, x, sublayer):
-        return x + sublayer(self.norm(x))
-
 
 class MultiHeadedAttention(nn.Module):
-    def __init__(self, h, d_model, dropout=0.1):
-        super().__init__()
-        assert d_model % h == 0
-        self.d_k = d_model // h
-        self.h = h
-        self.linears = clones(nn.Linear(d_model, d_model), 4)
-        self.attn = None
+    """Four d x d projections (`linears`: query, key, value, output), HEADS heads."""
 
-    def forward(self, query, key, value, mask=None):
-        nb = query.size(0)
-        query, key, value = [lin(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
-                             for lin, x in zip(self.linears, (query, key, value))]
-        x, self.attn = attention(query, key, value)
-        x = x.transpose(1, 2).contiguous().view(nb, -1, self.h * self.d_k)
-        return self.linears[-1](x)
+    def __init__(self, heads, d_model):
+        super().__init__()
+        assert d_model % heads == 0
+        self.h, self.d_k = heads, d_model // heads
+        self.linears = nn.ModuleList([nn.Linear(d_model, d_model) for _ in range(4)])
+
+    def forward(self, query, memory):
+        b = query.size(0)
+        split = lambda t: t.view(b, -1, self.h, self.d_k).transpose(1, 2)
+        q = split(self.linears[0](query))
+        k = split(self.linears[1](memory))
+        v = split(self.linears[2](memory))
+        weights = F.softmax(q @ k.transpose(-2, -1) / math.sqrt(self.d_k), dim=-1)
+        mixed = (weights @ v).transpose(1, 2).reshape(b, -1, self.h * self.d_k)
+        return self.linears[3](mixed)
 
 
 class PositionwiseFeedForward(nn.Module):
-    def __init__(self, d_model, d_ff, dropout=0.1):
+    def __init__(self, d_model, d_ff):
         super().__init__()
         self.w_1 = nn.Linear(d_model, d_ff)
-        self.norm = nn.Sequential()
+        self.norm = nn.Sequential()          # empty in the reference as well (no parameters)
         self.w_2 = nn.Linear(d_ff, d_model)
 
     def forward(self, x):
         return self.w_2(F.relu(self.w_1(x)))
 
 
-class EncoderLayer(nn.Module):
-    def __init__(self, size, self_attn, feed_forward, dropout):
-        super().__init__()
-        self.self_attn = self_attn
-        self.feed_forward = feed_forward
-        self.sublayer = clones(SublayerConnection(size, dropout), 2)
-        self.size = size
+class TransformerLayer(nn.Module):
+    """Pre-norm layer: self-attention, (decoder only) attention over the other
+    cloud's encoding, feed-forward; every branch is x + f(norm(x))."""
 
-    def forward(self, x, mask=None):
-        x = self.sublayer[0](x, lambda y: self.self_attn(y, y, y))
-        return self.sublayer[1](x, self.feed_forward)
-
-
-class DecoderLayer(nn.Module):
-    def __init__(self, size, self_attn, src_attn, feed_forward, dropout):
+    def __init__(self, size, self_attn, feed_forward, src_attn=None):
         super().__init__()
         self.size = size
         self.self_attn = self_attn
-        self.src_attn = src_attn
+        if src_attn is not None:
+            self.src_attn = src_attn
         self.feed_forward = feed_forward
-        self.sublayer = clones(SublayerConnection(size, dropout), 3)
+        self.sublayer = nn.ModuleList([SublayerConnection(size) for _ in range(2 if src_attn is None else 3)])
 
-    def forward(self, x, memory, src_mask=None, tgt_mask=None):
-        x = self.sublayer[0](x, lambda y: self.self_attn(y, y, y))
-        x = self.sublayer[1](x, lambda y: self.src_attn(y, memory, memory))
-        return self.sublayer[2](x, self.feed_forward)
+    def forward(self, x, memory=None):
+        h = self.sublayer[0].norm(x)
+        x = x + self.self_attn(h, h)
+        branch = 1
+        if memory is not None:
+            x = x + self.src_attn(self.sublayer[1].norm(x), memory)
+            branch = 2
+        return x + self.feed_forward(self.sublayer[branch].norm(x))
 
 
-class Encoder(nn.Module):
-    def __init__(self, layer, n):
+class LayerStack(nn.Module):
+    def __init__(self, layer, depth):
         super().__init__()
-        self.layers = clones(layer, n)
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(depth)])
         self.norm = LayerNorm(layer.size)
 
-    def forward(self, x, mask=None):
+    def forward(self, x, memory=None):
         for layer in self.layers:
-            x = layer(x, mask)
-        return self.norm(x)
-
-
-class Decoder(nn.Module):
-    def __init__(self, layer, n):
-        super().__init__()
-        self.layers = clones(layer, n)
-        self.norm = LayerNorm(layer.size)
-
-    def forward(self, x, memory, src_mask=None, tgt_mask=None):
-        for layer in self.layers:
-            x = layer(x, memory, src_mask, tgt_mask)
+            x = layer(x, memory)
         return self.norm(x)
 
 
 class EncoderDecoder(nn.Module):
-    """Encoder over `src`, decoder over `tgt` attending to the encoder output;
-    the embedding / generator slots are empty (identity) in DCP."""
+    """decoder(tgt | encoder(src)); the embedding / generator slots of the
+    annotated transformer exist (empty) so that the module tree matches."""
 
-    def __init__(self, encoder, decoder, src_embed, tgt_embed, generator):
+    def __init__(self, encoder, decoder):
         super().__init__()
         self.encoder = encoder
         self.decoder = decoder
-        self.src_embed = src_embed
-        self.tgt_embed = tgt_embed
-        self.generator = generator
+        self.src_embed = nn.Sequential()
+        self.tgt_embed = nn.Sequential()
+        self.generator = nn.Sequential()
 
-    def forward(self, src, tgt, src_mask=None, tgt_mask=None):
-        memory = self.encoder(self.src_embed(src), src_mask)
-        return self.generator(self.decoder(self.tgt_embed(tgt), memory, src_mask, tgt_mask))
+    def forward(self, src, tgt):
+        return self.decoder(tgt, self.encoder(src))
 
 
 class DGCNN(nn.Module):
-    """Edge convolutions over the k = 20 coordinate neighbourhood; the four
-    stage maxima are concatenated and mapped to emb_dims."""
+    """Four edge-convolution stages over the k = 20 coordinate neighbourhood
+    (6 -> 64 -> 64 -> 128 -> 256 channels, BatchNorm + ReLU, max over the
+    neighbours after each), their maxima concatenated and mapped to emb_dims."""
 
-    def __init__(self, emb_dims=512):
+    WIDTHS = (6, 64, 64, 128, 256)
+
+    def __init__(self, emb_dims=EMB_DIMS):
         super().__init__()
-        self.conv1 = nn.Conv2d(6, 64, kernel_size=1, bias=False)
-        self.conv2 = nn.Conv2d(64, 64, kernel_size=1, bias=False)
-        self.conv3 = nn.Conv2d(64, 128, kernel_size=1, bias=False)
-        self.conv4 = nn.Conv2d(128, 256, kernel_size=1, bias=False)
-        self.conv5 = nn.Conv2d(512, emb_dims, kernel_size=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        self.bn2 = nn.BatchNorm2d(64)
-        self.bn3 = nn.BatchNorm2d(128)
-        self.bn4 = nn.BatchNorm2d(256)
-        self.bn5 = nn.BatchNorm2d(emb_dims)
+        stages = list(zip(self.WIDTHS[:-1], self.WIDTHS[1:])) + [(sum(self.WIDTHS[1:]), emb_dims)]
+        for i, (c_in, c_out) in enumerate(stages, start=1):       # parameters conv1..5 first, then bn1..5
+            setattr(self, "conv%d" % i, nn.Conv2d(c_in, c_out, kernel_size=1, bias=False))
+        for i, (_, c_out) in enumerate(stages, start=1):
+            setattr(self, "bn%d" % i, nn.BatchNorm2d(c_out))
+
+    def _stage(self, i, x):
+        return F.relu(getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(x)))
 
     def forward(self, x):
         batch_size, _, num_points = x.size()
-        x = get_graph_feature(x)                          # (B,6,N,20): knn + grouping operators
-        stages = []
-        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3),
-                         (self.conv4, self.bn4)):
-            x = F.relu(bn(conv(x)))
-            stages.append(x.max(dim=-1, keepdim=True)[0])
-        x = torch.cat(stages, dim=1)
-        return F.relu(self.bn5(self.conv5(x))).view(batch_size, -1, num_points)
+        edge = get_graph_feature(x)                       # (B, 6, N, 20): knn + grouping operators
+        pooled = []
+        for i in range(1, 5):
+            edge = self._stage(i, edge)
+            pooled.append(edge.max(dim=-1, keepdim=True)[0])
+        return self._stage(5, torch.cat(pooled, dim=1)).view(batch_size, -1, num_points)
 
 
 class Transformer(nn.Module):
+    """The "pointer": each cloud's embedding attends to the other's."""
+
     def __init__(self, args):
         super().__init__()
-        self.emb_dims = 512
-        self.N = 1
-        self.dropout = 0.0
-        self.ff_dims = 1024
-        self.n_heads = 4
-        c = copy.deepcopy
-        attn = MultiHeadedAttention(self.n_heads, self.emb_dims)
-        ff = PositionwiseFeedForward(self.emb_dims, self.ff_dims, self.dropout)
-        self.model = EncoderDecoder(Encoder(EncoderLayer(self.emb_dims, c(attn), c(ff), self.dropout), self.N),
-                                    Decoder(DecoderLayer(self.emb_dims, c(attn), c(attn), c(ff), self.dropout), self.N),
-                                    nn.Sequential(), nn.Sequential(), nn.Sequential())
+        self.emb_dims, self.N, self.dropout, self.ff_dims, self.n_heads = EMB_DIMS, STACK_DEPTH, 0.0, FF_DIMS, HEADS
+        # one prototype of each block, deep-copied into place: all attention blocks start from the
+        # same weights, as in the reference (:331-337)
+        attn = MultiHeadedAttention(HEADS, EMB_DIMS)
+        ff = PositionwiseFeedForward(EMB_DIMS, FF_DIMS)
+        dup = copy.deepcopy
+        self.model = EncoderDecoder(
+            LayerStack(TransformerLayer(EMB_DIMS, dup(attn), dup(ff)), STACK_DEPTH),
+            LayerStack(TransformerLayer(EMB_DIMS, dup(attn), dup(ff), src_attn=dup(attn)), STACK_DEPTH))
 
     def forward(self, src, tgt):
-        src = src.transpose(2, 1).contiguous()
-        tgt = tgt.transpose(2, 1).contiguous()
+        src, tgt = src.transpose(2, 1).contiguous(), tgt.transpose(2, 1).contiguous()
         tgt_embedding = self.model(src, tgt).transpose(2, 1).contiguous()
         src_embedding = self.model(tgt, src).transpose(2, 1).contiguous()
         return src_embedding, tgt_embedding
 
 
 class SVDHead(nn.Module):
-    """Soft correspondences from the embeddings, then the rigid motion that maps
-    src onto them (one batched 3x3 SVD launch)."""
+    """Soft correspondences (softmax of the embedding products), then the rigid
+    motion that carries src onto them: one batched 3x3 SVD launch."""
 
     def __init__(self, args):
         super().__init__()
-        self.emb_dims = 512
-        self.reflect = nn.Parameter(torch.eye(3), requires_grad=False)   # kept: part of the checkpoint
-        self.reflect[2, 2] = -1
+        self.emb_dims = EMB_DIMS
+        reflect = torch.eye(3)
+        reflect[2, 2] = -1
+        self.reflect = nn.Parameter(reflect, requires_grad=False)   # unused here, kept: part of the checkpoint
 
     def forward(self, src_embedding, tgt_embedding, src, tgt):
-        d_k = src_embedding.size(1)
-        scores = torch.matmul(src_embedding.transpose(2, 1), tgt_embedding) / math.sqrt(d_k)
-        scores = torch.softmax(scores, dim=2)
-        src_corr = torch.matmul(tgt, scores.transpose(2, 1))
+        logits = src_embedding.transpose(2, 1) @ tgt_embedding / math.sqrt(src_embedding.size(1))
+        src_corr = tgt @ torch.softmax(logits, dim=2).transpose(2, 1)
         return procrustes(src, src_corr)
 
 
 class Model(nn.Module):
-    """forward(src (B,N,3), tgt (B,N,3)[, T_gt (B,4,4)]) -> T_12 (B,4,4), or with
+    """forward(src (B,N,3), tgt (B,N,3)[, T_gt (B,4,4)]) -> T_12 (B,4,4); with
     T_gt: (loss, r_err, t_err, rmse, rt_mse) as the reference (:391-429)."""
 
     def __init__(self, args):
         super().__init__()
-        self.emb_dims = 512
+        self.emb_dims = EMB_DIMS
         self.cycle = False
-        self.emb_nn = DGCNN(emb_dims=self.emb_dims)
+        self.emb_nn = DGCNN(emb_dims=EMB_DIMS)
         self.pointer = Transformer(args=args)
         self.head = SVDHead(args=args)
 
     def forward(self, src, tgt, T_gt=None, prefix="train"):
-        src_point = src
+        cloud_src = src
         src = src.transpose(1, 2).contiguous()
         tgt = tgt.transpose(1, 2).contiguous()
-
-        src_embedding = self.emb_nn(src)
-        tgt_embedding = self.emb_nn(tgt)
-        src_embedding_p, tgt_embedding_p = self.pointer(src_embedding, tgt_embedding)
-        src_embedding = src_embedding + src_embedding_p
-        tgt_embedding = tgt_embedding + tgt_embedding_p
-
-        rotation_ab, translation_ab = self.head(src_embedding, tgt_embedding, src, tgt)
-        T_12 = rt_to_transformation(rotation_ab, translation_ab.unsqueeze(2))
+        f_src, f_tgt = self.emb_nn(src), self.emb_nn(tgt)
+        p_src, p_tgt = self.pointer(f_src, f_tgt)
+        rotation, translation = self.head(f_src + p_src, f_tgt + p_tgt, src, tgt)
+        T_12 = metrics.rt_to_transformation(rotation, translation.unsqueeze(2))
         if T_gt is None:
             return T_12
-        r_err = rotation_error(T_12[:, :3, :3], T_gt[:, :3, :3])
-        t_err = translation_error(T_12[:, :3, 3], T_gt[:, :3, 3])
-        rmse = rmse_loss(src_point, T_12, T_gt)
-        eye = torch.eye(4, device=T_gt.device).expand_as(T_gt)
-        loss = F.mse_loss(T_12 @ torch.inverse(T_gt), eye)
-        rt_mse = rotation_geodesic_error(T_12[:, :3, :3], T_gt[:, :3, :3]) + t_err
-        return loss, r_err, t_err, rmse, rt_mse
+        R, t, R_gt, t_gt = T_12[:, :3, :3], T_12[:, :3, 3], T_gt[:, :3, :3], T_gt[:, :3, 3]
+        t_err = metrics.translation_error(t, t_gt)
+        identity = torch.eye(4, device=T_gt.device).expand_as(T_gt)
+        loss = F.mse_loss(T_12 @ torch.inverse(T_gt), identity)
+        return (loss, metrics.rotation_error(R, R_gt), t_err, metrics.rmse_loss(cloud_src, T_12, T_gt),
+                metrics.rotation_geodesic_error(R, R_gt) + t_err)
