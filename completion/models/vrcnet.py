@@ -110,50 +110,52 @@ class MSAP_SKN_decoder(nn.Module):
         self.conv_f2 = pointwise1d(self.expand_feature_size, 3)
         self.af = nn.ReLU(inplace=False)
 
+    def _coarse_raw(self, global_feat):
+        hidden = self.af(self.fc2(self.af(self.fc1(global_feat))))
+        return self.fc3(hidden).view(global_feat.size(0), 3, self.num_coarse_raw)
+
+    def _labelled(self, generated, observed):
+        """Generated and observed points side by side; with points_label a 4th channel tells them apart (0 / 1)."""
+        if not self.points_label:
+            return torch.cat((generated, observed), 2)
+        tag = lambda pts, value: torch.cat((pts, pts.new_full((pts.size(0), 1, pts.size(2)), value)), 1)
+        return torch.cat((tag(generated, 0.0), tag(observed, 1.0)), 2)
+
+    @staticmethod
+    def _keep(idx, *tensors):
+        return [gather_points(t.contiguous(), idx) for t in tensors]
+
     def forward(self, global_feat, point_input):
         batch_size = global_feat.size(0)
-        coarse_raw = self.fc3(self.af(self.fc2(self.af(self.fc1(global_feat))))) \
-            .view(batch_size, 3, self.num_coarse_raw)
-
-        if self.points_label:      # 4th channel tells generated (0) from observed (1) points
-            zeros = coarse_raw.new_zeros(batch_size, 1, coarse_raw.shape[2])
-            ones = point_input.new_ones(batch_size, 1, point_input.shape[2])
-            points = torch.cat((torch.cat((coarse_raw, zeros), 1), torch.cat((point_input, ones), 1)), 2)
-        else:
-            points = torch.cat((coarse_raw, point_input), 2)
-        dense_feat = self.encoder(points)
-        if self.up_scale >= 2:
+        coarse_raw = self._coarse_raw(global_feat)
+        dense_feat = self.encoder(self._labelled(coarse_raw, point_input))
+        if self.expansion1 is not None:
             dense_feat = self.expansion1(dense_feat)
-
         coarse_features = self.conv_cup1(dense_feat, relu=True)
         coarse_high = self.conv_cup2(coarse_features)
 
-        if coarse_high.size(2) > self.num_fps:
-            idx_fps = furthest_point_sample(coarse_high.transpose(1, 2).contiguous(), self.num_fps)
-            coarse_fps = gather_points(coarse_high.contiguous(), idx_fps)
-            coarse_features = gather_points(coarse_features.contiguous(), idx_fps)
+        # stage 1: furthest point sampling down to num_fps
+        coarse = coarse_high
+        if coarse.size(2) > self.num_fps:
+            picked = furthest_point_sample(coarse.transpose(1, 2).contiguous(), self.num_fps)
+            coarse, coarse_features = self._keep(picked, coarse, coarse_features)
+        # stage 2: the num_coarse points with the best learned score
+        if coarse.size(2) > self.num_coarse:
+            hidden = self.af(self.conv_s2(self.af(self.conv_s1(coarse_features))))
+            scores = F.softplus(self.conv_s3(hidden))
+            picked = scores.topk(k=self.num_coarse, dim=2)[1].view(batch_size, -1).int()
+            coarse, coarse_features = self._keep(picked, coarse, coarse_features)
+        # stage 3: up to num_fine by local folding (or edge-feature expansion)
+        if coarse.size(2) == self.num_fine:
+            return coarse_raw, coarse_high, coarse, coarse
+        assert coarse.size(2) < self.num_fine
+        if self.local_folding:
+            ratio = self.num_fine // self.num_coarse
+            up_features = self.expansion2(coarse_features, global_feat)
+            center = coarse.unsqueeze(3).expand(-1, -1, -1, ratio).reshape(batch_size, 3, self.num_fine)
+            fine = self.conv_f2(self.conv_f1(up_features, relu=True)) + center
         else:
-            coarse_fps = coarse_high
-
-        if coarse_fps.size(2) > self.num_coarse:
-            scores = F.softplus(self.conv_s3(self.af(self.conv_s2(self.af(self.conv_s1(coarse_features))))))
-            idx_scores = scores.topk(k=self.num_coarse, dim=2)[1].view(batch_size, -1).int()
-            coarse = gather_points(coarse_fps.contiguous(), idx_scores)
-            coarse_features = gather_points(coarse_features.contiguous(), idx_scores)
-        else:
-            coarse = coarse_fps
-
-        if coarse.size(2) < self.num_fine:
-            if self.local_folding:
-                up_features = self.expansion2(coarse_features, global_feat)
-                ratio = self.num_fine // self.num_coarse
-                center = coarse.unsqueeze(3).expand(-1, -1, -1, ratio).reshape(batch_size, 3, self.num_fine)
-                fine = self.conv_f2(self.conv_f1(up_features, relu=True)) + center
-            else:
-                fine = self.conv_f2(self.conv_f1(self.expansion2(coarse_features), relu=True))
-        else:
-            assert coarse.size(2) == self.num_fine
-            fine = coarse
+            fine = self.conv_f2(self.conv_f1(self.expansion2(coarse_features), relu=True))
         return coarse_raw, coarse_high, coarse, fine
 
 
@@ -201,52 +203,51 @@ class Model(nn.Module):
         mu, std = torch.split(raw, self.size_z, dim=1)
         return mu, F.softplus(std)
 
-    def forward(self, x, gt=None, prefix="train", mean_feature=None, alpha=None):
-        num_input = x.size(2)
-        train = prefix == "train"
+    def _posterior(self, feat):
+        return torch.distributions.Normal(*self._normal(self.posterior_infer2(self.posterior_infer1(feat))))
 
+    def _latent_loss(self, q, p):
+        """20 x (reconstruction-path + completion-path) distribution loss of the training objective."""
+        p_fixed = torch.distributions.Normal(p.loc.detach(), p.scale.detach())
+        unit = torch.distributions.Normal(torch.zeros_like(p.loc), torch.ones_like(p.scale))
+        if self.distribution_loss == 'MMD':
+            z_m, z_q = unit.rsample(), q.rsample()
+            z_p, z_p_fix = p.rsample(), p_fixed.rsample()
+            rec, gen = self.mmd_loss(z_m, z_p), self.mmd_loss2(z_q, z_p_fix)
+        elif self.distribution_loss == 'KLD':
+            rec = torch.distributions.kl_divergence(unit, p)
+            gen = torch.distributions.kl_divergence(p_fixed, q)
+        else:
+            raise NotImplementedError('Distribution loss is either MMD or KLD')
+        return (rec.mean() + gen.mean()) * 20
+
+    def forward(self, x, gt=None, prefix="train", mean_feature=None, alpha=None):
+        train = prefix == "train"
+        q = p = None
         if train:
-            # reconstruction path sees the (sub-sampled) complete shape; both
-            # paths are decoded in one doubled batch (:450-455)
-            y = gather_points(gt.transpose(1, 2).contiguous(), furthest_point_sample(gt, num_input))
-            gt = torch.cat([gt, gt], dim=0)
-            feat = self.encoder(torch.cat([x, y], dim=0))
-            x = torch.cat([x, x], dim=0)
-            feat_x, feat_y = feat.chunk(2)
-            q_mu, q_std = self._normal(self.posterior_infer2(self.posterior_infer1(feat_x)))
-            p_mu, p_std = self._normal(self.prior_infer(feat_y))
-            q_distribution = torch.distributions.Normal(q_mu, q_std)
-            p_distribution = torch.distributions.Normal(p_mu, p_std)
-            p_distribution_fix = torch.distributions.Normal(p_mu.detach(), p_std.detach())
-            m_distribution = torch.distributions.Normal(torch.zeros_like(p_mu), torch.ones_like(p_std))
-            z = torch.cat([q_distribution.rsample(), p_distribution.rsample()], dim=0)
+            # the reconstruction path sees the (sub-sampled) complete shape; both paths are decoded
+            # in ONE doubled batch (:450-455)
+            y = gather_points(gt.transpose(1, 2).contiguous(), furthest_point_sample(gt, x.size(2)))
+            feat_x, feat_y = self.encoder(torch.cat([x, y], dim=0)).chunk(2)
+            q = self._posterior(feat_x)
+            p = torch.distributions.Normal(*self._normal(self.prior_infer(feat_y)))
+            z = torch.cat([q.rsample(), p.rsample()], dim=0)
             feat = torch.cat([feat_x, feat_x], dim=0)
+            x, gt = torch.cat([x, x], dim=0), torch.cat([gt, gt], dim=0)
         else:
             feat = self.encoder(x)
-            q_mu, q_std = self._normal(self.posterior_infer2(self.posterior_infer1(feat)))
-            q_distribution = torch.distributions.Normal(q_mu, q_std)
-            z = q_distribution.rsample()
+            z = self._posterior(feat).rsample()
 
-        feat = feat + self.generator(z)
-        coarse_raw, coarse_high, coarse, fine = [t.transpose(1, 2).contiguous() for t in self.decoder(feat, x)]
-
-        if train:
-            if self.distribution_loss == 'MMD':
-                z_m, z_q = m_distribution.rsample(), q_distribution.rsample()
-                z_p, z_p_fix = p_distribution.rsample(), p_distribution_fix.rsample()
-                dl_rec = self.mmd_loss(z_m, z_p)
-                dl_g = self.mmd_loss2(z_q, z_p_fix)
-            elif self.distribution_loss == 'KLD':
-                dl_rec = torch.distributions.kl_divergence(m_distribution, p_distribution)
-                dl_g = torch.distributions.kl_divergence(p_distribution_fix, q_distribution)
-            else:
-                raise NotImplementedError('Distribution loss is either MMD or KLD')
-            if self.train_loss != 'cd':
-                raise NotImplementedError('Only CD is supported')
-            loss1, loss2, loss3, loss4 = [calc_cd(o, gt)[0] for o in (coarse_raw, coarse_high, coarse, fine)]
-            total_train_loss = loss1.mean() * 10 + loss2.mean() * 0.5 + loss3.mean() + loss4.mean() * alpha
-            total_train_loss = total_train_loss + (dl_rec.mean() + dl_g.mean()) * 20
-            return fine, loss4, total_train_loss
+        outputs = self.decoder(feat + self.generator(z), x)
+        coarse_raw, coarse_high, coarse, fine = [t.transpose(1, 2).contiguous() for t in outputs]
         if prefix == "val":
             return eval_outputs(coarse_raw, fine, gt, self.eval_emd)
-        return {'result': fine}
+        if not train:
+            return {'result': fine}
+
+        if self.train_loss != 'cd':
+            raise NotImplementedError('Only CD is supported')
+        latent = self._latent_loss(q, p)     # (raises on an unknown distribution_loss before any CD is run)
+        cd_raw, cd_high, cd_coarse, cd_fine = [calc_cd(o, gt)[0] for o in (coarse_raw, coarse_high, coarse, fine)]
+        total = cd_raw.mean() * 10 + cd_high.mean() * 0.5 + cd_coarse.mean() + cd_fine.mean() * alpha + latent
+        return fine, cd_fine, total
