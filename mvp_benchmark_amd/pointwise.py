@@ -30,6 +30,13 @@ USE_MFMA = True   # A-B switch (tools/bench_models.py)
 # this kernel's (80-117); the weight gradients tie except for wide inputs (Cin > 512: 1.5x).
 MFMA_DGRAD = False
 MFMA_WGRAD_MIN_CIN = 513
+MFMA_FWD_MAX_CIN = 256    # wider inputs: a tie with the library (1.0-1.1x), which then keeps its own algorithm choice
+# Under autograd the routed layers go through a Python autograd.Function (saved tensors, mask, scratch):
+# at VRCNet's 37 such layers per step that host-side cost (the step is close to CPU-bound: 32 ms of
+# host time for 34 ms of GPU time) outweighs the kernels' gains -- 34.6-35.6 ms per step routed against
+# 33.1 ms with the library (profiles/r2_bench_models.txt).  So training keeps the library unless this is
+# set; inference (no autograd) uses the MFMA forward.
+MFMA_TRAIN = False
 
 _WGRAD_SCRATCH = {}   # (device, stream) -> one growing workspace for the partial tiles (no allocator churn)
 
@@ -43,8 +50,13 @@ def _wgrad_scratch(device, nbytes):
     return buf
 
 
+def _mfma_fwd(x, cin, cout):
+    """Forward GEMM through mvp_pointwise_mfma?"""
+    return cin <= MFMA_FWD_MAX_CIN and _mfma_ok(x, cin, cout)
+
+
 def _mfma_ok(x, cin, cout):
-    """Forward / data-gradient GEMM through mvp_pointwise_mfma?"""
+    """Shape / layout covered by the MFMA kernels?"""
     if not (USE_MFMA and x.is_cuda and x.dtype == torch.float32 and x.dim() in (3, 4) and x.is_contiguous()):
         return False
     length = x[0, 0].numel() if x.numel() else 0
@@ -104,7 +116,7 @@ class _PointwiseConv(Function):
         cout, cin = weight.shape[:2]
         ctx.has_bias = bias is not None
         ctx.relu = relu
-        if _mfma_ok(x, cin, cout):
+        if _mfma_fwd(x, cin, cout):
             y = mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
         else:
             y = conv(x, weight, bias)
@@ -167,8 +179,11 @@ def pointwise_conv(x, weight, bias=None, relu=False):
     routed = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() \
         and weight.is_contiguous() and x.numel() > 0 and (_mfma_ok(x, cin, cout) or _covered(x, weight))
     if routed and (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
-        return _PointwiseConv.apply(x, weight, bias, relu)
-    if routed and _mfma_ok(x, cin, cout):                          # inference
+        if MFMA_TRAIN or _covered(x, weight):
+            return _PointwiseConv.apply(x, weight, bias, relu)
+        y = conv(x, weight, bias)
+        return torch.relu(y) if relu else y
+    if routed and _mfma_fwd(x, cin, cout):                         # inference
         return mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
     y = conv(x, weight, bias)
     return torch.relu(y) if relu else y

@@ -394,10 +394,15 @@ def test_pointwise_conv_weight_gradient(shape, cout, bias):
     _lib.call("mvp_pointwise_wgrad", DEV, B, cin, cout, length, x.detach(), go, gw2, None, ws, nbytes)
     assert torch.equal(gw, gw2)                                          # fixed summation order: reproducible
     # the autograd route
+    import mvp_benchmark_amd.pointwise as pw
+    pw.MFMA_TRAIN = True
     y = pointwise_conv(x, w, b)
-    mfma = cin >= MFMA_MIN_CH and cout >= MFMA_MIN_CH and length % 4 == 0
+    pw.MFMA_TRAIN = False
+    mfma = cin >= MFMA_MIN_CH and cout >= MFMA_MIN_CH and length % 4 == 0     # (forward: only for cin <= MFMA_FWD_MAX_CIN)
     small = cin <= MAX_CIN and cout <= MAX_COUT and length % 4 == 0
     assert isinstance(y.grad_fn, _PointwiseConv._backward_cls) == (mfma or small)
+    y_lib = pointwise_conv(x, w, b)                                      # default: training keeps the library unless small
+    assert isinstance(y_lib.grad_fn, _PointwiseConv._backward_cls) == small
     got = torch.autograd.grad(y, params, go)
     if mfma:
         assert close(y, ref) and close(got[0], want[0])
@@ -516,7 +521,7 @@ def test_pointwise_conv_autograd_through_mfma():
     for cin, cout, L, dgrad, wmin in ((128, 256, 768, False, 513), (128, 256, 768, True, 32), (64, 64, 512, True, 32),
                                       (256, 3, 300, False, 513), (24, 24, 256, False, 513), (515, 128, 384, True, 32),
                                       (1090, 256, 256, False, 513), (96, 160, 1000, True, 32)):
-        pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN = dgrad, wmin          # every route of the backward pass
+        pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN = dgrad, wmin, True          # every route of the backward pass
         layer = PointwiseConv1d(cin, cout).to(DEV)
         x = torch.randn(4, cin, L, device=DEV, requires_grad=True)
         go = torch.randn(4, cout, L, device=DEV)
@@ -529,4 +534,4 @@ def test_pointwise_conv_autograd_through_mfma():
             for a, r, name in ((y, yr, "y"), (gx, rx, "gx"), (gw, rw, "gw"), (gb, rb, "gb")):
                 scale = r.abs().max().item() + 1e-6
                 assert (a - r).abs().max().item() < 2e-5 * scale * math.sqrt(max(cin, L)), (cin, cout, relu, name)
-    pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN = False, 513
+    pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN = False, 513, False

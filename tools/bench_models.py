@@ -4,15 +4,19 @@
    (+ ECG train step).  Synthetic data, random-init weights."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "completion"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "completion"))
 import torch
 import train
+import mvp_benchmark_amd.pointwise as pw
+if "MVP_MFMA_TRAIN" in os.environ:                       # A/B of the training-path routing (pointwise.py)
+    pw.MFMA_TRAIN = os.environ["MVP_MFMA_TRAIN"] == "1"
+REPS = int(os.environ.get("MVP_BENCH_REPS", "10"))
 
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
 
-def timed(fn, reps=3):
-    fn(); torch.cuda.synchronize()
+def timed(fn, reps=REPS):
+    fn(); fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
@@ -44,5 +48,5 @@ for name in ("vrcnet", "ecg"):
         loss.backward()
         opt.step()
     ms = timed(step)
-    print("%s train step (batch 32, 2048 pts): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
-        name, ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
+    print("%s train step (batch 32, 2048 pts, MFMA_TRAIN=%s): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
+        name, pw.MFMA_TRAIN, ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
