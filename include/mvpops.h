@@ -40,7 +40,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 6
+#define MVP_ABI_VERSION 7
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -88,8 +88,14 @@ int mvp_chamfer_backward(int b, int n, int m, const float *xyz1,
 /* Bytes of device scratch mvp_emd_forward needs for (b, n); the reference
  * passes 11 scratch tensors instead (utils/metrics/EMD/emd_module.py:54-65).
  * Contents on entry are irrelevant (the kernel initialises its own state).
- * The last 16*b bytes receive per-cloud {int64 rounds, int64 bids} statistics. */
+ * The last 16*b bytes of the buffer passed to mvp_emd_forward (its
+ * scratch_bytes, a multiple of 16) receive per-cloud {int64 rounds, int64 bids}
+ * statistics.  mvp_emd_scratch_bytes_iters is the exact requirement of a call
+ * with that many rounds (the list-driven tail kernel, mvp_emd_configure(tail =
+ * 2), keeps 6.2 KB per point for auctions of >= 512 rounds);
+ * mvp_emd_scratch_bytes is enough for any number of rounds. */
 long long mvp_emd_scratch_bytes(int b, int n);
+long long mvp_emd_scratch_bytes_iters(int b, int n, int iters);
 
 /* Replaces emd.forward = emd_forward (utils/metrics/EMD/emd.cpp:14-20,29) ->
  * emd_cuda_forward (emd_cuda.cu:228-282): `iters` auction rounds of
@@ -123,7 +129,9 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  * first use).  A negative argument leaves that knob unchanged.
  *   cluster     0 = automatic, or 1|2|4|8: cap of the workgroups per cloud
  *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
- *   tail        0: no hand-over to the single-workgroup tail kernel
+ *   tail        0: the clustered kernel runs every round; 1: hand-over to the
+ *               tail kernel (emd_tail.hip); 2: hand-over to the list-driven
+ *               single-workgroup kernel (emd_solo.hip)
  *   tail_delta  width of the candidate caches in units of eps (0: no caches)
  *   tail_cluster 0 = as the first kernel, or 1|2|4|8: cap of the tail kernel's
  *               workgroups per cloud

@@ -64,6 +64,8 @@
 namespace mvp {
 
 // emd_tail.hip
+void emd_solo_launch(int b, int n, const float *xyz1, float *dist, int *assignment, float eps, int iters,
+                     char *scratch, char *lists, float delta, hipStream_t stream);
 void emd_tail_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps, int iters,
                      char *scratch, float delta, hipStream_t stream);
 
@@ -1084,7 +1086,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         Utot += cntw[w];
         if (w != wg) overflow |= (int)s_gout[2 * w + 1] > kChgCap;
       }
-      if (tail_ok && Utot > 0 && Utot <= kTailCap && it + 1 < iters) {
+      if (tail_ok && Utot > 0 && Utot <= (tail_ok >> 16) && iters - (it + 1) >= (tail_ok & 0xFFFF)) {
         // ---- hand the cloud to the tail kernel: every member appends its list
         // (<= kTailCap < kRecCap entries: all in LDS) to the hand-over record
         int off = 0;
@@ -1246,7 +1248,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     } else {
       __syncthreads();
       Utot = s_cnt[nxt];
-      if (tail_ok && Utot > 0 && Utot <= kTailCap && it + 1 < iters) {
+      if (tail_ok && Utot > 0 && Utot <= (tail_ok >> 16) && iters - (it + 1) >= (tail_ok & 0xFFFF)) {
         if (t < Utot) resume->list[t] = s_ri[nxt][t].x;
         if (t == 0) {
           if (s_err) resume->pad = 1;
@@ -1353,21 +1355,24 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
 // environment ONCE (first use), mvp_emd_configure() overrides them at run time:
 //   MVP_EMD_CLUSTER=1|2|4|8   cap of the workgroups per cloud
 //   MVP_EMD_SAME_XCD=0        keep the write-through stores even when a cluster shares an XCD
-//   MVP_EMD_TAIL=0            no hand-over to the tail kernel (the clustered kernel runs every round)
+//   MVP_EMD_TAIL=0|1|2        0: the clustered kernel runs every round; 1: hand-over to the tail kernel of
+//                             emd_tail.hip; 2: hand-over to the list-driven kernel of emd_solo.hip
 //   MVP_EMD_TAIL_DELTA=<x>    candidate-cache width in units of eps (0: no caches)
 //   MVP_EMD_TAIL_CLUSTER=1|2|4|8  cap of the tail kernel's workgroups per cloud
 struct EmdKnobs {
   int cluster, same_xcd, tail, tail_cluster;
   float tail_delta;
+  int solo_cap;  // unassigned persons at which the list-driven kernel takes over (<= kTailCap)
 };
 static EmdKnobs &emd_knobs() {
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 0, 0, 3.f};  // tail kernel off by default: not faster yet
+    EmdKnobs v{kMaxCluster, 1, 0, 0, 3.f, kTailCap};  // tail kernel off by default: not faster yet
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
-    if (const char *e = getenv("MVP_EMD_TAIL")) v.tail = atoi(e) != 0;
+    if (const char *e = getenv("MVP_EMD_TAIL")) v.tail = atoi(e);
     if (const char *e = getenv("MVP_EMD_TAIL_DELTA")) v.tail_delta = (float)atof(e);
     if (const char *e = getenv("MVP_EMD_TAIL_CLUSTER")) v.tail_cluster = atoi(e);
+    if (const char *e = getenv("MVP_EMD_SOLO_CAP")) v.solo_cap = max(1, min(kTailCap, atoi(e)));
     return v;
   }();
   return k;
@@ -1418,10 +1423,23 @@ static hipError_t emd_launch(int b, int n, const float *xyz1, const float *xyz2,
 
 using namespace mvp;
 
-extern "C" long long mvp_emd_scratch_bytes(int b, int n) {
-  if (b < 0 || n < 0) return -1;
-  return (long long)b * ((long long)emd_scratch_per_cloud(n) + (long long)kEmdTailPerCloud);
+// Which kernel runs the rounds after the hand-over, and the fewest remaining rounds worth one:
+// 0 = none (the clustered kernel runs them all).
+static int emd_tail_mode(int n, int iters) {
+  const int mode = emd_knobs().tail;
+  if (mode == 0 || n > kTailMaxN || iters <= 1) return 0;
+  if (mode == 2) return iters >= kListMinIters ? 2 : 0;
+  return 1;
 }
+static long long emd_base_bytes(int b, int n) {
+  return (long long)b * ((long long)emd_scratch_per_cloud(n) + (long long)kEmdTailPerCloud);  // a multiple of 16
+}
+
+extern "C" long long mvp_emd_scratch_bytes_iters(int b, int n, int iters) {
+  if (b < 0 || n < 0) return -1;
+  return emd_base_bytes(b, n) + (emd_tail_mode(n, iters) == 2 ? (long long)b * (long long)emd_lists_per_cloud(n) : 0);
+}
+extern "C" long long mvp_emd_scratch_bytes(int b, int n) { return mvp_emd_scratch_bytes_iters(b, n, 1 << 30); }
 
 extern "C" int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail_delta, int tail_cluster) {
   EmdKnobs &k = emd_knobs();
@@ -1430,7 +1448,10 @@ extern "C" int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail
     k.cluster = cluster == 0 ? kMaxCluster : cluster;
   }
   if (same_xcd >= 0) k.same_xcd = same_xcd != 0;
-  if (tail >= 0) k.tail = tail != 0;
+  if (tail >= 0) {
+    if (tail > 2) return MVP_EBADARG;
+    k.tail = tail;
+  }
   if (tail_delta >= 0.f) k.tail_delta = tail_delta;
   if (tail_cluster >= 0) {
     if (tail_cluster != 0 && tail_cluster != 1 && tail_cluster != 2 && tail_cluster != 4 && tail_cluster != 8)
@@ -1451,16 +1472,22 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
   if (n > (1 << 20)) return MVP_EBADSHAPE;
   if (b == 0) return MVP_OK;
   if (!xyz1 || !xyz2 || !dist || !assignment || !scratch) return MVP_EBADARG;
-  if (scratch_bytes < mvp_emd_scratch_bytes(b, n)) return MVP_EBADARG;
+  if (scratch_bytes < mvp_emd_scratch_bytes_iters(b, n, iters)) return MVP_EBADARG;
   if ((reinterpret_cast<uintptr_t>(scratch) & 15) != 0) return MVP_EBADARG;
-  char *sbase = reinterpret_cast<char *>(scratch);
+  // The per-cloud areas, hand-over records and statistics take the END of the buffer (so the
+  // statistics are its last 16*b bytes whatever else it holds); the neighbour lists its start.
+  char *lists = reinterpret_cast<char *>(scratch);
+  char *sbase = lists + ((scratch_bytes - emd_base_bytes(b, n)) & ~15LL);
   hipStream_t st = as_stream(stream);
   // barrier granules and statistics start from zero on every call
   if (hipMemsetAsync(sbase + (size_t)b * emd_scratch_per_cloud(n), 0, (size_t)b * kEmdTailPerCloud, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
   const int w = emd_cluster_width(b);
   // rounds after the first kTailCap-or-fewer unassigned persons run in the tail kernel
-  const int tail_ok = emd_knobs().tail && n <= kTailMaxN && iters > 1;
+  const int mode = emd_tail_mode(n, iters);
+  // (the value is the fewest remaining rounds that are handed over; the lists want their build amortised)
+  // low half: the fewest remaining rounds; high half: the most unassigned persons
+  const int tail_ok = mode == 2 ? (kListMinIters / 2) | (emd_knobs().solo_cap << 16) : mode ? 1 | (kTailCap << 16) : 0;
   hipError_t err = hipErrorUnknown;
   if (w == 8) err = emd_launch<8>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, tail_ok, st);
   else if (w == 4) err = emd_launch<4>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, tail_ok, st);
@@ -1469,7 +1496,9 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
     (void)hipGetLastError();
     (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, tail_ok, st);
   }
-  if (tail_ok)  // exits at once for clouds that finished in the first kernel
+  if (mode == 2)
+    emd_solo_launch(b, n, xyz1, dist, assignment, eps, iters, sbase, lists, emd_knobs().tail_delta * eps, st);
+  else if (mode == 1)  // exits at once for clouds that finished in the first kernel
     emd_tail_launch(b, n, emd_tail_width(b, w), xyz1, dist, assignment, eps, iters, sbase, emd_knobs().tail_delta * eps, st);
   return check_launch("mvp_emd_forward");
 }

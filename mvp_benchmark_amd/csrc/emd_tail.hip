@@ -67,71 +67,6 @@
 
 namespace mvp {
 
-constexpr int kTailCells = 1331;  // 11^3: n <= 16384 objects give g <= 11 (emd.hip: (g+1)^3 * 12 <= n)
-constexpr int kStage = 40;        // candidates a search can stage for the cache (more: no cache this time)
-
-// fp16 bounds of a float, rounded outwards (box lo down, box hi up), as bits
-__device__ __forceinline__ unsigned half_bits_down(float x) {
-  _Float16 h = (_Float16)x;  // round to nearest even; +-inf on overflow
-  unsigned short b = __builtin_bit_cast(unsigned short, h);
-  if ((float)h > x) {  // step to the next smaller half
-    if (b == 0x0000u) b = 0x8001u;
-    else if (b & 0x8000u) b += 1;
-    else b -= 1;
-  }
-  return b;
-}
-__device__ __forceinline__ unsigned half_bits_up(float x) {
-  _Float16 h = (_Float16)x;
-  unsigned short b = __builtin_bit_cast(unsigned short, h);
-  if ((float)h < x) {  // step to the next larger half
-    if (b == 0x8000u) b = 0x0001u;
-    else if (b & 0x8000u) b -= 1;
-    else b += 1;
-  }
-  return b;
-}
-__device__ __forceinline__ float half_bits_to_float(unsigned b) {
-  return (float)__builtin_bit_cast(_Float16, (unsigned short)b);
-}
-
-template <int CTRL>
-__device__ __forceinline__ int quad_i32(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
-}
-
-// LDS-only phase boundary: this wave's LDS traffic has landed, then s_barrier.
-// Global stores are NOT waited for.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// One step of the wave-wide merge of per-lane exact top-2 {b1, slot k1, b2, slot k2}: the two
-// lane sets are disjoint; equal best values are ordered by the reference's rule on ORIGINAL
-// object indices (perm).  Lanes the DPP control / row mask does not write merge with nothing.
-template <int CTRL, int RM>
-__device__ __forceinline__ void top2k_merge_step(float &b1, int &k1, float &b2, int &k2, int n, int tpu,
-                                                 const int *__restrict__ perm) {
-  const float ob1 = dpp_f32<CTRL, RM>(-1e9f, b1);
-  const float ob2 = dpp_f32<CTRL, RM>(-1e9f, b2);
-  const int ok1 = __builtin_amdgcn_update_dpp(-1, k1, CTRL, RM, 0xF, false);
-  const int ok2 = __builtin_amdgcn_update_dpp(-1, k2, CTRL, RM, 0xF, false);
-  const bool tie = ob1 == b1 && ok1 >= 0 && k1 >= 0;
-  bool other_first = false;
-  if (__any(tie)) {
-    if (tie) other_first = emd_precedes(perm[ok1], perm[k1], n, tpu);
-  }
-  if (ob1 > b1 || other_first) {
-    const bool fb = b1 >= ob2;
-    b2 = fb ? b1 : ob2;
-    k2 = fb ? k1 : ok2;
-    b1 = ob1;
-    k1 = ok1;
-  } else {
-    const bool fo = ob1 >= b2;
-    k2 = fo ? ok1 : k2;
-    b2 = fo ? ob1 : b2;
-  }
-}
-
 template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_tail_kernel(
     int b, int bpad, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment, float eps,

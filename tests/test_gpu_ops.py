@@ -261,15 +261,61 @@ def test_emd_tail_cluster_widths_match_oracle(oracle, emd_variant, tail_width, k
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("delta", [1.0, 3.0, 20.0])
+@pytest.mark.parametrize("kind", ["uniform", "duplicates", "barely_handed_over", "last_round_forced", "person_blob",
+                                  "object_blob", "two_blobs"])
+def test_emd_list_driven_tail_matches_oracle(oracle, emd_variant, kind, delta):
+    """mvp_emd_configure(tail=2): after the hand-over one workgroup per cloud runs the rounds
+    with prices and owners in LDS, and a bid is a scan of the person's static neighbour list
+    (emd_solo.hip; lists written between the two kernels, ordered by distance + price at
+    hand-over).  Same bits as the oracle for narrow / default / wide candidate caches.
+    `duplicates`: value ties (tie order on original indices) inside lists and caches;
+    `barely_handed_over`: the fewest remaining rounds that are still handed over;
+    `last_round_forced`: persons left for the forced last round (emd_cuda.cu:201);
+    `person_blob` / `object_blob` / `two_blobs`: lists that are cut early or empty (every
+    shell overflows), i.e. the full-scan fallback of the list search."""
+    from mvp_benchmark_amd.metrics import emd
+    emd_variant(2, delta)
+    if kind == "uniform":
+        x1, x2, eps, iters = rand_clouds(61, 3, 4096, 3), rand_clouds(62, 3, 4096, 3), 0.004, 3000
+    elif kind == "duplicates":
+        x1 = np.tile(rand_clouds(63, 2, 512, 3), (1, 4, 1))
+        x2, eps, iters = np.tile(rand_clouds(64, 2, 256, 3), (1, 8, 1)), 0.005, 1500
+    elif kind == "barely_handed_over":
+        x1, x2, eps = rand_clouds(65, 2, 2048, 3), rand_clouds(66, 2, 2048, 3), 0.004
+        trace = oracle.emd_forward_ex(x1, x2, eps, 3000)[3]
+        handover = max(int(np.argmax(row <= 256)) for row in trace)
+        assert 0 < handover < 2000
+        iters = handover + 256
+    elif kind == "last_round_forced":
+        x1, x2, eps, iters = rand_clouds(67, 2, 2048, 3), rand_clouds(68, 2, 2048, 3), 0.0005, 700
+        assert oracle.emd_forward_ex(x1, x2, eps, iters)[3][:, -1].min() > 0   # persons left for the forced round
+    elif kind == "person_blob":
+        x1 = (0.5 + 0.01 * rand_clouds(69, 2, 1024, 3)).astype(np.float32)
+        x2, eps, iters = rand_clouds(70, 2, 1024, 3), 0.004, 1500
+    elif kind == "object_blob":
+        x1 = rand_clouds(71, 2, 2048, 3)
+        x2, eps, iters = (0.3 + 0.002 * rand_clouds(72, 2, 2048, 3)).astype(np.float32), 0.004, 800
+    else:
+        x1 = np.concatenate([0.2 + 0.02 * rand_clouds(73, 2, 1024, 3), 0.8 + 0.02 * rand_clouds(74, 2, 1024, 3)], 1).astype(np.float32)
+        x2 = np.concatenate([0.25 + 0.02 * rand_clouds(75, 2, 1024, 3), 0.7 + 0.05 * rand_clouds(76, 2, 1024, 3)], 1).astype(np.float32)
+        eps, iters = 0.004, 1200
+    dist, ass = emd()(dev(x1), dev(x2), eps, iters)
+    od, oa = oracle.emd_forward(x1, x2, eps, iters)
+    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
 def test_emd_headline_cloud_matches_oracle(oracle, emd_variant):
     """Two cloud pairs of the headline shape (16384 points, eps 0.004, 3000
     rounds) against the exhaustive oracle, bit for bit -- with the clustered
-    kernel alone and with the hand-over to the tail kernel (round ~150 onwards).
+    kernel alone, with the hand-over to the tail kernel (round ~150 onwards) and
+    with the hand-over to the list-driven kernel.
     (~70 s of CPU per cloud, once.)"""
     from mvp_benchmark_amd.metrics import emd
     x1, x2 = rand_clouds(41, 2, 16384, 3), rand_clouds(42, 2, 16384, 3)
     od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
-    for tail in (0, 1):
+    for tail in (0, 1, 2):
         emd_variant(tail, 3.0)
         dist, ass = emd()(dev(x1), dev(x2), 0.004, 3000)
         np.testing.assert_array_equal(ass.cpu().numpy(), oa)

@@ -28,6 +28,20 @@ def test_library_exports_every_declared_symbol():
     # (n <= 16384 only) + barrier granules, hand-over record, statistics
     assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * (132 + 128) + 8 * 2048 * 8 + 1732 * 4 + 512 + 1056 + 16)
     assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 512 + 1056 + 16)
+    # the list-driven tail kernel (opt-in) adds 1344 cell records + the persons by cell + 6208 B per person,
+    # for auctions of >= 512 rounds on clouds of <= 16384 points; the knob is process-wide: restore it
+    base = lib.mvp_emd_scratch_bytes(3, 4096)
+    assert lib.mvp_emd_scratch_bytes_iters(3, 4096, 50) == base
+    try:
+        assert lib.mvp_emd_configure(-1, -1, 2, -1.0, -1) == 0
+        lists = 3 * (1344 * 16 + 1344 * 2 + 16384 * 2 + 4096 * (64 + 1024 * 6))
+        assert lib.mvp_emd_scratch_bytes(3, 4096) == base + lists
+        assert lib.mvp_emd_scratch_bytes_iters(3, 4096, 3000) == base + lists
+        assert lib.mvp_emd_scratch_bytes_iters(3, 4096, 50) == base            # too short to amortise the build
+        assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 512 + 1056 + 16)
+        assert lib.mvp_emd_configure(-1, -1, 3, -1.0, -1) == -2               # MVP_EBADARG
+    finally:
+        assert lib.mvp_emd_configure(-1, -1, _lib.EMD_DEFAULT_TAIL, -1.0, -1) == 0
 
 
 def test_argument_guards_need_no_gpu():
