@@ -184,6 +184,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ int s_wbusy[kEmdWaves];
   __shared__ unsigned long long s_hist2[4];
   if (threadIdx.x < 4) s_hist2[threadIdx.x] = 0;
+  __shared__ unsigned long long s_slow[2][8];  // [d >= 10k cycles][count, nsub, cells, visit steps, extra member iterations, folds, seed cycles, visit cycles]
+  if (threadIdx.x < 16) s_slow[threadIdx.x >> 3][threadIdx.x & 7] = 0;
   __shared__ unsigned long long s_hist[16];  // wave-mode bids: [0..7] duration buckets, [8] sum nsub, [9] sum cells visited, [10] count, [11] linear scans, [12] sum cycles
   if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
 #endif
@@ -563,9 +565,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               s[r4] = 0;
               s1[r4] = 0;
               if (k < nlist) {
-                const int cc = wl[k];
-                s[r4] = c_start[cc] + l16;
-                s1[r4] = c_start[cc + 1];
+                const int cw = wl[k], cc = cw & 0x7FFF;
+                const int m0 = c_start[cc], m1 = c_start[cc + 1];
+                s[r4] = (cw & 0x8000) ? m0 + 16 + l16 : m0 + l16;
+                s1[r4] = (cw & 0x8000) ? m1 : min(m1, m0 + 16);
               }
             }
             bool more = true;
@@ -605,10 +608,18 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             const float tq = tm - cl.w;
             cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
           }
+          // (a cell with more than 16 members is listed twice, see the one-bidder-per-wave path)
+          const bool big = cpass && c_start[c + 1] - c_start[c] > 16;
           const unsigned rmask = (unsigned)((__ballot(cpass) >> rsh) & 0xFFFFull);
-          if (cpass) wl[nlist + __builtin_popcount(rmask & ((1u << l16) - 1u))] = (unsigned short)c;
-          nlist += __builtin_popcount(rmask);
-          if (__any(nlist > kRowListCap - 16)) visit();  // keep room for the next 16
+          const unsigned bmask = (unsigned)((__ballot(big) >> rsh) & 0xFFFFull);
+          if (cpass) {
+            const unsigned lt = (1u << l16) - 1u;
+            const int pos = nlist + __builtin_popcount(rmask & lt) + __builtin_popcount(bmask & lt);
+            wl[pos] = (unsigned short)c;
+            if (big) wl[pos + 1] = (unsigned short)(c | 0x8000);
+          }
+          nlist += __builtin_popcount(rmask) + __builtin_popcount(bmask);
+          if (__any(nlist > kRowListCap - 32)) visit();  // keep room for the next 16 cells
         }
         visit();
 
@@ -722,7 +733,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #ifdef MVP_EMD_PROFILE
       const long long tb1 = __builtin_readcyclecounter();
       long long t_visit = 0;
-      int n_visit = 0, prof_fold = 0;
+      int n_visit = 0, prof_fold = 0, prof_more = 0;
 #endif
 
       // (2) Only cells that intersect the cube |o - q|_inf <= tm can hold a
@@ -775,13 +786,14 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             s[r] = 0;
             s1[r] = 0;
             if (k < nlist) {
-              const int cc = wl[k];
-              s[r] = c_start[cc] + sl;
-              s1[r] = c_start[cc + 1];
+              const int cw = wl[k], cc = cw & 0x7FFF;
+              const int m0 = c_start[cc], m1 = c_start[cc + 1];
+              s[r] = (cw & 0x8000) ? m0 + 16 + sl : m0 + sl;
+              s1[r] = (cw & 0x8000) ? m1 : min(m1, m0 + 16);
             }
           }
           bool more = true;
-          while (more) {
+          while (more) {  // (a second pass only for cells of more than 32 members)
             float4 o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -805,6 +817,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               mine |= s[r] < s1[r];
             }
             more = __any(mine);
+#ifdef MVP_EMD_PROFILE
+            prof_more += more ? 1 : 0;
+#endif
           }
         }
         nlist = 0;
@@ -850,14 +865,22 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const float tq = st.tm - cl.w;
           cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
         }
-        const unsigned long long cmask = __ballot(cpass);
-        if (cpass)
-          wl[nlist + __builtin_popcountll(cmask & ((1ull << lane) - 1ull))] = (unsigned short)c;
-        nlist += __builtin_popcountll(cmask);
+        // A cell with more than 16 members is listed twice: the second entry (bit 15) stands for
+        // members 16.. -- they travel in the same round trip as everything else of the visit step
+        // instead of in a second, dependent one (12 % of the cells, i.e. two of three bids).
+        const bool big = cpass && c_start[c + 1] - c_start[c] > 16;
+        const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
+        if (cpass) {
+          const unsigned long long lt = (1ull << lane) - 1ull;
+          const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(bmask & lt);
+          wl[pos] = (unsigned short)c;
+          if (big) wl[pos + 1] = (unsigned short)(c | 0x8000);
+        }
+        nlist += __builtin_popcountll(cmask) + __builtin_popcountll(bmask);
 #ifdef MVP_EMD_PROFILE
         prof_cells += __builtin_popcountll(cmask);
 #endif
-        if (nlist > (4 * kRowListCap) - kWave) visit();  // keep room for the next 64
+        if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells
       }
       visit();
 #ifdef MVP_EMD_PROFILE
@@ -875,6 +898,15 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         atomicAdd(&s_hist2[1], (unsigned long long)t_visit);
         atomicAdd(&s_hist2[2], (unsigned long long)n_visit);
         atomicAdd(&s_hist2[3], (unsigned long long)prof_fold);
+        unsigned long long *sl = s_slow[d >= 10000 ? 1 : 0];
+        atomicAdd(&sl[0], 1ull);
+        atomicAdd(&sl[1], (unsigned long long)nsub);
+        atomicAdd(&sl[2], (unsigned long long)prof_cells);
+        atomicAdd(&sl[3], (unsigned long long)n_visit);
+        atomicAdd(&sl[4], (unsigned long long)prof_more);
+        atomicAdd(&sl[5], (unsigned long long)prof_fold);
+        atomicAdd(&sl[6], (unsigned long long)(tb1 - tb0));
+        atomicAdd(&sl[7], (unsigned long long)t_visit);
       }
 #endif
       if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
@@ -1303,6 +1335,12 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
              (s_hist[12] - s_hist2[0] - s_hist2[1]) / (s_hist[10] + 1));
     if (cloud < 2)
       printf("cloud %d wg %d price-bound refreshes after round 100: %llu\n", cloud, wg, s_hist2[0] >> 40);
+    if (cloud == 0 && wg == 0)
+      for (int k = 0; k < 2; ++k) {
+        const double c = (double)s_slow[k][0] + 1e-9;
+        printf("cloud 0 wg 0 searches %s 10k cycles: %llu | mean sub-box %.0f cells, visited %.1f, visit steps %.2f, extra member iterations %.2f, folds %.1f, seed %.0f cycles, visits %.0f cycles\n",
+               k ? ">=" : "<", s_slow[k][0], s_slow[k][1] / c, s_slow[k][2] / c, s_slow[k][3] / c, s_slow[k][4] / c, s_slow[k][5] / c, s_slow[k][6] / c, s_slow[k][7] / c);
+      }
     if (cloud < 2)
       printf("cloud %d wg %d Assign (thread 0, %lld samples): loads done at %lld cycles, eviction handled at %lld (sum over winning rounds / all), body done at %lld, phase %lld\n", cloud, wg, prof_an, prof_a1 / (prof_an + 1), prof_a2 / (prof_an + 1), prof_a3 / (prof_an + 1), prof_a4 / (prof_an + 1));
     if (cloud < 2)
