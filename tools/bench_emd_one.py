@@ -13,7 +13,7 @@ nbytes = _lib.emd_scratch_bytes(b, n)
 scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
 dist = torch.zeros(b, n, device=dev); ass = torch.zeros(b, n, dtype=torch.int32, device=dev)
 best = 1e9
-for rep in range(3 if len(sys.argv) <= 5 else 1):
+for rep in range(int(os.environ.get("MVP_BENCH_REPS", 3 if len(sys.argv) <= 5 else 1))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.call("mvp_emd_forward", dev, b, n, x1, x2, dist, ass, eps, iters, scratch, nbytes)
