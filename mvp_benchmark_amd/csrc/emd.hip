@@ -107,6 +107,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   };
+  auto ld_price = [&](int s) -> float {  // obj[s].w alone
+    if constexpr (W == 1) return sc.obj[s].w;
+    else return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)s * 16u + 12u, 0, 16));
+  };
   auto ld_ostate = [&](int s) -> int4 {
     if constexpr (W == 1) {
       return sc.ostate[s];
@@ -1064,10 +1068,14 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         const int c = emd_cell(gg, oo.x, oo.y, oo.z);
         if (oo.w <= c_lo[c].w) {
           float pm = oo.w + bi;
-          const int e1 = c_start[c + 1];
-#pragma unroll 8
-          for (int s = c_start[c]; s < e1; ++s)
-            pm = __builtin_fminf(pm, s == o ? pm : ld_obj(s).w);
+          const int e0 = c_start[c], e1 = c_start[c + 1];
+          // (the first 16 members in ONE round trip: 88 % of the cells have no more)
+          float pv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) pv[k] = (e0 + k < e1 && e0 + k != o) ? ld_price(e0 + k) : __builtin_inff();
+#pragma unroll
+          for (int k = 0; k < 16; ++k) pm = __builtin_fminf(pm, pv[k]);
+          for (int s = e0 + 16; s < e1; ++s) pm = __builtin_fminf(pm, s == o ? pm : ld_price(s));
           c_lo[c].w = pm;
 #ifdef MVP_EMD_PROFILE
           if (it >= 100) atomicAdd(&s_hist2[0], 1ull << 40);  // refresh count in the high bits
