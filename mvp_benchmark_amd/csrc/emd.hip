@@ -470,6 +470,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         {
           float a1 = -1e9f, a2 = -1e9f;
           const int s0 = c_start[c0], s1 = act ? c_start[c0 + 1] : s0;
+          // (the hint objects' load is issued first: it shares the round trip of the home cell's)
+          const bool hint = act && ((l16 == 0 && p1 >= 0) || (l16 == 1 && p2 >= 0));
+          float4 oh = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (hint) oh = ld_obj(l16 == 0 ? p1 : p2);
           for (int s = s0 + l16; __any(s < s1); s += 16) {
             if (s < s1) {
               const float4 o = ld_obj(s);
@@ -477,8 +481,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             }
           }
           bool extra = false;
-          if (act && ((l16 == 0 && p1 >= 0) || (l16 == 1 && p2 >= 0))) {
-            const float4 o = ld_obj(l16 == 0 ? p1 : p2);
+          if (hint) {
+            const float4 o = oh;
             if (emd_cell(gg, o.x, o.y, o.z) != c0) {
               extra = true;
               top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
@@ -709,13 +713,17 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       {
         float a1 = -1e9f, a2 = -1e9f;
         const int s0 = c_start[c0], s1 = c_start[c0 + 1];
+        // (the hint objects' load is issued first: it shares the round trip of the home cell's)
+        const bool hint = (lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0);
+        float4 oh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hint) oh = ld_obj(lane == 0 ? p1 : p2);
         for (int s = s0 + lane; s < s1; s += kWave) {
           const float4 o = ld_obj(s);
           top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
         }
         bool extra = false;
-        if ((lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0)) {
-          const float4 o = ld_obj(lane == 0 ? p1 : p2);
+        if (hint) {
+          const float4 o = oh;
           if (emd_cell(gg, o.x, o.y, o.z) != c0) {
             extra = true;
             top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
