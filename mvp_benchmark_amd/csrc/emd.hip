@@ -509,21 +509,21 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const float tq = tm - o.w;
           const bool ps = in_range && tq >= 0.f && sd <= tq * tq;
           if (__any(ps)) {
-            if (ps) {
-              const float v = emd_value(sd, o.w);
-              if (v > lb1) {
-                lb2 = lb1; lb2k = lbk; lb1 = v; lbk = slot;
-              } else if (v == lb1) {   // rare: reference order on ORIGINAL indices
-                lb2 = v;
-                if (emd_precedes(sc.perm[slot], sc.perm[lbk], n, tpu)) {
-                  lb2k = lbk; lbk = slot;
-                } else {
-                  lb2k = slot;
-                }
-              } else if (v > lb2) {
-                lb2 = v; lb2k = slot;
-              }
+            // (selects, not branches: with branches the compiler keeps the two slots in a
+            // dynamically indexed stack array -- scratch traffic in this loop)
+            const float v = ps ? emd_value(sd, o.w) : -2e9f;
+            const bool gt = v > lb1, eq = ps && v == lb1;
+            bool first = false;   // rare tie for the best: reference order on ORIGINAL indices
+            if (__any(eq)) {
+              if (eq) first = emd_precedes(sc.perm[slot], sc.perm[lbk], n, tpu);
             }
+            const bool g2 = v > lb2;
+            const int nk2 = gt ? lbk : (eq ? (first ? lbk : slot) : (g2 ? slot : lb2k));
+            const float n2 = gt ? lb1 : (eq ? v : (g2 ? v : lb2));
+            lbk = (gt || first) ? slot : lbk;
+            lb1 = gt ? v : lb1;
+            lb2k = nk2;
+            lb2 = n2;
           }
         };
 
