@@ -68,9 +68,10 @@ def parse():
                     help="clouds in the CPU-baseline sample (0 = min(cores, 64))")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20 if args.workload == "eval" else 10
+        # (~7 s of timed region for the eval step: long enough for a 5-s utilisation sampler to see it)
+        args.steps = 150 if args.workload == "eval" else 10
     if args.warmup is None:
-        args.warmup = 2 if args.workload == "eval" else 3
+        args.warmup = 3
     if args.batch is None:
         args.batch = 64 if args.workload == "eval" else 32
     return args
