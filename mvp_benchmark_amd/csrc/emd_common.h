@@ -141,7 +141,7 @@ __device__ __forceinline__ bool emd_band_alarm(u64 old, float inc) {
 
 // Reference merge order between two candidates (ORIGINAL object indices) of
 // equal value: lexicographically smaller (thread_in_unass, tile, k) wins.
-__device__ __forceinline__ bool emd_precedes(int ka, int kb, int n, int tpu) {
+__device__ __attribute__((noinline)) bool emd_precedes(int ka, int kb, int n, int tpu) {
   const int tile_a = ka >> 11, tile_b = kb >> 11;
   const int kka = ka & 2047, kkb = kb & 2047;
   const int end_a = min(n - (tile_a << 11), 2048);
