@@ -489,7 +489,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             }
           }
           const int have = (s1 - s0) + __builtin_popcountll((__ballot(extra) >> rsh) & 0xFFFFull);
-          if (act && have < 2) {  // row-uniform; rare: the first 16 slots (distinct objects)
+          if (__builtin_expect(act && have < 2, 0)) {  // row-uniform; rare: the first 16 slots (distinct objects)
             const float4 o = ld_obj(l16);
             a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
             a2 = -1e9f;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         // search cube covers most of the grid (clustered prediction against a
         // spread target): scan the cell-sorted objects linearly instead
         const bool linear = act && 2 * nsub_all > ncell;
-        if (__any(linear)) {
+        if (__builtin_expect(__any(linear), 0)) {
           for (int base = 0; base < n; base += 64) {   // n % 1024 == 0
             float4 o[4];
 #pragma unroll
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const int oo1 = __builtin_amdgcn_update_dpp(0, lo1, CTRL, 0xF, 0xF, false);
           const bool tie = ob1 == lb1 && obk >= 0 && lbk >= 0;
           bool other_first = false;
-          if (__any(tie)) other_first = tie && emd_precedes(oo1, lo1, n, tpu);
+          if (__builtin_expect(__any(tie), 0)) other_first = tie && emd_precedes(oo1, lo1, n, tpu);
           const bool other_wins = ob1 > lb1 || other_first;
           if (other_wins) {
             const bool from_b1 = lb1 >= ob2;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           }
         }
         const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
-        if (have < 2) {  // wave-uniform; rare: fall back to the first 64 slots
+        if (__builtin_expect(have < 2, 0)) {  // wave-uniform; rare: fall back to the first 64 slots
           const float4 o = ld_obj(lane);
           a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
           a2 = -1e9f;
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       // machinery only adds overhead: scan the cell-sorted objects linearly,
       // 4 x 64 per step, with the same lossless filter.
       const bool linear = 2 * nsub > ncell;
-      if (linear) {
+      if (__builtin_expect(linear, 0)) {
         for (int base = 0; base < n; base += 4 * kWave) {
           float4 o[4];
 #pragma unroll
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     // increments within the 1e-6 band met on one object this round.  Every
     // bidder inside the band of the object's maximal increment raises the
     // key's bidder field; the increment field stays.
-    if (any_alarm) {
+    if (__builtin_expect(any_alarm, 0)) {
 #ifdef MVP_EMD_PROFILE
       n_alarm += 1;
 #endif
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         for (int w = 0; w < W; ++w) maxc = max(maxc, cntw[w]);
         const int even = (Utot + W - 1) / W;
         const int cap = even > kRowModeMin ? (even + 63) / 64 * 64 : (even + 15) / 16 * 16;
-        if (maxc > cap && it + 1 < iters) {
+        if (__builtin_expect(maxc > cap && it + 1 < iters, 0)) {
           const int base = Utot / W, rem = Utot % W;
           int exc[W], dfc[W], exoff = 0, dfoff = 0, my_exoff = 0, my_dfoff = 0;
 #pragma unroll
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       }
       if (!clustered) {
         // (just collapsed: nothing to fetch)
-      } else if (overflow) {
+      } else if (__builtin_expect(overflow, 0)) {
         // too many refreshes to broadcast (the first, heavy rounds): recompute
         // every bound from the prices themselves (stable between barriers)
         for (int c = t; c < ncell; c += kEmdThreads) {
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           total += cnt;
         }
         over = total > kEmdThreads;
-        if (over) {
+        if (__builtin_expect(over, 0)) {
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             if (w == wg) continue;

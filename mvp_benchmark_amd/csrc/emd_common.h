@@ -186,7 +186,7 @@ __device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
       st.b2k = st.bk;
       st.b1 = vl;
       st.bk = kl;
-    } else if (vl == st.b1) {
+    } else if (__builtin_expect(vl == st.b1, 0)) {
       st.b2 = st.b1;
       if (emd_precedes(perm[kl], perm[st.bk], n, tpu)) {
         st.b2k = st.bk;
