@@ -828,7 +828,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               s[r] += 16;
               mine |= s[r] < s1[r];
             }
-            more = __any(mine);
+            more = __builtin_expect(__any(mine), 0);
 #ifdef MVP_EMD_PROFILE
             prof_more += more ? 1 : 0;
 #endif
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       if (u >= U) continue;
       int j, o, b2k;
       float bi;
-      if (u < kBidCache) {
+      if (__builtin_expect(u < kBidCache, 1)) {
         j = s_bj[u]; o = s_bo[u]; bi = s_binc[u]; b2k = s_b2k[u];
       } else {
         j = L[u];
@@ -1054,8 +1054,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           // the evicted owner bids again next round, in this workgroup's list
           st_i32(&ass[prev], -1);
           const int pos = atomicAdd(&s_cnt[nxt], 1);
-          if (pos >= kRecCap) Lnext[pos] = prev;   // entries below kRecCap live in LDS only
-          if (pos < kRecCap) {
+          if (__builtin_expect(pos >= kRecCap, 0)) Lnext[pos] = prev;   // entries below kRecCap live in LDS only
+          if (__builtin_expect(pos < kRecCap, 1)) {
             const float4 pa = ld_person(prev, 0);
             const float4 pb = ld_person(prev, 1);
             s_rq[nxt][pos] = pa;
@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         Utot += cntw[w];
         if (w != wg) overflow |= (int)s_gout[2 * w + 1] > kChgCap;
       }
-      if (tail_ok && Utot > 0 && Utot <= (tail_ok >> 16) && iters - (it + 1) >= (tail_ok & 0xFFFF)) {
+      if (__builtin_expect(tail_ok && Utot > 0 && Utot <= (tail_ok >> 16) && iters - (it + 1) >= (tail_ok & 0xFFFF), 0)) {
         // ---- hand the cloud to the tail kernel: every member appends its list
         // (<= kTailCap < kRecCap entries: all in LDS) to the hand-over record
         int off = 0;
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         }
         return;
       }
-      if (Utot > 0 && Utot <= kSoloMax && it + 1 < iters) {
+      if (__builtin_expect(Utot > 0 && Utot <= kSoloMax && it + 1 < iters, 0)) {
         // ---- hand everything to member 0 (lists of <= kSoloMax persons live
         // in LDS only: publish the person ids; their records are in memory)
         if (wg != 0 && t < cntw[wg]) st_i32(my_ulist + t, s_ri[nxt][t].x);
