@@ -379,7 +379,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       bz1 = __builtin_fmaxf(bz1, o.z);
     }
     c_lo[c] = make_float4(bx0, by0, bz0, 0.f);
-    c_hi[c] = make_float4(bx1, by1, bz1, 0.f);
+    // (.w: the cell holds more than 16 objects -- it is listed twice by the searches, see there)
+    c_hi[c] = make_float4(bx1, by1, bz1, c_start[c + 1] - c_start[c] > 16 ? 1.f : 0.f);
   }
   __syncthreads();
 
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         };
         for (int cb = 0; __any(cb < nsub); cb += 16) {
           const int i = cb + l16;
-          bool cpass = false;
+          bool cpass = false, big_cell = false;
           int c = 0;
           if (i < nsub) {
             // exact small-integer division via float (i < 1728, divisors <= 144)
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             const int kx = rem - ky * nx;
             c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
             const float4 cl = c_lo[c], ch = c_hi[c];
+            big_cell = ch.w != 0.f;
             const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
             const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
             const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
           }
           // (a cell with more than 16 members is listed twice, see the one-bidder-per-wave path)
-          const bool big = cpass && c_start[c + 1] - c_start[c] > 16;
+          const bool big = cpass && big_cell;
           const unsigned rmask = (unsigned)((__ballot(cpass) >> rsh) & 0xFFFFull);
           const unsigned bmask = (unsigned)((__ballot(big) >> rsh) & 0xFFFFull);
           if (cpass) {
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       }
       for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
         const int i = cb + lane;
-        bool cpass = false;
+        bool cpass = false, big_cell = false;
         int c = 0;
         if (i < nsub) {
           // exact small-integer division via float (i < 1728, divisors <= 144)
@@ -876,11 +878,12 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
           const float tq = st.tm - cl.w;
           cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
+          big_cell = ch.w != 0.f;
         }
         // A cell with more than 16 members is listed twice: the second entry (bit 15) stands for
         // members 16.. -- they travel in the same round trip as everything else of the visit step
         // instead of in a second, dependent one (12 % of the cells, i.e. two of three bids).
-        const bool big = cpass && c_start[c + 1] - c_start[c] > 16;
+        const bool big = cpass && big_cell;
         const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
         if (cpass) {
           const unsigned long long lt = (1ull << lane) - 1ull;
