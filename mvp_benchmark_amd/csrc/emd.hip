@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   // alone (same code, workgroup barriers), the others leave.
   bool clustered = W > 1;
 #ifdef MVP_EMD_PROFILE
-  long long cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0, prof_a1 = 0, prof_an = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0;
+  long long prof_pg1 = 0, prof_drain = 0, prof_gather = 0, cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0, prof_a1 = 0, prof_an = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0;
 #endif
 #ifdef MVP_EMD_PROFILE
   const long long t_loop0 = __builtin_readcyclecounter();
@@ -1124,10 +1124,19 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #endif
     // ---------------- end of round: next list sizes + refreshed price bounds
     if (clustered) {
+#ifdef MVP_EMD_PROFILE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long long tpd = __builtin_readcyclecounter();
+#endif
       if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort, same_xcd)) {
         aborted = true;
         break;
       }
+#ifdef MVP_EMD_PROFILE
+      const long long tpg2 = __builtin_readcyclecounter();
+      prof_drain += tpd - tp3;
+      prof_gather += tpg2 - tpd;
+#endif
       Utot = 0;
       bool overflow = false;
       int cntw[W];
@@ -1247,6 +1256,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #endif
         }
       }
+#ifdef MVP_EMD_PROFILE
+      const long long tpb = __builtin_readcyclecounter();
+      prof_pg1 += tpb - tpg2;
+#endif
       if (!clustered) {
         // (just collapsed: nothing to fetch)
       } else if (__builtin_expect(overflow, 0)) {
@@ -1370,8 +1383,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
              cloud, wg, s_hist[10], s_hist[12] / (s_hist[10] + 1), s_hist[8] / (s_hist[10] + 1), s_hist[9] / (s_hist[10] + 1), s_hist[11],
              s_hist[0], s_hist[1], s_hist[2], s_hist[3], s_hist[4], s_hist[5], s_hist[6], s_hist[7]);
     if (cloud < 2)
-      printf("cloud %d wg %d: rounds %lld bids %lld alarms %lld rebalances %lld | cycles bid %lld sync1 %lld assign %lld sync2 %lld\n",
+      printf("cloud %d wg %d: rounds %lld bids %lld alarms %lld rebalances %lld | cycles bid %lld sync1 %lld assign %lld sync2 %lld \n",
              cloud, wg, n_rounds, n_bids, n_alarm, n_rebal, cyc_bid, cyc_sync1, cyc_assign, cyc_sync2);
+    if (cloud < 2)
+      printf("cloud %d wg %d: sync2 = store drain %lld + closing gather %lld + list bookkeeping %lld + bound fetch (rest)\n", cloud, wg, prof_drain, prof_gather, prof_pg1);
 #endif
   }
   // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
