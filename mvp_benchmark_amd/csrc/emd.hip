@@ -1139,12 +1139,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #endif
       Utot = 0;
       bool overflow = false;
-      int cntw[W];
+      int cntw[W], chgw[W];  // (the same for every lane: kept in scalar registers, the arithmetic on them is SALU work)
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        cntw[w] = (int)s_gout[2 * w];
+        cntw[w] = __builtin_amdgcn_readfirstlane((int)s_gout[2 * w]);
+        chgw[w] = __builtin_amdgcn_readfirstlane((int)s_gout[2 * w + 1]);
         Utot += cntw[w];
-        if (w != wg) overflow |= (int)s_gout[2 * w + 1] > kChgCap;
+        if (w != wg) overflow |= chgw[w] > kChgCap;
       }
       if (__builtin_expect(tail_ok && Utot > 0 && Utot <= (tail_ok >> 16) && iters - (it + 1) >= (tail_ok & 0xFFFF), 0)) {
         // ---- hand the cloud to the tail kernel: every member appends its list
@@ -1281,7 +1282,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #pragma unroll
         for (int w = 0; w < W; ++w) {
           if (w == wg) continue;
-          const int cnt = (int)s_gout[2 * w + 1];
+          const int cnt = chgw[w];
           if (!chg_have && idx >= 0 && idx < cnt) {
             chg_pend = __hip_atomic_load(sc.chg + (size_t)w * kChgCap + idx, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
@@ -1295,7 +1296,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             if (w == wg) continue;
-            const int cnt = (int)s_gout[2 * w + 1];
+            const int cnt = chgw[w];
             const u64 *src = sc.chg + (size_t)w * kChgCap;
             for (int i = t; i < cnt; i += kEmdThreads) {
               const u64 e = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
