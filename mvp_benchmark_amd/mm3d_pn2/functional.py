@@ -13,6 +13,8 @@ Reference wrappers mirrored here (paths under utils/mm3d_pn2/ops/):
   interpolate/three_nn.py:8-45         interpolate/three_interpolate.py:8-63
   gather_points/gather_points.py:7-52  group_points/group_points.py:166-221
 """
+import threading
+
 import torch
 from torch.autograd import Function
 
@@ -36,29 +38,61 @@ SCATTER_OVERWRITE, SCATTER_INDEX_READY = 1, 2      # mode bits of the *_grad_ws 
 # SA_module, centre + neighbour features, xyz and features of edge_preserve_sampling), and a
 # retained graph may be differentiated repeatedly.  An entry holds a reference to its index
 # (and weight) tensor, so the storage it describes cannot be recycled while the entry lives;
-# `_version` detects in-place edits.  Small LRU: the lists are a few MB each.
+# `_version` detects in-place edits made through PyTorch.
+#
+# Contract: an index / weight tensor that went through a backward pass must not be rewritten
+# through a RAW POINTER afterwards (`_lib.call` writing into a pre-allocated index workspace,
+# `.data` edits): `_version` does not see such writes and the next backward on it would reduce
+# over the stale inverted list.  Code that recycles index buffers that way calls
+# `clear_scatter_cache()` after the rewrite, or switches the cache off
+# (`SCATTER_CACHE = False`: every backward rebuilds its list, ~15 us).
+# An entry is published only AFTER the kernel that builds its list has been launched
+# successfully (`_scatter_commit`), so a call that raises leaves nothing behind.  Autograd runs
+# one thread per device: the list is guarded by a lock.
+SCATTER_CACHE = True
 _TRANSPOSED = []
 _TRANSPOSED_CAP = 12
+_TRANSPOSED_LOCK = threading.Lock()
+
+
+def clear_scatter_cache():
+    """Forget every cached inverted index list (see the contract above)."""
+    with _TRANSPOSED_LOCK:
+        del _TRANSPOSED[:]
 
 
 def _scatter_scratch(idx, weight, b, n_dst, m_src, r):
-    """Workspace of the scatter-add gradients -> (scratch, nbytes, mode bits).
+    """Workspace of the scatter-add gradients -> (scratch, nbytes, mode bits, key).
     0 bytes when the shape is not covered: the entry point then runs the plain
-    kernels (zero-filling first, since OVERWRITE is always requested)."""
+    kernels (zero-filling first, since OVERWRITE is always requested).  `key` is
+    not None when the caller has to publish the list it is about to build
+    (`_scatter_commit`, after the launch succeeded)."""
     nbytes = scatter_scratch_bytes(b, n_dst, m_src, r)
     if not nbytes:
-        return None, 0, SCATTER_OVERWRITE
-    key = (idx.data_ptr(), idx._version, tuple(idx.shape), n_dst,
+        return None, 0, SCATTER_OVERWRITE, None
+    if not SCATTER_CACHE:
+        return torch.empty(nbytes, dtype=torch.uint8, device=idx.device), nbytes, SCATTER_OVERWRITE, None
+    key = (idx.data_ptr(), idx._version, tuple(idx.shape), n_dst, idx.device,
            None if weight is None else (weight.data_ptr(), weight._version))
-    for i, (k, _, _, scratch) in enumerate(_TRANSPOSED):
-        if k == key:
-            _TRANSPOSED.append(_TRANSPOSED.pop(i))
-            return scratch, nbytes, SCATTER_OVERWRITE | SCATTER_INDEX_READY
+    with _TRANSPOSED_LOCK:
+        for i, (k, _, _, scratch) in enumerate(_TRANSPOSED):
+            if k == key:
+                _TRANSPOSED.append(_TRANSPOSED.pop(i))
+                return scratch, nbytes, SCATTER_OVERWRITE | SCATTER_INDEX_READY, None
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=idx.device)
-    _TRANSPOSED.append((key, idx, weight, scratch))
-    if len(_TRANSPOSED) > _TRANSPOSED_CAP:
-        _TRANSPOSED.pop(0)
-    return scratch, nbytes, SCATTER_OVERWRITE
+    return scratch, nbytes, SCATTER_OVERWRITE, key
+
+
+def _scatter_commit(key, idx, weight, scratch):
+    """Publish the inverted list the call just built (no-op for key None)."""
+    if key is None:
+        return
+    with _TRANSPOSED_LOCK:
+        if any(k == key for k, _, _, _ in _TRANSPOSED):   # another thread built the same list
+            return
+        _TRANSPOSED.append((key, idx, weight, scratch))
+        if len(_TRANSPOSED) > _TRANSPOSED_CAP:
+            _TRANSPOSED.pop(0)
 
 
 # ------------------------------------------------------------------ sampling
@@ -200,9 +234,10 @@ class ThreeInterpolate(Function):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.shape
         grad_features = _new(grad_out, B, c, m)          # written, not accumulated into (OVERWRITE)
-        scratch, nbytes, mode = _scatter_scratch(idx, weight, B, m, n, 3)
+        scratch, nbytes, mode, key = _scatter_scratch(idx, weight, B, m, n, 3)
         call("mvp_three_interpolate_grad_ws", grad_out.device, B, c, n, m, grad_out.data.contiguous(), idx, weight,
              grad_features, scratch, nbytes, mode)
+        _scatter_commit(key, idx, weight, scratch)
         return grad_features, None, None
 
 
@@ -227,9 +262,10 @@ class GatherPoints(Function):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.shape
         grad_features = _new(grad_out, B, C, N)
-        scratch, nbytes, mode = _scatter_scratch(idx, None, B, N, npoint, 1)
+        scratch, nbytes, mode, key = _scatter_scratch(idx, None, B, N, npoint, 1)
         call("mvp_gather_points_grad_ws", grad_out.device, B, C, N, npoint, grad_out.data.contiguous(), idx,
              grad_features, scratch, nbytes, mode)
+        _scatter_commit(key, idx, None, scratch)
         return grad_features, None
 
 
@@ -253,9 +289,10 @@ class GroupingOperation(Function):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.shape
         grad_features = _new(grad_out, B, C, N)
-        scratch, nbytes, mode = _scatter_scratch(idx, None, B, N, npoint * nsample, 1)
+        scratch, nbytes, mode, key = _scatter_scratch(idx, None, B, N, npoint * nsample, 1)
         call("mvp_group_points_grad_ws", grad_out.device, B, C, N, npoint, nsample, grad_out.data.contiguous(), idx,
              grad_features, scratch, nbytes, mode)
+        _scatter_commit(key, idx, None, scratch)
         return grad_features, None
 
 
