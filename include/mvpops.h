@@ -16,7 +16,10 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *     Launches are asynchronous on that stream; nothing here synchronises.
  *   - the caller owns every buffer, including scratch; the library allocates
- *     nothing and keeps no state between calls (re-entrant, any thread).
+ *     nothing and keeps no DATA between calls (re-entrant, any thread).  The one
+ *     piece of process-wide state is the set of tuning knobs behind
+ *     mvp_emd_configure (which kernels mvp_emd_forward launches, never what it
+ *     computes); nothing else is remembered.
  *   - return value: MVP_OK (0) on success; MVP_EBADSHAPE / MVP_EBADARG for
  *     argument errors (nothing launched); MVP_ELAUNCH if HIP reported a
  *     launch error (details via mvp_last_hip_error()).  The reference's
@@ -40,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 7
+#define MVP_ABI_VERSION 8
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -90,12 +93,8 @@ int mvp_chamfer_backward(int b, int n, int m, const float *xyz1,
  * Contents on entry are irrelevant (the kernel initialises its own state).
  * The last 16*b bytes of the buffer passed to mvp_emd_forward (its
  * scratch_bytes, a multiple of 16) receive per-cloud {int64 rounds, int64 bids}
- * statistics.  mvp_emd_scratch_bytes_iters is the exact requirement of a call
- * with that many rounds (the list-driven tail kernel, mvp_emd_configure(tail =
- * 2), keeps 6.2 KB per point for auctions of >= 512 rounds);
- * mvp_emd_scratch_bytes is enough for any number of rounds. */
+ * statistics. */
 long long mvp_emd_scratch_bytes(int b, int n);
-long long mvp_emd_scratch_bytes_iters(int b, int n, int iters);
 
 /* Replaces emd.forward = emd_forward (utils/metrics/EMD/emd.cpp:14-20,29) ->
  * emd_cuda_forward (emd_cuda.cu:228-282): `iters` auction rounds of
@@ -109,13 +108,14 @@ long long mvp_emd_scratch_bytes_iters(int b, int n, int iters);
  * iters >= 1; eps > 0 (-> MVP_EBADARG: the auction needs strictly positive bid
  * increments, and the search prunes on prices that never fall).  Deterministic: GetMax's racy last-writer (emd_cuda.cu:188-191)
  * is pinned to the highest qualifying bidder index.
- * Two launches: a persistent cooperative kernel in which up to 8 workgroups
- * share a cloud when b leaves CUs free (b*W <= CU count), and -- for n <= 16384
- * -- a second kernel that takes a cloud over once at most 256 persons are
- * unassigned (every workgroup of the cloud keeps the prices in LDS, exact
- * per-person candidate caches, one all-gather per round; exits at once for
- * clouds that were finished before).  The call enqueues one small
- * memset (barrier words, hand-over records, statistics) ahead of them.
+ * Launches: one small memset (barrier words, hand-over records, statistics),
+ * then a persistent cooperative kernel in which up to 8 workgroups share a
+ * cloud when b leaves CUs free (b*W <= CU count), and -- for auctions of more
+ * than 64 rounds, unless mvp_emd_configure(split = 0) -- a second cooperative
+ * kernel of the same shape (csrc/emd_lean.hip) that takes a cloud over for the
+ * rounds in which every workgroup has fewer bidders than four per wave (from
+ * round ~100 on at 16384 points); it exits at once for clouds the first kernel
+ * finished.
  * If a cluster wait is abandoned (members not co-resident for tens of seconds;
  * never seen) dist is filled with NaN, assignment with -1 and the statistics
  * word `rounds` is negative: the host wrapper checks for NaN lazily, and
@@ -125,19 +125,15 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
                     void *scratch, long long scratch_bytes, void *stream);
 
 /* Tuning / A-B knobs of mvp_emd_forward, process-wide (defaults: environment
- * variables MVP_EMD_CLUSTER / _SAME_XCD / _TAIL / _TAIL_DELTA read once at
- * first use).  A negative argument leaves that knob unchanged.
+ * variables MVP_EMD_CLUSTER / _SAME_XCD / _SPLIT read once at first use).  A
+ * negative argument leaves that knob unchanged.
  *   cluster     0 = automatic, or 1|2|4|8: cap of the workgroups per cloud
  *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
- *   tail        0: the clustered kernel runs every round; 1: hand-over to the
- *               tail kernel (emd_tail.hip); 2: hand-over to the list-driven
- *               single-workgroup kernel (emd_solo.hip)
- *   tail_delta  width of the candidate caches in units of eps (0: no caches)
- *   tail_cluster 0 = as the first kernel, or 1|2|4|8: cap of the tail kernel's
- *               workgroups per cloud
- * Results never depend on these (every variant is bit-identical). */
-int mvp_emd_configure(int cluster, int same_xcd, int tail, float tail_delta,
-                      int tail_cluster);
+ *   split       1 (default): the tail rounds run in the second kernel;
+ *               0: the first kernel runs every round
+ * This is the library's only process-wide state.  Results never depend on it
+ * (every setting is bit-identical: tests/test_gpu_ops.py). */
+int mvp_emd_configure(int cluster, int same_xcd, int split);
 
 /* Replaces emd.backward = emd_backward (emd.cpp:22-25,30) ->
  * emd_cuda_backward (emd_cuda.cu:302-316) -> NmDistanceGradKernel (:284-300).

@@ -50,10 +50,10 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 7   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 8   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
-# defaults of mvp_emd_configure's knobs (csrc/emd.hip: emd_knobs)
-EMD_DEFAULT_TAIL, EMD_DEFAULT_TAIL_DELTA = 0, 3.0
+# default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
+EMD_DEFAULT_SPLIT = 1
 
 _lib = None
 
@@ -78,10 +78,8 @@ def load():
     lib.mvp_last_hip_error.restype = ctypes.c_char_p
     lib.mvp_emd_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_emd_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
-    lib.mvp_emd_scratch_bytes_iters.restype = ctypes.c_longlong
-    lib.mvp_emd_scratch_bytes_iters.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.mvp_emd_configure.restype = ctypes.c_int
-    lib.mvp_emd_configure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+    lib.mvp_emd_configure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.mvp_fps_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_fps_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_chamfer_scratch_bytes.restype = ctypes.c_longlong
@@ -137,16 +135,14 @@ def call(name, device, *args):
 
 
 def emd_scratch_bytes(b, n, iters=None):
-    """Scratch of mvp_emd_forward: for any number of rounds, or exactly for `iters` rounds."""
-    if iters is None:
-        return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
-    return int(load().mvp_emd_scratch_bytes_iters(int(b), int(n), int(iters)))
+    """Scratch of mvp_emd_forward (the same for any number of rounds)."""
+    return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
 
 
-def emd_configure(cluster=-1, same_xcd=-1, tail=-1, tail_delta=-1.0, tail_cluster=-1):
+def emd_configure(cluster=-1, same_xcd=-1, split=-1):
     """Process-wide tuning knobs of mvp_emd_forward (negative = unchanged;
-    cluster / tail_cluster = 0: automatic).  Results do not depend on them."""
-    rc = load().mvp_emd_configure(int(cluster), int(same_xcd), int(tail), float(tail_delta), int(tail_cluster))
+    cluster = 0: automatic).  Results do not depend on them."""
+    rc = load().mvp_emd_configure(int(cluster), int(same_xcd), int(split))
     if rc != MVP_OK:
         raise MvpOpsError("mvp_emd_configure: %s" % _ERR.get(rc, rc))
 
@@ -176,6 +172,6 @@ def pointwise_wgrad_mfma_scratch_bytes(b, cin, cout, length, with_bias):
 
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
-    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_scratch_bytes_iters", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes",
+    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes",
             "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes", "mvp_pointwise_wgrad_mfma_scratch_bytes"] \
         + list(SIGNATURES)

@@ -1,5 +1,5 @@
-// Shared device helpers of the EMD auction kernels (emd.hip: the clustered head
-// kernel; emd_tail.hip: the single-workgroup tail kernel).  See emd.hip for the
+// Shared device helpers of the EMD auction kernels (emd.hip: the clustered first
+// kernel; emd_lean.hip: the kernel of the one-bidder-per-wave rounds).  See emd.hip for the
 // design notes and the reference citations.
 #pragma once
 #include <stdlib.h>
@@ -30,14 +30,12 @@ constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broad
 // four-bidders-per-wave schedule were tried in round 2: 5 % / 23 % / 57 % slower at the headline shape)
 constexpr int kSoloMax = MVP_EMD_SOLO;
 constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens of seconds), then abort
-// The tail of the auction (emd_tail.hip): once at most kTailCap persons are
-// unassigned (their number never grows) the clustered kernel hands the cloud to
-// a single-workgroup kernel that keeps the prices in LDS.  Clouds of more than
-// kTailMaxN points (prices would not fit) finish in the clustered kernel.
-constexpr int kTailCap = 256;
-constexpr int kTailMaxN = 16384;
-constexpr int kTailK = 16;        // candidates cached per person
-constexpr int kCacheRec = 128;    // bytes of a person's candidate cache in scratch
+// The lean kernel (emd_lean.hip) takes a cloud over once no workgroup has more than kRowModeMin
+// bidders, at most kLeanCap persons are unassigned (their number never grows, so every later
+// list fits the LDS record cache) and at least kLeanMinRounds rounds are left.
+constexpr int kLeanCap = 384;
+constexpr int kLeanMinRounds = 64;
+static_assert(kLeanCap <= kRecCap, "the lean kernel keeps every list entry's record in LDS");
 
 // Filter slack.  An object is skipped only if
 //   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)
@@ -67,40 +65,38 @@ struct EmdScratch {
   int *perm;       // (n) slot -> original object index
   int *ulist;      // (W x 2n) ping-pong unassigned lists, one pair per workgroup
   u64 *chg;        // (W x kChgCap) {cell, bits(price bound)} broadcast per round
-  int *cstart;     // (kMaxCells + 4) cell offsets of the cell-sorted order (for the tail kernel)
-  char *cache;     // (n x kCacheRec, n <= kTailMaxN only) candidate cache per person:
-                   //   u16 slot[16] | f32 sqrt-distance[16] | f32 tau | i32 count | pad
+  int *cstart;     // (kMaxCells + 4) cell offsets of the cell-sorted order (for the lean kernel)
 };
 
-// Hand-over record of a cloud (head kernel -> tail kernel), one per cloud after
-// the barrier granules.  next_it == 0: nothing to resume.
-struct EmdResume {
-  int next_it;     // first round the tail kernel runs
-  int utot;        // persons still unassigned (= entries of `list`)
+// Hand-over record of a cloud (first kernel -> lean kernel), after the barrier granules.
+// next_it == 0: nothing to resume.  The members' lists of unassigned persons are at the start
+// of their list areas (EmdScratch::ulist).
+struct EmdHandover {
+  int next_it;     // first round the lean kernel runs
+  int utot;        // persons still unassigned
   int g;           // grid geometry (same arithmetic in both kernels)
   float lox, loy, loz, invh;
-  int pad;
-  int list[kTailCap];
+  int err;         // the first kernel's internal-error flag
+  int cnt[kMaxCluster];   // entries of each member's list
 };
 
 __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
-  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg + cstart (+ caches)
-  return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8 + (size_t)(kMaxCells + 4) * 4 +
-         (n <= kTailMaxN ? (size_t)n * kCacheRec : 0);
+  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg + cstart
+  return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8 + (size_t)(kMaxCells + 4) * 4;
 }
 // After the per-cloud areas ("tail" of the scratch buffer, zeroed by the host
-// before the launch): 256 B of barrier granules per cloud for the clustered
-// kernel, 256 B per cloud for the tail kernel, the hand-over records, then the
+// before the launch): 256 B of barrier granules per cloud for the first
+// kernel, 256 B per cloud for the lean kernel, the hand-over records, then the
 // per-cloud statistics {rounds, bids} (last: read by bench.py).
-constexpr size_t kEmdTailPerCloud = 256 + 256 + sizeof(EmdResume) + 16;
+constexpr size_t kEmdTailPerCloud = 256 + 256 + sizeof(EmdHandover) + 16;
 __host__ __device__ inline unsigned long long *emd_granules(char *tail, int b, int cloud, int which) {
   return reinterpret_cast<unsigned long long *>(tail + (size_t)which * b * 256 + (size_t)cloud * 256);
 }
-__host__ __device__ inline EmdResume *emd_resume(char *tail, int b, int cloud) {
-  return reinterpret_cast<EmdResume *>(tail + (size_t)b * 512) + cloud;
+__host__ __device__ inline EmdHandover *emd_handover(char *tail, int b, int cloud) {
+  return reinterpret_cast<EmdHandover *>(tail + (size_t)b * 512) + cloud;
 }
 __host__ __device__ inline long long *emd_stats(char *tail, int b, int cloud) {
-  return reinterpret_cast<long long *>(tail + (size_t)b * (512 + sizeof(EmdResume))) + 2 * (size_t)cloud;
+  return reinterpret_cast<long long *>(tail + (size_t)b * (512 + sizeof(EmdHandover))) + 2 * (size_t)cloud;
 }
 
 __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
@@ -112,7 +108,6 @@ __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
   s.ulist = reinterpret_cast<int *>(base + (size_t)n * 68);
   s.chg = reinterpret_cast<u64 *>(base + (size_t)n * (68 + 8 * kMaxCluster));
   s.cstart = reinterpret_cast<int *>(base + (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8);
-  s.cache = reinterpret_cast<char *>(s.cstart + (kMaxCells + 4));
   return s;
 }
 
@@ -170,11 +165,9 @@ struct BidState {
 
 // Fold the candidates flagged in `mask` (exact value v and slot k per lane)
 // into the uniform state, lowest lane first.
-// dl > 0 (tail kernel): the filter is kept dl looser than the second best
-// needs, so that everything within dl of it is seen (candidate cache).
 __device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
                                          float v, int k, int n, int tpu,
-                                         const int *__restrict__ perm, float dl = 0.f) {
+                                         const int *__restrict__ perm) {
   while (mask) {
     const int l = __builtin_ctzll(mask);
     mask &= mask - 1;
@@ -200,7 +193,7 @@ __device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
     }
   }
   // thresholds only ever tighten (the seed may already be tighter)
-  st.tm = __builtin_fminf(st.tm, (3.0f - (st.b2 - dl)) + kMargin);
+  st.tm = __builtin_fminf(st.tm, (3.0f - st.b2) + kMargin);
 }
 
 __device__ __forceinline__ void top2_insert(float &a1, float &a2, float v) {
@@ -306,51 +299,6 @@ __device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned 
   }
   __syncthreads();
   return *s_abort == 0;
-}
-
-constexpr int kTailCells = 1331;  // 11^3: n <= 16384 objects give g <= 11 (emd.hip: (g+1)^3 * 12 <= n)
-constexpr int kStage = 40;        // candidates a search can stage for the cache (more: no cache this time)
-
-// ---- Static neighbour lists of the list-driven tail kernel (emd_solo.hip), in their own area
-// after the hand-over records.  Per cloud: one 16-byte record per grid cell (bounding box as fp16
-// rounded outwards + price lower bound at hand-over), then one record per PERSON:
-//   u16 hdr[32]  | u16 slot[kListCap] | f32 dist[kListCap]
-// holding every object whose key = fl(sqrtf distance + price at hand-over) lies in one of the
-// first hdr[31] shells of width 1/64; hdr[s] = entries in shells 0..s (entries are grouped by
-// shell, unordered inside one).  Prices only rise, so an object that is NOT listed is worth
-// < 3 - hdr[31]/64 for the rest of the auction.
-constexpr int kListCap = 1024;      // entries per person
-constexpr int kListShells = 31;     // shells a header can describe (keys < 31/64)
-constexpr float kListScale = 64.f;  // 1 / shell width (a power of two: the scaling is exact)
-constexpr size_t kListRec = 64 + (size_t)kListCap * 6;
-// 1344 cell records, then the persons sorted by cell: u16 pstart[1344], u16 pperm[kTailMaxN]
-constexpr size_t kListCellArea = (size_t)(kTailCells + 13) * 16 + (size_t)(kTailCells + 13) * 2 + (size_t)kTailMaxN * 2;
-constexpr int kListMinIters = 512;  // shorter auctions do not amortise the build
-__host__ __device__ inline size_t emd_lists_per_cloud(int n) { return kListCellArea + (size_t)n * kListRec; }
-
-// fp16 bounds of a float, rounded outwards (box lo down, box hi up), as bits
-__device__ __forceinline__ unsigned half_bits_down(float x) {
-  _Float16 h = (_Float16)x;  // round to nearest even; +-inf on overflow
-  unsigned short b = __builtin_bit_cast(unsigned short, h);
-  if ((float)h > x) {  // step to the next smaller half
-    if (b == 0x0000u) b = 0x8001u;
-    else if (b & 0x8000u) b += 1;
-    else b -= 1;
-  }
-  return b;
-}
-__device__ __forceinline__ unsigned half_bits_up(float x) {
-  _Float16 h = (_Float16)x;
-  unsigned short b = __builtin_bit_cast(unsigned short, h);
-  if ((float)h < x) {  // step to the next larger half
-    if (b == 0x8000u) b = 0x0001u;
-    else if (b & 0x8000u) b -= 1;
-    else b += 1;
-  }
-  return b;
-}
-__device__ __forceinline__ float half_bits_to_float(unsigned b) {
-  return (float)__builtin_bit_cast(_Float16, (unsigned short)b);
 }
 
 template <int CTRL>

@@ -50,7 +50,7 @@ class emdFunction(Function):
         dist = torch.zeros(batchsize, n, device=device)
         assignment = torch.zeros(batchsize, n, device=device,
                                  dtype=torch.int32) - 1
-        nbytes = emd_scratch_bytes(batchsize, n, iters)
+        nbytes = emd_scratch_bytes(batchsize, n)
         scratch = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
 
         call("mvp_emd_forward", device, batchsize, n, xyz1, xyz2, dist,

@@ -174,12 +174,12 @@ def cluster_width():
 
 
 @pytest.fixture
-def emd_variant():
-    """Selects the auction variant: tail kernel on / off, candidate-cache width
-    (mvp_emd_configure); defaults restored afterwards."""
+def emd_split():
+    """Selects whether the tail rounds run in the lean second kernel (mvp_emd_configure(split));
+    default restored afterwards."""
     from mvp_benchmark_amd import _lib
-    yield lambda tail, delta, tail_cluster=0: _lib.emd_configure(tail=tail, tail_delta=delta, tail_cluster=tail_cluster)
-    _lib.emd_configure(tail=_lib.EMD_DEFAULT_TAIL, tail_delta=_lib.EMD_DEFAULT_TAIL_DELTA, tail_cluster=0)
+    yield lambda split: _lib.emd_configure(split=split)
+    _lib.emd_configure(split=_lib.EMD_DEFAULT_SPLIT)
 
 
 @pytest.mark.parametrize("width", [1, 2, 4, 8])
@@ -205,90 +205,45 @@ def test_emd_every_cluster_width_matches_oracle(oracle, cluster_width, width, ki
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
-@pytest.mark.parametrize("variant", ["no_tail", "tail_no_cache", "tail_cache_narrow", "tail_cache_default", "tail_cache_wide"])
-@pytest.mark.parametrize("kind", ["uniform", "duplicates", "few_rounds_left", "last_round_forced"])
-def test_emd_tail_kernel_variants_match_oracle(oracle, emd_variant, cluster_width, variant, kind):
-    """The rounds after <= 256 persons are unassigned run in emd_tail_kernel
-    (prices in LDS, exact per-person candidate caches).  Every variant -- no
-    hand-over at all, hand-over without caches, narrow / default / wide caches
-    (hit rates from ~30 % to ~75 %) -- must give the oracle's bits: assignment
-    and distances.  `duplicates` forces value ties inside the caches (tie order
-    on original indices); `few_rounds_left` hands over two rounds before the end;
-    `last_round_forced` ends with persons still unassigned (forced assignment,
-    emd_cuda.cu:201)."""
+def _handover_round(oracle, x1, x2, eps, width):
+    """First round the lean kernel runs for every cloud of the batch (oracle trace of the
+    unassigned counts): the hand-over needs <= 384 unassigned persons in total and <= 96 per
+    workgroup; with the persons spread evenly over `width` lists that is the first round that
+    starts with <= min(384, 96 * width) of them (an upper bound of the real hand-over round is
+    enough for the tests below: they only need to straddle it)."""
+    trace = oracle.emd_forward_ex(x1, x2, eps, 3000)[3]
+    cap = min(384, 96 * width)
+    return max(int(np.argmax(row <= cap)) for row in trace)
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("width", [1, 2, 4, 8])
+@pytest.mark.parametrize("kind", ["uniform", "duplicates", "few_rounds_left", "last_round_forced", "person_blob",
+                                  "object_blob", "two_blobs"])
+def test_emd_split_kernels_match_oracle(oracle, emd_split, cluster_width, split, width, kind):
+    """The rounds after the last four-bidders-per-wave round run in emd_lean_kernel (split = 1,
+    the default) or stay in emd_auction_kernel (split = 0): both must give the oracle's bits --
+    assignment and distances -- for every cluster width.  `duplicates` forces value ties (tie
+    order on original indices); `few_rounds_left` ends the auction a few rounds after the
+    earliest possible hand-over (the hand-over needs 64 remaining rounds, so some clouds are
+    handed over and some are not); `last_round_forced` ends with persons still unassigned (forced
+    assignment, emd_cuda.cu:201) in the second kernel; the blobs make the search cube cover the
+    grid (linear-scan fallback) and keep many bidders on few objects."""
     from mvp_benchmark_amd.metrics import emd
-    tail, delta = {"no_tail": (0, 5.0), "tail_no_cache": (1, 0.0), "tail_cache_narrow": (1, 1.0),
-                   "tail_cache_default": (1, 5.0), "tail_cache_wide": (1, 20.0)}[variant]
-    emd_variant(tail, delta)
+    emd_split(split)
+    cluster_width(width)
     if kind == "uniform":
         x1, x2, eps, iters = rand_clouds(31, 3, 4096, 3), rand_clouds(32, 3, 4096, 3), 0.004, 3000
     elif kind == "duplicates":
         x1 = np.tile(rand_clouds(33, 2, 512, 3), (1, 4, 1))
         x2, eps, iters = np.tile(rand_clouds(34, 2, 256, 3), (1, 8, 1)), 0.005, 1500
     elif kind == "few_rounds_left":
-        x1, x2, eps, iters = rand_clouds(35, 2, 2048, 3), rand_clouds(36, 2, 2048, 3), 0.004, 0
-    else:
-        x1, x2, eps, iters = rand_clouds(37, 2, 2048, 3), rand_clouds(38, 2, 2048, 3), 0.002, 400
-    if kind == "few_rounds_left":
-        # hand-over = first round that starts with <= 256 unassigned persons (oracle trace)
-        trace = oracle.emd_forward_ex(x1, x2, eps, 3000)[3]
-        handover = max(int(np.argmax(row <= 256)) for row in trace)
+        x1, x2, eps = rand_clouds(35, 2, 2048, 3), rand_clouds(36, 2, 2048, 3), 0.004
+        handover = _handover_round(oracle, x1, x2, eps, width)
         assert 0 < handover < 2900
-        iters = handover + 2
-    if kind == "last_round_forced":
-        assert oracle.emd_forward_ex(x1, x2, eps, iters)[3][:, -1].min() > 0   # persons left for the forced round
-    dist, ass = emd()(dev(x1), dev(x2), eps, iters)
-    od, oa = oracle.emd_forward(x1, x2, eps, iters)
-    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
-    np.testing.assert_array_equal(dist.cpu().numpy(), od)
-
-
-@pytest.mark.parametrize("tail_width", [1, 2, 4, 8])
-@pytest.mark.parametrize("kind", ["uniform", "duplicates"])
-def test_emd_tail_cluster_widths_match_oracle(oracle, emd_variant, tail_width, kind):
-    """The tail kernel with 1, 2, 4 or 8 workgroups per cloud (each with its own
-    LDS copy of the prices, bids exchanged behind one all-gather per round)."""
-    from mvp_benchmark_amd.metrics import emd
-    emd_variant(1, 5.0, tail_width)
-    if kind == "uniform":
-        x1, x2, eps, iters = rand_clouds(51, 3, 4096, 3), rand_clouds(52, 3, 4096, 3), 0.004, 3000
-    else:
-        x1 = np.tile(rand_clouds(53, 2, 512, 3), (1, 4, 1))
-        x2, eps, iters = np.tile(rand_clouds(54, 2, 256, 3), (1, 8, 1)), 0.005, 1500
-    dist, ass = emd()(dev(x1), dev(x2), eps, iters)
-    od, oa = oracle.emd_forward(x1, x2, eps, iters)
-    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
-    np.testing.assert_array_equal(dist.cpu().numpy(), od)
-
-
-@pytest.mark.parametrize("delta", [1.0, 3.0, 20.0])
-@pytest.mark.parametrize("kind", ["uniform", "duplicates", "barely_handed_over", "last_round_forced", "person_blob",
-                                  "object_blob", "two_blobs"])
-def test_emd_list_driven_tail_matches_oracle(oracle, emd_variant, kind, delta):
-    """mvp_emd_configure(tail=2): after the hand-over one workgroup per cloud runs the rounds
-    with prices and owners in LDS, and a bid is a scan of the person's static neighbour list
-    (emd_solo.hip; lists written between the two kernels, ordered by distance + price at
-    hand-over).  Same bits as the oracle for narrow / default / wide candidate caches.
-    `duplicates`: value ties (tie order on original indices) inside lists and caches;
-    `barely_handed_over`: the fewest remaining rounds that are still handed over;
-    `last_round_forced`: persons left for the forced last round (emd_cuda.cu:201);
-    `person_blob` / `object_blob` / `two_blobs`: lists that are cut early or empty (every
-    shell overflows), i.e. the full-scan fallback of the list search."""
-    from mvp_benchmark_amd.metrics import emd
-    emd_variant(2, delta)
-    if kind == "uniform":
-        x1, x2, eps, iters = rand_clouds(61, 3, 4096, 3), rand_clouds(62, 3, 4096, 3), 0.004, 3000
-    elif kind == "duplicates":
-        x1 = np.tile(rand_clouds(63, 2, 512, 3), (1, 4, 1))
-        x2, eps, iters = np.tile(rand_clouds(64, 2, 256, 3), (1, 8, 1)), 0.005, 1500
-    elif kind == "barely_handed_over":
-        x1, x2, eps = rand_clouds(65, 2, 2048, 3), rand_clouds(66, 2, 2048, 3), 0.004
-        trace = oracle.emd_forward_ex(x1, x2, eps, 3000)[3]
-        handover = max(int(np.argmax(row <= 256)) for row in trace)
-        assert 0 < handover < 2000
-        iters = handover + 256
+        iters = handover + 70
     elif kind == "last_round_forced":
-        x1, x2, eps, iters = rand_clouds(67, 2, 2048, 3), rand_clouds(68, 2, 2048, 3), 0.0005, 700
+        x1, x2, eps, iters = rand_clouds(37, 2, 2048, 3), rand_clouds(38, 2, 2048, 3), 0.002, 400
         assert oracle.emd_forward_ex(x1, x2, eps, iters)[3][:, -1].min() > 0   # persons left for the forced round
     elif kind == "person_blob":
         x1 = (0.5 + 0.01 * rand_clouds(69, 2, 1024, 3)).astype(np.float32)
@@ -306,20 +261,58 @@ def test_emd_list_driven_tail_matches_oracle(oracle, emd_variant, kind, delta):
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
-def test_emd_headline_cloud_matches_oracle(oracle, emd_variant):
+def test_emd_second_kernel_really_runs(emd_split):
+    """The statistics words say how many rounds ran in total; with the split on, a long auction
+    must have been handed over (hand-over record: next round > 0), with it off not."""
+    from mvp_benchmark_amd import _lib
+    b, n = 2, 4096
+    x1, x2 = dev(rand_clouds(81, b, n, 3)), dev(rand_clouds(82, b, n, 3))
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    out = {}
+    for split in (0, 1):
+        emd_split(split)
+        scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        dist = torch.zeros(b, n, device=DEV)
+        ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+        _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
+        torch.cuda.synchronize()
+        stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()
+        # hand-over records: b records of 16 ints right before the statistics
+        rec = scratch[nbytes - b * 16 - b * 64: nbytes - b * 16].view(torch.int32).view(b, 16).cpu().numpy()
+        out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), stats, rec)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])          # same rounds, same bids
+    assert (out[0][3][:, 0] == 0).all()                           # split off: nothing handed over
+    assert (out[1][3][:, 0] > 0).all() and (out[1][3][:, 0] < 1500).all()   # split on: round of the hand-over
+    assert (out[1][3][:, 1] <= 384).all()
+
+
+def test_emd_headline_cloud_matches_oracle(oracle, emd_split):
     """Two cloud pairs of the headline shape (16384 points, eps 0.004, 3000
-    rounds) against the exhaustive oracle, bit for bit -- with the clustered
-    kernel alone, with the hand-over to the tail kernel (round ~150 onwards) and
-    with the hand-over to the list-driven kernel.
+    rounds) against the exhaustive oracle, bit for bit -- with the split into two
+    kernels (hand-over around round 100) and with the first kernel alone.
     (~70 s of CPU per cloud, once.)"""
     from mvp_benchmark_amd.metrics import emd
     x1, x2 = rand_clouds(41, 2, 16384, 3), rand_clouds(42, 2, 16384, 3)
     od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
-    for tail in (0, 1, 2):
-        emd_variant(tail, 3.0)
+    for split in (1, 0):
+        emd_split(split)
         dist, ass = emd()(dev(x1), dev(x2), 0.004, 3000)
         np.testing.assert_array_equal(ass.cpu().numpy(), oa)
         np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
+def test_emd_cfg4_full_batch_matches_oracle(oracle):
+    """BASELINE cfg 4 at its FULL batch: 64 clouds of 1024 points, eval setting (eps 0.004,
+    3000 rounds), every cloud against the oracle (cfg 4 was only ever compared at
+    B <= 3 below the headline size).  64 clouds -> four workgroups per cloud."""
+    from mvp_benchmark_amd.metrics import emd
+    x1, x2 = rand_clouds(91, 64, 1024, 3), rand_clouds(92, 64, 1024, 3)
+    dist, ass = emd()(dev(x1), dev(x2), 0.004, 3000)
+    od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
+    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
 def test_emd_cluster_widths_agree_at_full_size(cluster_width):

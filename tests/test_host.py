@@ -24,24 +24,16 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.mvp_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MVP_ABI_VERSION (\d+)", header).group(1))
-    # per cloud: state 132 B/pt + bound broadcast buffers + cell offsets + candidate caches 128 B/pt
-    # (n <= 16384 only) + barrier granules, hand-over record, statistics
-    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * (132 + 128) + 8 * 2048 * 8 + 1732 * 4 + 512 + 1056 + 16)
-    assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 512 + 1056 + 16)
-    # the list-driven tail kernel (opt-in) adds 1344 cell records + the persons by cell + 6208 B per person,
-    # for auctions of >= 512 rounds on clouds of <= 16384 points; the knob is process-wide: restore it
-    base = lib.mvp_emd_scratch_bytes(3, 4096)
-    assert lib.mvp_emd_scratch_bytes_iters(3, 4096, 50) == base
+    # per cloud: state 132 B/pt + bound broadcast buffers + cell offsets + barrier granules (2 x 256 B),
+    # hand-over record (64 B), statistics (16 B)
+    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * 132 + 8 * 2048 * 8 + 1732 * 4 + 512 + 64 + 16)
+    assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 512 + 64 + 16)
+    # the knobs are process-wide: restore what is touched
     try:
-        assert lib.mvp_emd_configure(-1, -1, 2, -1.0, -1) == 0
-        lists = 3 * (1344 * 16 + 1344 * 2 + 16384 * 2 + 4096 * (64 + 1024 * 6))
-        assert lib.mvp_emd_scratch_bytes(3, 4096) == base + lists
-        assert lib.mvp_emd_scratch_bytes_iters(3, 4096, 3000) == base + lists
-        assert lib.mvp_emd_scratch_bytes_iters(3, 4096, 50) == base            # too short to amortise the build
-        assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 512 + 1056 + 16)
-        assert lib.mvp_emd_configure(-1, -1, 3, -1.0, -1) == -2               # MVP_EBADARG
+        assert lib.mvp_emd_configure(-1, -1, 0) == 0
+        assert lib.mvp_emd_configure(3, -1, -1) == -2               # MVP_EBADARG: cluster width
     finally:
-        assert lib.mvp_emd_configure(-1, -1, _lib.EMD_DEFAULT_TAIL, -1.0, -1) == 0
+        assert lib.mvp_emd_configure(0, -1, _lib.EMD_DEFAULT_SPLIT) == 0
 
 
 def test_argument_guards_need_no_gpu():
