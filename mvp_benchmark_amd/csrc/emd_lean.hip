@@ -136,6 +136,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   // this round's bids, by list position
   __shared__ int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
   __shared__ float s_binc[kLeanBid];
+  __shared__ int s_own_chg[kLeanBid];   // cells whose cheapest member this workgroup's winners made dearer this round
   // person records {qx,qy,qz,-} / {j, prev1, prev2, -} of the current / next unassigned list
   __shared__ float4 s_rq[2][kRecCap];
   __shared__ int4 s_ri[2][kRecCap];
@@ -223,8 +224,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   int Utot = resume->utot;  // unassigned persons of the whole cloud
   long long n_rounds = 0, n_bids = 0;
   bool aborted = false;
-  u64 chg_pend = 0ull;    // a bound broadcast by another workgroup, not yet folded in
-  bool chg_have = false;
   // Once at most kSoloMax persons are left (their number never grows) one
   // workgroup bids for all of them in a single pass and the cluster's barriers
   // would only add latency: member 0 adopts the others' lists and carries on
@@ -280,43 +279,70 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
       const long long tb0 = __builtin_readcyclecounter();
       int prof_cells = 0;
 #endif
-      const int c0 = emd_cell(gg, qx, qy, qz);
+      // grid coordinates of the bidder (emd_cell's arithmetic) and its home cell
+      const float fx = (qx - gg.lox) * gg.invh, fy = (qy - gg.loy) * gg.invh, fz = (qz - gg.loz) * gg.invh;
+      const int cix = min(gg.g - 1, max(0, (int)fx)), ciy = min(gg.g - 1, max(0, (int)fy)), ciz = min(gg.g - 1, max(0, (int)fz));
+      const int c0 = (ciz * gg.g + ciy) * gg.g + cix;
 
       // (1) seed: second-largest exact value among DISTINCT real objects --
       // the home cell's members plus the previous best / second best when
       // they live elsewhere.  Two real objects reach it, so it is a valid
       // lower bound of the final second-best value.
       BidState st;
+      st.b1 = -1e9f;
+      st.b2 = -1e9f;
+      st.bk = -1;
+      st.b2k = -1;
+      const int s0 = c_start[c0], s1 = c_start[c0 + 1];
+      // One pass, one value per lane: lanes 0.. take the home cell's members, lanes 62 / 63 the
+      // previous best / second best when they live in another cell (the slots are cell-sorted:
+      // outside [s0, s1)).  p1 != p2 (distinct objects of the last search) or -1.
+      int seed_slot = s0 + lane;
+      bool seed_valid = seed_slot < s1;
+      if (lane >= kWave - 2) {
+        seed_slot = lane == kWave - 2 ? p1 : p2;
+        seed_valid = seed_slot >= 0 && (seed_slot < s0 || seed_slot >= s1);
+      }
+      // (issued unconditionally: straight-line code up to the reduction)
+      const float4 o_seed = ld_obj(seed_valid ? seed_slot : 0);
       {
-        float a1 = -1e9f, a2 = -1e9f;
-        const int s0 = c_start[c0], s1 = c_start[c0 + 1];
-        // (the hint objects' load is issued first: it shares the round trip of the home cell's)
-        const bool hint = (lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0);
-        float4 oh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (hint) oh = ld_obj(lane == 0 ? p1 : p2);
-        for (int s = s0 + lane; s < s1; s += kWave) {
-          const float4 o = ld_obj(s);
-          top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
-        }
-        bool extra = false;
-        if (hint) {
-          const float4 o = oh;
-          if (emd_cell(gg, o.x, o.y, o.z) != c0) {
-            extra = true;
+        float seed_b2;
+        if (__builtin_expect(s1 - s0 <= kWave - 2, 1)) {
+          const bool valid = seed_valid;
+          float v = -__builtin_inff();
+          if (valid) v = emd_value(sqdist3(o_seed.x - qx, o_seed.y - qy, o_seed.z - qz), o_seed.w);
+          if (__builtin_expect(__builtin_popcountll(__ballot(valid)) < 2, 0)) {  // rare: the first 64 slots instead
+            const float4 o = ld_obj(lane);
+            v = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
+          }
+          seed_b2 = wave_second_largest(v, -1e9f);
+        } else
+        {
+          float a1 = -1e9f, a2 = -1e9f;
+          // (the hint objects' load is issued first: it shares the round trip of the home cell's)
+          const bool hint = (lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0);
+          float4 oh = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (hint) oh = ld_obj(lane == 0 ? p1 : p2);
+          for (int s = s0 + lane; s < s1; s += kWave) {
+            const float4 o = ld_obj(s);
             top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
           }
+          bool extra = false;
+          if (hint) {
+            const float4 o = oh;
+            if (emd_cell(gg, o.x, o.y, o.z) != c0) {
+              extra = true;
+              top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
+            }
+          }
+          const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
+          if (__builtin_expect(have < 2, 0)) {  // wave-uniform; rare: fall back to the first 64 slots
+            const float4 o = ld_obj(lane);
+            a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
+            a2 = -1e9f;
+          }
+          seed_b2 = wave_second_largest(a1, a2);
         }
-        const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
-        if (__builtin_expect(have < 2, 0)) {  // wave-uniform; rare: fall back to the first 64 slots
-          const float4 o = ld_obj(lane);
-          a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
-          a2 = -1e9f;
-        }
-        st.b1 = -1e9f;
-        st.b2 = -1e9f;
-        st.bk = -1;
-        st.b2k = -1;
-        const float seed_b2 = wave_second_largest(a1, a2);
         st.tm = (3.0f - seed_b2) + kMargin;
       }
 #ifdef MVP_EMD_PROFILE
@@ -330,31 +356,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
       // grid 64 cells at a time and test each cell's exact bounding box and
       // price lower bound; (3) visit the survivors, 4 cells per step with 16
       // lanes each.
-      int ix0, iy0, iz0, nx, ny, nz;
-      {
-        const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
-        const float fx = (qx - gg.lox) * gg.invh;
-        const float fy = (qy - gg.loy) * gg.invh;
-        const float fz = (qz - gg.loz) * gg.invh;
-        const float gm = (float)(gg.g - 1);
-        ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
-        iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
-        iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
-        nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
-        ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
-        nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
-        ix0 = __builtin_amdgcn_readfirstlane(ix0);
-        iy0 = __builtin_amdgcn_readfirstlane(iy0);
-        iz0 = __builtin_amdgcn_readfirstlane(iz0);
-        nx = __builtin_amdgcn_readfirstlane(nx);
-        ny = __builtin_amdgcn_readfirstlane(ny);
-        nz = __builtin_amdgcn_readfirstlane(nz);
-      }
-      const int nxy = nx * ny;
-      const int nsub = nxy * nz;
-      // approximate reciprocals are enough: (i + 0.5) / m is >= 0.5/144 away
-      // from an integer, far above the 1 ulp error of v_rcp_f32
-      const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
       const int sub = lane >> 4, sl = lane & 15;
       unsigned short *wl = w_list[wave];
       int nlist = 0;
@@ -416,61 +417,87 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
         t_visit += __builtin_readcyclecounter() - tv0;
 #endif
       };
-      // When the search cube covers most of the grid (high prices everywhere,
-      // e.g. a clustered prediction against a spread target) the cell
-      // machinery only adds overhead: scan the cell-sorted objects linearly,
-      // 4 x 64 per step, with the same lossless filter.
-      const bool linear = 2 * nsub > ncell;
-      if (__builtin_expect(linear, 0)) {
-        for (int base = 0; base < n; base += 4 * kWave) {
-          float4 o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = ld_obj(base + r * kWave + lane);  // n % 1024 == 0
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
-            const float tq = st.tm - o[r].w;
-            const bool ps = tq >= 0.f && sd <= tq * tq;
-            const unsigned long long m = __ballot(ps);
-            if (m) emd_fold(st, m, emd_value(sd, o[r].w), base + r * kWave + lane, n, tpu, sc.perm);
+      int nsub = 0;          // cells tested
+      bool linear = false;
+      {
+        int ix0, iy0, iz0, nx, ny, nz;
+        {
+          const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
+          const float gm = (float)(gg.g - 1);
+          ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
+          iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
+          iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
+          nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
+          ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
+          nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
+          ix0 = __builtin_amdgcn_readfirstlane(ix0);
+          iy0 = __builtin_amdgcn_readfirstlane(iy0);
+          iz0 = __builtin_amdgcn_readfirstlane(iz0);
+          nx = __builtin_amdgcn_readfirstlane(nx);
+          ny = __builtin_amdgcn_readfirstlane(ny);
+          nz = __builtin_amdgcn_readfirstlane(nz);
+        }
+        const int nxy = nx * ny;
+        nsub = nxy * nz;
+        // approximate reciprocals are enough: (i + 0.5) / m is >= 0.5/144 away
+        // from an integer, far above the 1 ulp error of v_rcp_f32
+        const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
+        // When the search cube covers most of the grid (high prices everywhere,
+        // e.g. a clustered prediction against a spread target) the cell
+        // machinery only adds overhead: scan the cell-sorted objects linearly,
+        // 4 x 64 per step, with the same lossless filter.
+        linear = 2 * nsub > ncell;
+        if (__builtin_expect(linear, 0)) {
+          for (int base = 0; base < n; base += 4 * kWave) {
+            float4 o[4];
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = ld_obj(base + r * kWave + lane);  // n % 1024 == 0
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
+              const float tq = st.tm - o[r].w;
+              const bool ps = tq >= 0.f && sd <= tq * tq;
+              const unsigned long long m = __ballot(ps);
+              if (m) emd_fold(st, m, emd_value(sd, o[r].w), base + r * kWave + lane, n, tpu, sc.perm);
+            }
           }
         }
-      }
-      for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
-        const int i = cb + lane;
-        bool cpass = false, big_cell = false;
-        int c = 0;
-        if (i < nsub) {
-          // exact small-integer division via float (i < 1728, divisors <= 144)
-          const int kz = (int)(((float)i + 0.5f) * inv_nxy);
-          const int rem = i - kz * nxy;
-          const int ky = (int)(((float)rem + 0.5f) * inv_nx);
-          const int kx = rem - ky * nx;
-          c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
-          const float4 cl = c_lo[c], ch = c_hi[c];
-          const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
-          const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
-          const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
-          const float tq = st.tm - cl.w;
-          cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
-          big_cell = ch.w != 0.f;
+        for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
+          const int i = cb + lane;
+          bool cpass = false, big_cell = false;
+          int c = 0;
+          if (i < nsub) {
+            // exact small-integer division via float (i < 1728, divisors <= 144)
+            const int kz = (int)(((float)i + 0.5f) * inv_nxy);
+            const int rem = i - kz * nxy;
+            const int ky = (int)(((float)rem + 0.5f) * inv_nx);
+            const int kx = rem - ky * nx;
+            c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
+            const float4 cl = c_lo[c], ch = c_hi[c];
+            const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
+            const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
+            const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
+            const float tq = st.tm - cl.w;
+            cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
+            big_cell = ch.w != 0.f;
+          }
+          // A cell with more than 16 members is listed twice: the second entry (bit 15) stands for
+          // members 16.. -- they travel in the same round trip as everything else of the visit step
+          // instead of in a second, dependent one (12 % of the cells, i.e. two of three bids).
+          const bool big = cpass && big_cell;
+          const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
+          if (cpass) {
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(bmask & lt);
+            wl[pos] = (unsigned short)c;
+            if (big) wl[pos + 1] = (unsigned short)(c | 0x8000);
+          }
+          nlist += __builtin_popcountll(cmask) + __builtin_popcountll(bmask);
+  #ifdef MVP_EMD_PROFILE
+          prof_cells += __builtin_popcountll(cmask);
+  #endif
+          if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells
         }
-        // A cell with more than 16 members is listed twice: the second entry (bit 15) stands for
-        // members 16.. -- they travel in the same round trip as everything else of the visit step
-        // instead of in a second, dependent one (12 % of the cells, i.e. two of three bids).
-        const bool big = cpass && big_cell;
-        const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
-        if (cpass) {
-          const unsigned long long lt = (1ull << lane) - 1ull;
-          const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(bmask & lt);
-          wl[pos] = (unsigned short)c;
-          if (big) wl[pos + 1] = (unsigned short)(c | 0x8000);
-        }
-        nlist += __builtin_popcountll(cmask) + __builtin_popcountll(bmask);
-#ifdef MVP_EMD_PROFILE
-        prof_cells += __builtin_popcountll(cmask);
-#endif
-        if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells
       }
       visit();
 #ifdef MVP_EMD_PROFILE
@@ -521,14 +548,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     }
     }
     alarm |= emd_band_alarm(pend_old, pend_inc);
-    if constexpr (W > 1) {
-      if (chg_have) {
-        const int pmb = (int)(unsigned)chg_pend;
-        if (pmb >= 0)  // bits of a non-negative float order like ints
-          atomicMax(reinterpret_cast<int *>(&c_lo[(int)(chg_pend >> 32)].w), pmb);
-        chg_have = false;
-      }
-    }
     int *my_alarm = &s_alarm[it & 1];
     if (alarm) *my_alarm = 1;
     if (t == 0) s_cnt[cur ^ 1] = 0;
@@ -593,6 +612,15 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     // paths with their own memory round trips, which a single wave would run
     // one after the other.  (Many bidders: consecutive lanes, conflict-free LDS.)
     const bool spread = U <= 4 * kEmdWaves * 4;
+    // next round's list (position, or -1: no room -- cannot happen, the lists never outgrow the hand-over's)
+    auto append = [&]() {
+      const int pos = atomicAdd(&s_cnt[nxt], 1);
+      if (__builtin_expect(pos >= kRecCap, 0)) {
+        s_err = 1;
+        return -1;
+      }
+      return pos;
+    };
     for (int ub = 0; ub < U; ub += kEmdThreads) {
       const int u = ub + (spread ? lane * kEmdWaves + wave : t);
       if (u >= U) continue;
@@ -615,9 +643,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
         if (!last && prev != -1) {
           // the evicted owner bids again next round, in this workgroup's list
           st_i32(&ass[prev], -1);
-          const int pos = atomicAdd(&s_cnt[nxt], 1);
-          if (__builtin_expect(pos >= kRecCap, 0)) s_err = 1;   // cannot happen: the lists never outgrow the hand-over's
-          if (__builtin_expect(pos < kRecCap, 1)) {
+          const int pos = append();
+          if (__builtin_expect(pos >= 0, 1)) {
             const float4 pa = ld_person(prev, 0);
             const float4 pb = ld_person(prev, 1);
             s_rq[nxt][pos] = pa;
@@ -630,40 +657,24 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
         st_ostate(o, j);
         st_i32(&ass[j], o);
         st_f32(&sc.obj[o].w, oo.w + bi);
-        // The cell's price lower bound only needs a refresh when the object
-        // that just got dearer was (one of) the cheapest of its cell; then the
-        // members are re-scanned (prices read while other winners raise them
-        // are old or new -- either way a valid bound) and the new bound is
-        // broadcast to the other workgroups of the cluster.
+        // The cell's price lower bound only changes when the object that just got dearer was (one
+        // of) the cheapest of its cell (the bounds are exact at this point, see the re-scan after
+        // the closing barrier): report the cell; every member of the cluster re-scans the reported
+        // cells once all of this round's prices are in memory.
         const int c = emd_cell(gg, oo.x, oo.y, oo.z);
         if (oo.w <= c_lo[c].w) {
-          float pm = oo.w + bi;
-          const int e0 = c_start[c], e1 = c_start[c + 1];
-          // (the first 16 members in ONE round trip: 88 % of the cells have no more)
-          float pv[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) pv[k] = (e0 + k < e1 && e0 + k != o) ? ld_price(e0 + k) : __builtin_inff();
-#pragma unroll
-          for (int k = 0; k < 16; ++k) pm = __builtin_fminf(pm, pv[k]);
-          for (int s = e0 + 16; s < e1; ++s) pm = __builtin_fminf(pm, s == o ? pm : ld_price(s));
-          c_lo[c].w = pm;
-#ifdef MVP_EMD_PROFILE
-          if (it >= 100) atomicAdd(&s_hist2[0], 1ull << 40);  // refresh count in the high bits
-#endif
-          if (clustered) {
-            const int q = atomicAdd(&s_nchg, 1);
-            if (q < kChgCap) {
-              const u64 e = ((u64)(unsigned)c << 32) | (u64)__float_as_uint(pm);
-              if (same_xcd) __hip_atomic_store(my_chg + q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              else __hip_atomic_store(my_chg + q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+          const int q = atomicAdd(&s_nchg, 1);
+          if (q < kLeanBid) s_own_chg[q] = c;
+          if (clustered && q < kChgCap) {
+            const u64 e = (u64)(unsigned)c << 32;
+            if (same_xcd) __hip_atomic_store(my_chg + q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(my_chg + q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       } else {
         // lost: stays in the list, record carried over through LDS
-        const int pos = atomicAdd(&s_cnt[nxt], 1);
-        if (__builtin_expect(pos >= kRecCap, 0)) s_err = 1;
-        if (__builtin_expect(pos < kRecCap, 1)) {
+        const int pos = append();
+        if (__builtin_expect(pos >= 0, 1)) {
           s_rq[nxt][pos] = s_rq[cur][u];
           s_ri[nxt][pos] = make_int4(j, o, b2k, 0);
         }
@@ -743,7 +754,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
 #pragma unroll
         for (int w = 0; w < W; ++w) maxc = max(maxc, cntw[w]);
         const int even = (Utot + W - 1) / W;
-        const int cap = even > kRowModeMin ? (even + 63) / 64 * 64 : (even + 15) / 16 * 16;
+        const int cap = (even + 15) / 16 * 16;
         if (__builtin_expect(maxc > cap && it + 1 < iters, 0)) {
           const int base = Utot / W, rem = Utot % W;
           int exc[W], dfc[W], exoff = 0, dfoff = 0, my_exoff = 0, my_dfoff = 0;
@@ -793,58 +804,60 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
       const long long tpb = __builtin_readcyclecounter();
       prof_pg1 += tpb - tpg2;
 #endif
-      if (!clustered) {
-        // (just collapsed: nothing to fetch)
-      } else if (__builtin_expect(overflow, 0)) {
-        // too many refreshes to broadcast (the first, heavy rounds): recompute
-        // every bound from the prices themselves (stable between barriers)
-        for (int c = t; c < ncell; c += kEmdThreads) {
-          float pm = __builtin_inff();
-          for (int s = c_start[c]; s < c_start[c + 1]; ++s) pm = __builtin_fminf(pm, ld_obj(s).w);
-          if (pm >= c_lo[c].w) c_lo[c].w = pm;
-        }
-      } else {
-        // Fetch the other workgroups' refreshed bounds now, fold them in after
-        // this workgroup's next bids (a bound that arrives a round late is
-        // still a bound): the load latency hides behind the Bid phase.  The
-        // producer rewrites its buffer only after the next gather, which this
-        // workgroup enters after consuming the value.
-        int idx = t, total = 0;
-        bool over = false;   // more entries than threads: take them synchronously
+      {
+        // Exact price bounds: every cell a winner of the cluster reported is re-scanned by every
+        // member, from the prices in memory (all of this round's stores were drained before the
+        // barrier opened).  The highest waves take the entries: they start bidding a little later,
+        // the searches that run meanwhile may still see the old (lower, valid) bound.
+        const int own_cnt = min(chgw[wg], kLeanBid);
+        int idx = kEmdThreads - 1 - t, total = own_cnt;
+        int cell = idx < own_cnt ? s_own_chg[idx] : -1;
+        idx -= own_cnt;
+        // (also in the round the cluster collapses to member 0: the others' last reports count)
 #pragma unroll
         for (int w = 0; w < W; ++w) {
           if (w == wg) continue;
-          const int cnt = chgw[w];
-          if (!chg_have && idx >= 0 && idx < cnt) {
-            chg_pend = __hip_atomic_load(sc.chg + (size_t)w * kChgCap + idx, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-            chg_have = true;
-          }
-          idx -= cnt;   // negative once this thread's entry has been found
+          const int cnt = min(chgw[w], kChgCap);
+          if (cell < 0 && idx >= 0 && idx < cnt)
+            cell = (int)(__hip_atomic_load(sc.chg + (size_t)w * kChgCap + idx, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT) >> 32);
+          idx -= cnt;
           total += cnt;
         }
-        over = total > kEmdThreads;
-        if (__builtin_expect(over, 0)) {
-#pragma unroll
-          for (int w = 0; w < W; ++w) {
-            if (w == wg) continue;
-            const int cnt = chgw[w];
-            const u64 *src = sc.chg + (size_t)w * kChgCap;
-            for (int i = t; i < cnt; i += kEmdThreads) {
-              const u64 e = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              const int pmb = (int)(unsigned)e;
-              if (pmb >= 0)  // bits of a non-negative float order like ints
-                atomicMax(reinterpret_cast<int *>(&c_lo[(int)(e >> 32)].w), pmb);
-            }
+        if (__builtin_expect(overflow || total > kEmdThreads || chgw[wg] > kLeanBid, 0)) {
+          // (cannot happen with <= kLeanCap bidders per cloud) recompute every bound
+          for (int c = t; c < ncell; c += kEmdThreads) {
+            float pm = __builtin_inff();
+            for (int s2 = c_start[c]; s2 < c_start[c + 1]; ++s2) pm = __builtin_fminf(pm, ld_price(s2));
+            if (c_start[c + 1] > c_start[c]) c_lo[c].w = pm;
           }
-          chg_have = false;
-          __syncthreads();
+        } else if (cell >= 0) {
+          const int e0 = c_start[cell], e1 = c_start[cell + 1];
+          float pv[16], pm = __builtin_inff();
+#pragma unroll
+          for (int k = 0; k < 16; ++k) pv[k] = e0 + k < e1 ? ld_price(e0 + k) : __builtin_inff();
+#pragma unroll
+          for (int k = 0; k < 16; ++k) pm = __builtin_fminf(pm, pv[k]);
+          for (int s2 = e0 + 16; s2 < e1; ++s2) pm = __builtin_fminf(pm, ld_price(s2));
+          c_lo[cell].w = pm;
         }
       }
       if (t == 0) s_nchg = 0;
     } else {
       __syncthreads();
       Utot = s_cnt[nxt];
+      {
+        const int own_cnt = min(s_nchg, kLeanBid);
+        __syncthreads();
+        if (t == 0) s_nchg = 0;
+        const int idx = kEmdThreads - 1 - t;
+        if (idx < own_cnt) {
+          const int cell = s_own_chg[idx];
+          float pm = __builtin_inff();
+          for (int s2 = c_start[cell]; s2 < c_start[cell + 1]; ++s2) pm = __builtin_fminf(pm, ld_price(s2));
+          c_lo[cell].w = pm;
+        }
+      }
     }
 #ifdef MVP_EMD_PROFILE
     const long long tp4 = __builtin_readcyclecounter();
