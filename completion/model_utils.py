@@ -56,6 +56,15 @@ def calc_emd(output, gt, eps=0.005, iterations=50):
     return dist.sqrt().mean(1)
 
 
+def check_emd_status():
+    """Raise if any auction-EMD call made so far failed (abandoned cluster wait / internal check):
+    the status words travel to the host behind the kernels, this waits for them.  Called once at
+    the end of every validation / test pass (the reference has no counterpart: its kernels cannot
+    fail that way)."""
+    from mvp_benchmark_amd.metrics.EMD import emd_module
+    emd_module.check(block=True)
+
+
 # --------------------------------------------------------------------------
 # pure-PyTorch neighbourhood helpers (model_utils.py:242-272, 230-239)
 # --------------------------------------------------------------------------

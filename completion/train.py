@@ -29,6 +29,7 @@ import torch.optim as optim
 import yaml
 
 from dataset import build_dataset
+from model_utils import check_emd_status
 from train_utils import (AttrDict, AverageValueMeter, get_rank, get_world_size, init_distributed,
                          load_model, save_model, shard_indices, unwrap)
 
@@ -84,18 +85,28 @@ def make_loader(dataset, args, rank, world, shuffle, epoch=0, seed=0):
     return loader, valid
 
 
-def wrap_ddp(net, device, world):
+def _needs_unused_parameter_walk(net, args):
+    """True when the configuration leaves parameters without a gradient (DDP must then be told).
+    cfgs/vrcnet.yaml has num_fps == num_coarse == num_points, so MSAP_SKN_decoder never runs
+    conv_s1..3 / expansion2 / conv_f1..2; pcn and ecg use every parameter in every step.
+    `ddp_find_unused_parameters: True|False` in the cfg overrides the rule."""
+    forced = args.get("ddp_find_unused_parameters") if args is not None else None
+    if forced is not None:
+        return bool(forced)
+    return args is None or str(args.get("model_name") or "") not in ("pcn", "ecg")
+
+
+def wrap_ddp(net, device, world, args=None):
     """DistributedDataParallel around `net` when world > 1.
 
-    find_unused_parameters=True: the shipped cfgs leave whole branches without a
-    gradient (cfgs/vrcnet.yaml has num_fps == num_coarse == num_points, so
-    MSAP_SKN_decoder never runs conv_s1..3 / expansion2 / conv_f1..2); the
-    reference's nn.DataParallel (train.py:49) tolerates that, a plain DDP raises
-    "Expected to have finished reduction in the prior iteration" in the second
-    step.  The per-step graph walk costs well under a millisecond here."""
+    find_unused_parameters only where a configuration leaves whole branches without a gradient
+    (see above; unknown models: on): the reference's nn.DataParallel (train.py:49) tolerates
+    that, a plain DDP raises "Expected to have finished reduction in the prior iteration" in the
+    second step; for models that use every parameter the per-step graph walk is skipped."""
     if world > 1:
         ids = [device.index] if device.type == "cuda" else None
-        net = torch.nn.parallel.DistributedDataParallel(net, device_ids=ids, find_unused_parameters=True)
+        net = torch.nn.parallel.DistributedDataParallel(net, device_ids=ids,
+                                                        find_unused_parameters=_needs_unused_parameter_walk(net, args))
     return net
 
 
@@ -119,7 +130,7 @@ def build_model(args, device, world):
     net = model_module.Model(args).to(device)
     if hasattr(model_module, 'weights_init'):
         net.apply(model_module.weights_init)
-    return wrap_ddp(net, device, world)
+    return wrap_ddp(net, device, world, args)
 
 
 def train_one_epoch(net, optimizer, loader, device, alpha, meter, log_fn=None, scale=1.0):
@@ -165,6 +176,7 @@ def val(net, curr_epoch_num, val_loss_meters, loader, valid, best_epoch_losses, 
                 r = result_dict[k]
                 r = r[keep.to(r.device)] if torch.is_tensor(r) and r.dim() > 0 else r
                 v.update(float(r.mean()) if torch.is_tensor(r) else float(r), n_keep)
+    check_emd_status()      # a failed auction launch is an exception here, not a NaN in the log
     for v in val_loss_meters.values():
         v.all_reduce(device)
 
@@ -191,6 +203,11 @@ def train(args, log_dir, exp_name):
     rank, world, device = init_distributed()
     scale = loss_scale(args, world)
     logging.info(str(args))
+    # the multi-GPU gradient convention, once, where it can be found again (train.log)
+    logging.info('ranks: %d, loss scale before backward: %g (ddp_grad_scale: %s -> gradient = %s), '
+                 'DDP find_unused_parameters: %s', world, scale, args.get("ddp_grad_scale") or "sum",
+                 "sum over ranks of the per-rank mean loss, as the reference's DataParallel" if scale != 1.0 or world == 1
+                 else "global-batch mean", _needs_unused_parameter_walk(None, args) if world > 1 else "n/a (one rank)")
     metrics = ['cd_p', 'cd_t', 'emd', 'f1'] if args.eval_emd else ['cd_p', 'cd_t', 'f1']
     best_epoch_losses = {m: (0, 0) if m == 'f1' else (0, math.inf) for m in metrics}
     train_loss_meter = AverageValueMeter()

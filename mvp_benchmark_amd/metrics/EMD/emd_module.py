@@ -13,11 +13,15 @@ buffer of mvp_emd_scratch_bytes(B, n) is enough and its initial contents do
 not matter.  Shape guards raise instead of printf + ignored return code.
 
 Failure contract: if the kernel abandons a cluster wait (never observed; needs
-the workgroups of one cloud not to be co-resident for tens of seconds) the
-cloud's `dist` is NaN and its `assignment` -1, so every metric derived from it
-is NaN instead of silently wrong; backward skips such entries (zero gradient).
-Set `emd_module.CHECK_STATUS = True` to have every forward read the per-cloud
-status words back (one host synchronisation) and raise MvpOpsError instead.
+the workgroups of one cloud not to be co-resident for tens of seconds) or trips
+an internal check, the cloud's status word is negative, its `dist` NaN and its
+`assignment` -1 (abandoned wait), so every metric derived from it is NaN instead
+of silently wrong; backward skips such entries (zero gradient).  The status
+words are ALWAYS checked, without a host synchronisation: every forward copies
+them to pinned host memory behind its kernels and the NEXT forward -- or an
+explicit `emd_module.check()` (blocking; the eval loop calls it once at the
+end) -- raises MvpOpsError for any call that failed (`LAZY_STATUS = False`
+switches that off).  `CHECK_STATUS = True` checks synchronously in the same call.
 """
 import torch
 from torch import nn
@@ -25,10 +29,63 @@ from torch.autograd import Function
 
 from ..._lib import MvpOpsError, call, emd_scratch_bytes
 
-# True: every forward reads the kernel's per-cloud status words back (a host
-# synchronisation) and raises MvpOpsError on an abandoned cloud.  Off by default:
-# the failure is visible anyway (NaN distances, see the module docstring).
+# True: every forward reads the kernel's per-cloud status words back at once (a host
+# synchronisation) and raises MvpOpsError on a failed cloud.
 CHECK_STATUS = False
+# True (default): the status words of every call are copied to pinned host memory
+# asynchronously and examined by the next forward / by check() -- a failure is loud
+# one call late, at no synchronisation cost.
+LAZY_STATUS = True
+_PENDING = []          # (event, pinned int64 rounds, description) of calls not examined yet
+_PINNED_POOL = []      # recycled pinned buffers
+
+
+def _examine(rounds, what):
+    bad = rounds[rounds < 0]
+    if bad.numel():
+        raise MvpOpsError("mvp_emd_forward failed for %d cloud(s) of an earlier call (%s): status %s"
+                          % (bad.numel(), what, bad.tolist()))
+
+
+def check(block=True):
+    """Examine the status words of the EMD calls made so far (block=True: wait for them)."""
+    keep = []
+    try:
+        while _PENDING:
+            ev, host, what = _PENDING.pop(0)
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((ev, host, what))
+                continue
+            try:
+                _examine(host, what)
+            finally:
+                if len(_PINNED_POOL) < 8:
+                    _PINNED_POOL.append(host)
+    finally:
+        _PENDING[:0] = keep
+
+
+def _file_status(scratch, nbytes, batchsize, n, eps, iters):
+    if torch.cuda.is_current_stream_capturing():
+        return              # (a captured graph replays the launch, not this bookkeeping)
+    rounds = scratch[nbytes - batchsize * 16:].view(torch.int64).view(batchsize, 2)[:, 0]
+    host = None
+    for i, h in enumerate(_PINNED_POOL):
+        if h.numel() == batchsize:
+            host = _PINNED_POOL.pop(i)
+            break
+    if host is None:
+        host = torch.empty(batchsize, dtype=torch.int64, pin_memory=True)
+    host.copy_(rounds, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _PENDING.append((ev, host, "b=%d n=%d eps=%g iters=%d" % (batchsize, n, eps, iters)))
+    if len(_PENDING) > 64:      # bounded: a loop that never reaches check() still examines the old ones
+        check(block=False)
+        if len(_PENDING) > 64:
+            check(block=True)
 
 
 class emdFunction(Function):
@@ -47,6 +104,8 @@ class emdFunction(Function):
         xyz1 = xyz1.contiguous().float()
         xyz2 = xyz2.contiguous().float()
         device = xyz1.device
+        if LAZY_STATUS and _PENDING:
+            check(block=False)
         dist = torch.zeros(batchsize, n, device=device)
         assignment = torch.zeros(batchsize, n, device=device,
                                  dtype=torch.int32) - 1
@@ -61,6 +120,8 @@ class emdFunction(Function):
             if bool((rounds < 0).any()):
                 raise MvpOpsError("mvp_emd_forward abandoned %d cloud(s) (status %s)"
                                   % (int((rounds < 0).sum()), rounds[rounds < 0].tolist()))
+        elif LAZY_STATUS:
+            _file_status(scratch, nbytes, batchsize, n, eps, iters)
 
         ctx.save_for_backward(xyz1, xyz2, assignment)
         ctx.mark_non_differentiable(assignment)

@@ -50,14 +50,18 @@ def _wgrad_scratch(device, nbytes):
     return buf
 
 
-def _mfma_fwd(x, cin, cout):
+def _mfma_fwd(x, cin, cout, weight=None):
     """Forward GEMM through mvp_pointwise_mfma?"""
-    return cin <= MFMA_FWD_MAX_CIN and _mfma_ok(x, cin, cout)
+    return cin <= MFMA_FWD_MAX_CIN and _mfma_ok(x, cin, cout, weight)
 
 
-def _mfma_ok(x, cin, cout):
-    """Shape / layout covered by the MFMA kernels?"""
+def _mfma_ok(x, cin, cout, weight=None):
+    """Shape / layout covered by the MFMA kernels?  (`weight`: the kernels read it with 16-byte
+    loads -- a parameter that is a view at an odd offset of a flattened / bucketed storage falls
+    back to the library convolution instead of failing with MVP_EBADARG.)"""
     if not (USE_MFMA and x.is_cuda and x.dtype == torch.float32 and x.dim() in (3, 4) and x.is_contiguous()):
+        return False
+    if weight is not None and (weight.data_ptr() % 16 != 0 or not weight.is_contiguous()):
         return False
     length = x[0, 0].numel() if x.numel() else 0
     return cin >= MFMA_MIN_CH and cout >= MFMA_MIN_CH and length > 0 and length % 4 == 0 and x.size(0) <= 65535 \
@@ -116,7 +120,7 @@ class _PointwiseConv(Function):
         cout, cin = weight.shape[:2]
         ctx.has_bias = bias is not None
         ctx.relu = relu
-        if _mfma_fwd(x, cin, cout):
+        if _mfma_fwd(x, cin, cout, weight):
             y = mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
         else:
             y = conv(x, weight, bias)
@@ -134,8 +138,8 @@ class _PointwiseConv(Function):
         need_x = ctx.needs_input_grad[0]
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        gx_mfma = MFMA_DGRAD and need_x and _mfma_ok(gy, cout, cin) and cin % 4 == 0
-        gw_mfma = (need_w or need_b) and cin >= MFMA_WGRAD_MIN_CIN and _mfma_ok(x, cin, cout) and not _covered(x, weight) \
+        gx_mfma = MFMA_DGRAD and need_x and _mfma_ok(gy, cout, cin, weight) and cin % 4 == 0
+        gw_mfma = (need_w or need_b) and cin >= MFMA_WGRAD_MIN_CIN and _mfma_ok(x, cin, cout, weight) and not _covered(x, weight) \
             and pointwise_wgrad_mfma_scratch_bytes(x.size(0), cin, cout, x[0, 0].numel(), ctx.has_bias) > 0
         # ReLU'(.): the MFMA kernels mask grad_out by the saved output on load; the other routes get
         # the masked tensor
@@ -177,13 +181,13 @@ def pointwise_conv(x, weight, bias=None, relu=False):
     conv = F.conv1d if x.dim() == 3 else F.conv2d
     cout, cin = weight.shape[:2]
     routed = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() \
-        and weight.is_contiguous() and x.numel() > 0 and (_mfma_ok(x, cin, cout) or _covered(x, weight))
+        and weight.is_contiguous() and x.numel() > 0 and (_mfma_ok(x, cin, cout, weight) or _covered(x, weight))
     if routed and (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
         if MFMA_TRAIN or _covered(x, weight):
             return _PointwiseConv.apply(x, weight, bias, relu)
         y = conv(x, weight, bias)
         return torch.relu(y) if relu else y
-    if routed and _mfma_fwd(x, cin, cout):                         # inference
+    if routed and _mfma_fwd(x, cin, cout, weight):                 # inference
         return mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
     y = conv(x, weight, bias)
     return torch.relu(y) if relu else y

@@ -61,7 +61,10 @@ class MultiHeadedAttention(nn.Module):
         super().__init__()
         assert d_model % heads == 0
         self.h, self.d_k = heads, d_model // heads
-        self.linears = nn.ModuleList([nn.Linear(d_model, d_model) for _ in range(4)])
+        # the reference builds `clones(nn.Linear(d_model, d_model), 4)` (dcp.py:52-54,167): four deep copies
+        # of ONE layer, so the four projections of a block start from identical weights
+        proto = nn.Linear(d_model, d_model)
+        self.linears = nn.ModuleList([copy.deepcopy(proto) for _ in range(4)])
 
     def forward(self, query, memory):
         b = query.size(0)

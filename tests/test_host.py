@@ -173,3 +173,33 @@ def test_python_counterparts_match_reference_golden(chamfer_golden):
         cd_t = d1.mean(1) + d2.mean(1)
         np.testing.assert_array_equal(cd_p.numpy(), c["cd_p"])
         np.testing.assert_array_equal(cd_t.numpy(), c["cd_t"])
+
+
+def test_emd_lazy_status_check_raises_one_call_late():
+    """emd_module files every call's status words (async copy to pinned memory) and examines them
+    at the next forward / at check(): a negative word (abandoned cluster wait, internal check) is
+    an MvpOpsError, never a silent NaN.  Exercised here with hand-made pending entries."""
+    import torch
+    from mvp_benchmark_amd import _lib
+    from mvp_benchmark_amd.metrics.EMD import emd_module
+
+    class Done:
+        def query(self):
+            return True
+
+        def synchronize(self):
+            pass
+
+    class NotYet(Done):
+        def query(self):
+            return False
+
+    emd_module._PENDING.clear()
+    emd_module._PENDING.append((Done(), torch.tensor([3000, 3000]), "ok call"))
+    emd_module._PENDING.append((NotYet(), torch.tensor([3000, -2]), "failed call, still in flight"))
+    emd_module.check(block=False)                 # the finished one is fine, the other stays filed
+    assert len(emd_module._PENDING) == 1
+    with pytest.raises(_lib.MvpOpsError, match="failed call"):
+        emd_module.check(block=True)
+    assert not emd_module._PENDING
+    emd_module.check()                            # nothing pending: no-op
