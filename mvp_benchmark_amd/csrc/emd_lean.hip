@@ -16,7 +16,7 @@
 
 namespace mvp {
 
-constexpr int kLeanBid = 512;   // list positions (= kRecCap): every bidder's record and bid live in LDS
+constexpr int kLeanBid = 512;
 
 template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
