@@ -22,6 +22,14 @@ from models.pcn import PCN_encoder
 from models.relational import SA_module, SA_SKN_Res_encoder, SK_SA_module, SKN_Res_unit  # noqa: F401
 
 
+def _normal_dist(loc, scale):
+    """torch.distributions.Normal WITHOUT argument validation: the default validation evaluates
+    `(scale > 0).all()` on the host -- four device->host synchronisations per training step (the
+    reference pays them, vrcnet.py:438-470), which also make the step impossible to capture into a
+    HIP graph.  softplus keeps the scale positive; same samples, same losses."""
+    return torch.distributions.Normal(loc, scale, validate_args=False)
+
+
 class Folding(nn.Module):
     """Local folding: every point feature is repeated step_ratio times and
     concatenated with the global feature and a small 2-D grid."""
@@ -204,12 +212,12 @@ class Model(nn.Module):
         return mu, F.softplus(std)
 
     def _posterior(self, feat):
-        return torch.distributions.Normal(*self._normal(self.posterior_infer2(self.posterior_infer1(feat))))
+        return _normal_dist(*self._normal(self.posterior_infer2(self.posterior_infer1(feat))))
 
     def _latent_loss(self, q, p):
         """20 x (reconstruction-path + completion-path) distribution loss of the training objective."""
-        p_fixed = torch.distributions.Normal(p.loc.detach(), p.scale.detach())
-        unit = torch.distributions.Normal(torch.zeros_like(p.loc), torch.ones_like(p.scale))
+        p_fixed = _normal_dist(p.loc.detach(), p.scale.detach())
+        unit = _normal_dist(torch.zeros_like(p.loc), torch.ones_like(p.scale))
         if self.distribution_loss == 'MMD':
             z_m, z_q = unit.rsample(), q.rsample()
             z_p, z_p_fix = p.rsample(), p_fixed.rsample()
@@ -230,7 +238,7 @@ class Model(nn.Module):
             y = gather_points(gt.transpose(1, 2).contiguous(), furthest_point_sample(gt, x.size(2)))
             feat_x, feat_y = self.encoder(torch.cat([x, y], dim=0)).chunk(2)
             q = self._posterior(feat_x)
-            p = torch.distributions.Normal(*self._normal(self.prior_infer(feat_y)))
+            p = _normal_dist(*self._normal(self.prior_infer(feat_y)))
             z = torch.cat([q.rsample(), p.rsample()], dim=0)
             feat = torch.cat([feat_x, feat_x], dim=0)
             x, gt = torch.cat([x, x], dim=0), torch.cat([gt, gt], dim=0)

@@ -133,13 +133,81 @@ def build_model(args, device, world):
     return wrap_ddp(net, device, world, args)
 
 
-def train_one_epoch(net, optimizer, loader, device, alpha, meter, log_fn=None, scale=1.0):
+class GraphedStep:
+    """The training step (forward, loss, backward, optimizer) captured into ONE HIP graph and
+    replayed per batch -- opt-in (`hip_graph: True` in the cfg), one rank, Adam / AdamW only
+    (built `capturable`, learning rate kept in a device tensor).  Inputs are copied into static
+    buffers, `alpha` lives in a device scalar; a batch of another shape (the last, short one) runs
+    eagerly.  The step itself is the one of train_one_epoch (train.py:122-142 of the reference).
+    Measured on one MI355X (profiles/r3_vrcnet_step_4cell.txt): VRCNet 32.7 ms eager / 32.6 ms
+    replayed, ECG 24.8 / 23.0 -- the step is GPU-bound, so this stays an option, not the default."""
+
+    def __init__(self, net, optimizer, device):
+        self.net, self.opt, self.device = net, optimizer, device
+        self.graph = None
+        self.shape = None
+        for group in optimizer.param_groups:       # tensor lr: changes between replays without a re-capture
+            if not torch.is_tensor(group['lr']):
+                group['lr'] = torch.tensor(float(group['lr']), device=device)
+
+    def set_lr(self, lr):
+        for group in self.opt.param_groups:
+            group['lr'].fill_(float(lr))
+
+    def _step(self):
+        self.opt.zero_grad(set_to_none=True)
+        out2, loss2, net_loss = self.net(self.inputs, self.gt, alpha=self.alpha)
+        net_loss = net_loss.mean()
+        net_loss.backward()
+        self.opt.step()
+        return loss2.mean(), net_loss
+
+    def _capture(self, inputs, gt, alpha):
+        self.inputs, self.gt = inputs.clone(), gt.clone()
+        self.alpha = torch.tensor(float(alpha), device=self.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # warm-up steps off the capturing stream (they DO train)
+            for _ in range(3):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.fine, self.total = self._step()
+        self.shape = (tuple(inputs.shape), tuple(gt.shape))
+
+    def __call__(self, inputs, gt, alpha):
+        """-> (mean fine loss, total loss) as device scalars of THIS batch's step."""
+        if self.graph is None:
+            self._capture(inputs, gt, alpha)       # (three eager warm-up steps on this batch, then the capture)
+        if (tuple(inputs.shape), tuple(gt.shape)) != self.shape:
+            self.opt.zero_grad(set_to_none=True)
+            out2, loss2, net_loss = self.net(inputs, gt, alpha=torch.tensor(float(alpha), device=self.device))
+            net_loss = net_loss.mean()
+            net_loss.backward()
+            self.opt.step()
+            return loss2.mean(), net_loss
+        self.inputs.copy_(inputs)
+        self.gt.copy_(gt)
+        self.alpha.fill_(float(alpha))
+        self.graph.replay()
+        return self.fine, self.total
+
+
+def train_one_epoch(net, optimizer, loader, device, alpha, meter, log_fn=None, scale=1.0, graphed=None):
     unwrap(net).train()
     for i, data in enumerate(loader):
-        optimizer.zero_grad()
         _, inputs, gt = data
         inputs = inputs.float().to(device).transpose(2, 1).contiguous()
         gt = gt.float().to(device)
+        if graphed is not None:
+            fine, net_loss = graphed(inputs, gt, alpha)
+            meter.update(net_loss.item())
+            if log_fn:
+                log_fn(i, fine.item(), net_loss.item())
+            continue
+        optimizer.zero_grad()
         out2, loss2, net_loss = net(inputs, gt, alpha=alpha)
         net_loss = net_loss.mean()
         # DDP all-reduces (averages) the gradients; `scale` = loss_scale() restores the
@@ -232,20 +300,31 @@ def train(args, log_dir, exp_name):
         optimizer = opt_cls(params, lr=lr, initial_accumulator_value=args.initial_accum_val)
     else:
         betas = tuple(_floats(args.betas))
-        optimizer = opt_cls(params, lr=lr, weight_decay=args.weight_decay, betas=betas)
+        extra = {}
+        if args.get("hip_graph"):
+            if world != 1 or args.optimizer not in ('Adam', 'AdamW') or device.type != "cuda":
+                raise ValueError("hip_graph: True needs one rank on a GPU and the Adam / AdamW optimizer")
+            extra = {"capturable": True}
+        optimizer = opt_cls(params, lr=lr, weight_decay=args.weight_decay, betas=betas, **extra)
 
     if args.load_model:
         load_model(args.load_model, net, map_location=device)
         logging.info("%s's previous weights loaded." % args.model_name)
 
     loader_test, valid_test = make_loader(dataset_test, args, rank, world, shuffle=False)
+    graphed = GraphedStep(net, optimizer, device) if args.get("hip_graph") else None
+    if graphed is not None:
+        logging.info('training step captured into one HIP graph (hip_graph: True)')
     last = None
     for epoch in range(args.start_epoch, args.nepoch):
         train_loss_meter.reset()
         alpha = alpha_for_epoch(args, epoch)
         lr = lr_for_epoch(args, epoch, lr)
-        for group in optimizer.param_groups:
-            group['lr'] = lr
+        if graphed is not None:
+            graphed.set_lr(lr)
+        else:
+            for group in optimizer.param_groups:
+                group['lr'] = lr
         loader, _ = make_loader(dataset, args, rank, world, shuffle=True, epoch=epoch, seed=seed)
 
         def log_fn(i, fine, total, _epoch=epoch, _lr=lr, _alpha=alpha):
@@ -254,7 +333,7 @@ def train(args, log_dir, exp_name):
                              % (_epoch, i, len(dataset) / args.batch_size, args.loss, fine, total, _lr)
                              + ' alpha: ' + str(_alpha))
 
-        train_one_epoch(net, optimizer, loader, device, alpha, train_loss_meter, log_fn, scale)
+        train_one_epoch(net, optimizer, loader, device, alpha, train_loss_meter, log_fn, scale, graphed)
 
         if epoch % args.epoch_interval_to_save == 0:
             save_model('%s/network.pth' % log_dir, net)

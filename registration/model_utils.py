@@ -41,10 +41,19 @@ def knn(x, k):
     return pairwise.topk(k=k, dim=-1)[1]
 
 
-def get_graph_feature(x, k=20):
+def get_graph_feature(x, k=20, k_major=False):
     """x (B,C,N) -> (B,2C,N,k) = [neighbour, centre] (dcp.py:45-66: the
-    neighbour itself, not its offset from the centre)."""
+    neighbour itself, not its offset from the centre).  k_major: (B,2C,k,N) instead -- for the
+    1x1 convolution stack of DGCNN the layout is free, and the max over the neighbours then
+    reduces a strided dimension with N contiguous instead of 20-element rows (PyTorch's reduce
+    kernel runs those at ~0.6 TB/s: 14.7 of 91 ms of the cfg-5 forward, profiles/r3_bench_dcp.txt)."""
     idx = knn(x, k)
+    if k_major:
+        if _on_op_layer(x):
+            nbr = grouping_operation(x.contiguous(), idx.int().transpose(1, 2).contiguous())   # (B,C,k,N)
+        else:
+            nbr = get_graph_feature(x, k)[:, :x.size(1)].permute(0, 1, 3, 2)
+        return torch.cat((nbr, x.unsqueeze(2).expand(-1, -1, k, -1)), dim=1)
     if _on_op_layer(x):
         nbr = grouping_operation(x.contiguous(), idx.int().contiguous())   # (B,C,N,k)
     else:

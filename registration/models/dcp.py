@@ -159,11 +159,13 @@ class DGCNN(nn.Module):
 
     def forward(self, x):
         batch_size, _, num_points = x.size()
-        edge = get_graph_feature(x)                       # (B, 6, N, 20): knn + grouping operators
+        # (B, 6, 20, N): knn + grouping operators; neighbours on the SLOW spatial axis (the stages are
+        # 1x1 convolutions + per-channel BatchNorm: layout-agnostic; the reference keeps (B, 6, N, 20))
+        edge = get_graph_feature(x, k_major=True)
         pooled = []
         for i in range(1, 5):
             edge = self._stage(i, edge)
-            pooled.append(edge.max(dim=-1, keepdim=True)[0])
+            pooled.append(edge.max(dim=2, keepdim=True)[0])           # (B, C, 1, N)
         return self._stage(5, torch.cat(pooled, dim=1)).view(batch_size, -1, num_points)
 
 

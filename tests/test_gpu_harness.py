@@ -254,6 +254,63 @@ def test_pcn_training_reduces_chamfer_loss():
     assert losses[-1] < 0.5 * losses[0]
 
 
+def test_graphed_training_step_matches_eager():
+    """train.GraphedStep (cfg key `hip_graph`): the step replayed from one HIP graph trains the
+    same network as the eager step -- PCN (no random numbers in its forward), same initial
+    weights, same batches, alpha and learning rate changed between replays: losses and weights
+    agree after six steps."""
+    import train
+    from models import pcn
+    args = _pcn_args("/tmp")
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.rand(4, 2048, 3, generator=g).to(DEV) * 0.5) for _ in range(3)]
+
+    def run(graphed):
+        torch.manual_seed(0)
+        net = pcn.Model(args).to(DEV).train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)     # same update arithmetic both ways
+        step = train.GraphedStep(net, opt, torch.device(DEV)) if graphed else None
+        losses = []
+        # (the captured variant takes three eager warm-up steps on its first batch: do the same here)
+        if not graphed:
+            gt = batches[0]
+            for _ in range(3):
+                opt.zero_grad()
+                _, _, loss = net(gt.transpose(2, 1).contiguous(), gt, alpha=0.5)
+                loss.mean().backward()
+                opt.step()
+        for it in range(6):
+            gt = batches[it % 3]
+            x = gt.transpose(2, 1).contiguous()
+            alpha = 0.5 if it < 3 else 1.0
+            lr = 1e-3 if it < 4 else 5e-4
+            if graphed:
+                step.set_lr(lr)
+                _, total = step(x, gt, alpha)
+                losses.append(float(total))
+            else:
+                for group in opt.param_groups:
+                    group['lr'] = torch.tensor(lr, device=DEV)
+                opt.zero_grad()
+                _, _, loss = net(x, gt, alpha=alpha)
+                loss.mean().backward()
+                opt.step()
+                losses.append(float(loss.mean()))
+        return losses, [p.detach().clone() for p in net.parameters()]
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    # (Adam's first steps move every weight by ~lr whatever the gradient's size, so the float-atomic
+    # noise of the Chamfer gradient is amplified: per-mille agreement is what identical steps give;
+    # a step that ignored the new alpha / learning rate would be off by tens of per cent)
+    np.testing.assert_allclose(lg, le, rtol=2e-2)
+    assert abs(lg[3] - lg[2]) > 5 * abs(lg[3] - le[3])        # the alpha change at step 3 is visible in both
+    # weights: on average far closer than the ~9e-3 nine Adam steps of lr 1e-3 can move one
+    # (single weights with a near-zero, noise-dominated gradient may go opposite ways)
+    num = sum(float((a - b).abs().sum()) for a, b in zip(pg, pe))
+    assert num / sum(a.numel() for a in pg) < 5e-4
+
+
 def test_pcn_eval_config2_shapes():
     """BASELINE config 2: PCN eval 2048 -> 16384 points, batch 32: CD + F1 on
     the network output, EMD (eval settings) between two spread 16384-point

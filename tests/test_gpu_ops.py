@@ -315,6 +315,28 @@ def test_emd_cfg4_full_batch_matches_oracle(oracle):
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("kind", ["random", "tie_heavy"])
+def test_emd_result_is_a_member_of_the_reference_outcome_set(kind):
+    """The HIP result against oracle/emulator.py -- a thread-by-thread replay of the reference's
+    seven kernels per round, written independently of mvp_oracle.c -- under the ascending thread
+    order (the legal schedule of the reference program that GetMax's race is pinned to): bit-equal,
+    i.e. the HIP result IS one of the outcomes the reference program can produce
+    (tests/test_emulator.py shows oracle == emulator and which launches are order-sensitive)."""
+    from oracle import emulator
+    from mvp_benchmark_amd.metrics import emd
+    if kind == "random":
+        x1, x2, eps, iters = rand_clouds(201, 2, 1024, 3), rand_clouds(202, 2, 1024, 3), 0.005, 50
+    else:
+        x1 = np.tile(rand_clouds(203, 1, 256, 3), (1, 4, 1))
+        x2, eps, iters = np.tile(rand_clouds(204, 1, 128, 3), (1, 8, 1)), 0.005, 60
+    dist, ass = emd()(dev(x1), dev(x2), eps, iters)
+    ed, ea, info = emulator.emd_forward(x1, x2, eps, iters, "ascending", return_info=True)
+    np.testing.assert_array_equal(ass.cpu().numpy(), ea)
+    np.testing.assert_array_equal(dist.cpu().numpy(), ed)
+    if kind == "tie_heavy":
+        assert info[0]["racy_getmax_launches"] > 0
+
+
 def test_emd_cluster_widths_agree_at_full_size(cluster_width):
     """16384 points, eval setting: 1 and 4 workgroups per cloud give identical
     assignments (the oracle needs minutes at this size)."""
@@ -494,6 +516,19 @@ def test_fps_sorted_variant_ties(oracle):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
         _lib.call("mvp_furthest_point_sampling_sorted", tx.device, b, n, m, tx, temp, idx, ws, nbytes)
         np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample(x, m))
+
+
+def test_fps_equals_the_grid_emulator():
+    """The HIP FPS against the thread-by-thread replay of furthest_point_sampling_kernel
+    (oracle/emulator.py: strided per-thread scan, shared-memory tree level by level) on a lattice
+    with ties in almost every round and on a random cloud whose size is not a power of two."""
+    from oracle import emulator
+    from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample
+    g = np.stack(np.meshgrid(*[np.arange(8, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) / 8
+    lattice = np.tile(g[None], (2, 3, 1)).astype(np.float32)            # (2, 1536, 3), every point three times
+    for x, m in ((lattice, 96), (rand_clouds(77, 2, 1500, 3), 128)):
+        got = furthest_point_sample(dev(x), m).cpu().numpy()
+        np.testing.assert_array_equal(got, emulator.furthest_point_sample(x, m, "ascending"))
 
 
 def test_fps_with_dist_matches_oracle(oracle):
