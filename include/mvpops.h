@@ -239,6 +239,21 @@ int mvp_three_interpolate_grad(int b, int c, int n, int m,
 int mvp_gather_points(int b, int c, int n, int npoints, const float *points,
                       const int *idx, float *out, void *stream);
 
+/* Gather + max over the k neighbours of every output point, fused (not an operator of the
+ * reference: it replaces the gather_points + torch.max pair of edge_preserve_sampling,
+ * completion/model_utils.py:101-104, without materialising the (b,c,npoints,k) neighbour tensor):
+ *   out[b,c,p] = max_j points[b,c, idx[b,p,j]],  arg[b,c,p] = idx[b,p,j*] for the FIRST maximal j.
+ * points (b,c,n), idx (b,npoints,k) int32 in [0,n), out (b,c,npoints), arg (b,c,npoints) int32.
+ * MVP_EBADSHAPE when a row of n floats does not fit the 96 KiB LDS staging buffer (n > 24576): the
+ * caller then gathers and reduces. */
+int mvp_gather_max(int b, int c, int n, int npoints, int k, const float *points,
+                   const int *idx, float *out, int *arg, void *stream);
+
+/* Its gradient: grad_points[b,c, arg[b,c,p]] += grad_out[b,c,p] (overwrite != 0: every element of
+ * grad_points is written, no zero fill by the caller). */
+int mvp_gather_max_grad(int b, int c, int n, int npoints, const float *grad_out,
+                        const int *arg, float *grad_points, int overwrite, void *stream);
+
 /* Replaces gather_points_ext.gather_points_grad_wrapper
  * (gather_points.cpp:40-52,57) -> gather_points_grad_kernel_launcher
  * (gather_points_cuda.cu:72-94).  grad_points (b,c,n) accumulated into; zero

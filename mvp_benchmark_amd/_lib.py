@@ -35,6 +35,8 @@ SIGNATURES = {
     "mvp_three_interpolate_grad": "iiiipppp",
     "mvp_gather_points": "iiiippp",
     "mvp_gather_points_grad": "iiiippp",
+    "mvp_gather_max": "iiiiipppp",
+    "mvp_gather_max_grad": "iiiipppi",
     "mvp_group_points": "iiiiippp",
     "mvp_group_points_grad": "iiiiippp",
     "mvp_gather_points_grad_ws": "iiiippppqi",

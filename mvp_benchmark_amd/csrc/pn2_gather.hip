@@ -404,6 +404,95 @@ __global__ __launch_bounds__(kScThreads) __attribute__((amdgpu_waves_per_eu(D ==
   }
 }
 
+// ---------------------------------------------------------------------------
+// Gather + max over the neighbours of a point, fused (widening row N2, the pooling half):
+//   out[b,c,p] = max_j points[b,c, idx[b,p,j]],   arg[b,c,p] = idx[b,p,j*], j* the FIRST maximal j
+// edge_preserve_sampling (completion/model_utils.py:88-110 of the reference) gathers the
+// (B, C, P, k) neighbour tensor and reduces it with torch.max: at VRCNet's first level that is
+// 0.8 GB written, read again, and the same twice more on the way back.  Here a workgroup stages
+// `ch` complete rows of one cloud in LDS (the feature tensor is read exactly once, as in
+// gather_lds_kernel), a thread owns one output point, reads its k indices once per strip and keeps
+// the running maxima of the strip's channels in registers: the neighbour tensor never exists.
+// The winner's SOURCE index is kept for the gradient, which then is a scatter of P values per row
+// (gather_max_grad_kernel) instead of a pass over P*k of them.
+constexpr int kGmChan = 16;   // rows per strip at most (register arrays)
+__global__ __launch_bounds__(kScThreads) void gather_max_lds_kernel(
+    int c, int n_src, int p_out, int k, int ch, const float *__restrict__ points,
+    const int *__restrict__ idx, float *__restrict__ out, int *__restrict__ arg) {
+  __shared__ float rows[kScFloats];
+  const int t = threadIdx.x;
+  const int cloud = blockIdx.y;
+  const int c0 = blockIdx.x * ch;
+  const int cn = min(ch, c - c0);
+  const float *src = points + ((size_t)cloud * c + c0) * n_src;  // rows c0.. are contiguous
+  for (int i = t; i < cn * n_src; i += kScThreads) rows[i] = src[i];
+  __syncthreads();
+  float *dst = out + ((size_t)cloud * c + c0) * p_out;
+  int *adst = arg + ((size_t)cloud * c + c0) * p_out;
+  const int *id = idx + (size_t)cloud * p_out * k;
+  for (int p = t; p < p_out; p += kScThreads) {
+    float best[kGmChan];
+    int bi[kGmChan];
+#pragma unroll
+    for (int q = 0; q < kGmChan; ++q) {
+      best[q] = -__builtin_inff();
+      bi[q] = 0;
+    }
+    for (int j = 0; j < k; ++j) {
+      const int s = id[(size_t)p * k + j];
+      if (j == 0) {
+#pragma unroll
+        for (int q = 0; q < kGmChan; ++q) bi[q] = s;   // a row of -inf / NaN keeps the first neighbour
+      }
+#pragma unroll
+      for (int q = 0; q < kGmChan; ++q) {
+        if (q < cn) {
+          const float v = rows[q * n_src + s];
+          const bool gt = v > best[q];              // strict: the first maximum wins (torch.max's rule)
+          best[q] = gt ? v : best[q];
+          bi[q] = gt ? s : bi[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kGmChan; ++q) {
+      if (q < cn) {
+        dst[(size_t)q * p_out + p] = best[q];
+        adst[(size_t)q * p_out + p] = bi[q];
+      }
+    }
+  }
+}
+
+// grad_points[b,c, arg[b,c,p]] += grad_out[b,c,p]: one workgroup owns `ch` rows of one cloud and
+// accumulates them in LDS (ds_add_f32: several output points may share a winner), then writes
+// (OVERWRITE) or adds the finished rows with coalesced stores.
+template <bool OVERWRITE>
+__global__ __launch_bounds__(kScThreads) void gather_max_grad_kernel(
+    int c, int n_dst, int p_src, int ch, const float *__restrict__ grad_out, const int *__restrict__ arg,
+    float *__restrict__ grad_points) {
+  __shared__ float acc[kScFloats];
+  const int t = threadIdx.x;
+  const int cloud = blockIdx.y;
+  const int c0 = blockIdx.x * ch;
+  const int cn = min(ch, c - c0);
+  for (int i = t; i < cn * n_dst; i += kScThreads) acc[i] = 0.f;
+  __syncthreads();
+  const float *src = grad_out + ((size_t)cloud * c + c0) * p_src;
+  const int *asrc = arg + ((size_t)cloud * c + c0) * p_src;
+  for (int i = t; i < cn * p_src; i += kScThreads) {   // (row q, point p) = (i / p_src, i % p_src): coalesced
+    const int q = i / p_src;
+    const int j = asrc[i];
+    if ((unsigned)j < (unsigned)n_dst) atomicAdd(&acc[q * n_dst + j], src[i]);
+  }
+  __syncthreads();
+  float *dst = grad_points + ((size_t)cloud * c + c0) * n_dst;
+  for (int i = t; i < cn * n_dst; i += kScThreads) {
+    if constexpr (OVERWRITE) dst[i] = acc[i];
+    else dst[i] += acc[i];
+  }
+}
+
 static long long transposed_scratch_bytes(int b, int n_dst, int m_src, int r) {
   if (b <= 0 || b > 65535 || n_dst <= 0 || m_src <= 0 || (r != 1 && r != 3)) return 0;
   if (n_dst > kTrMaxDst) return 0;
@@ -617,4 +706,38 @@ extern "C" int mvp_three_interpolate_grad_ws(int b, int c, int n, int m, const f
   if (!grad_out || !idx || !weight || !grad_points) return MVP_EBADARG;
   transposed_scatter<true>(b, c, m, n, grad_out, idx, weight, grad_points, scratch, mode, as_stream(stream));
   return check_launch("mvp_three_interpolate_grad_ws");
+}
+
+extern "C" int mvp_gather_max(int b, int c, int n, int npoints, int k, const float *points, const int *idx,
+                              float *out, int *arg, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || k <= 0) return MVP_EBADSHAPE;
+  if (b == 0 || c == 0 || npoints == 0) return MVP_OK;
+  if (n == 0 || b > 65535) return MVP_EBADSHAPE;
+  if (!points || !idx || !out || !arg) return MVP_EBADARG;
+  const int ch = min(scatter_channels(c, n), kGmChan);
+  if (ch <= 0) return MVP_EBADSHAPE;   // rows longer than the LDS staging buffer: the caller gathers + reduces
+  dim3 grid((c + ch - 1) / ch, b);
+  if (!grid_ok(grid.x, grid.y, 1)) return MVP_EBADSHAPE;
+  hipLaunchKernelGGL(gather_max_lds_kernel, grid, dim3(kScThreads), 0, as_stream(stream), c, n, npoints, k, ch,
+                     points, idx, out, arg);
+  return check_launch("mvp_gather_max");
+}
+
+extern "C" int mvp_gather_max_grad(int b, int c, int n, int npoints, const float *grad_out, const int *arg,
+                                   float *grad_points, int overwrite, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0) return MVP_EBADSHAPE;
+  if (b == 0 || c == 0 || n == 0) return MVP_OK;
+  if (b > 65535) return MVP_EBADSHAPE;
+  if (!grad_out || !arg || !grad_points) return MVP_EBADARG;
+  const int ch = scatter_channels(c, n);
+  if (ch <= 0) return MVP_EBADSHAPE;
+  dim3 grid((c + ch - 1) / ch, b);
+  if (!grid_ok(grid.x, grid.y, 1)) return MVP_EBADSHAPE;
+  if (overwrite)
+    hipLaunchKernelGGL(gather_max_grad_kernel<true>, grid, dim3(kScThreads), 0, as_stream(stream), c, n, npoints, ch,
+                       grad_out, arg, grad_points);
+  else
+    hipLaunchKernelGGL(gather_max_grad_kernel<false>, grid, dim3(kScThreads), 0, as_stream(stream), c, n, npoints, ch,
+                       grad_out, arg, grad_points);
+  return check_launch("mvp_gather_max_grad");
 }

@@ -296,6 +296,48 @@ class GroupingOperation(Function):
         return grad_features, None
 
 
+class GatherMax(Function):
+    """out[b,c,p] = max_j features[b,c, indices[b,p,j]] -- the gather_points + torch.max pair of
+    edge_preserve_sampling fused (mvp_gather_max: the (B,C,P,k) neighbour tensor is never
+    written).  (features (B,C,N) float32, indices (B,P,k) int32) -> (B,C,P); differentiable w.r.t.
+    features: the gradient goes to the first maximal neighbour, torch.max's rule.  Not part of the
+    reference's operator set (row N2 of the widening plan)."""
+
+    @staticmethod
+    def forward(ctx, features, indices):
+        _need_contiguous(features, indices)
+        B, C, N = features.shape
+        _, P, K = indices.shape
+        out = _new(features, B, C, P)
+        arg = _new(features, B, C, P, dtype=torch.int32)
+        call("mvp_gather_max", features.device, B, C, N, P, K, features, indices, out, arg)
+        ctx.for_backwards = (arg, N)
+        ctx.mark_non_differentiable(indices)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        arg, N = ctx.for_backwards
+        B, C, P = grad_out.shape
+        grad_features = _new(grad_out, B, C, N)          # written, not accumulated into
+        call("mvp_gather_max_grad", grad_out.device, B, C, N, P, grad_out.data.contiguous(), arg, grad_features, 1)
+        return grad_features, None
+
+
+GATHER_MAX_LIMIT = 24576      # floats of one feature row the fused kernel can stage (96 KiB of LDS)
+
+
+def gather_max(features, indices):
+    """Fused neighbour max-pool (see GatherMax); rows too long for the LDS staging buffer take the
+    gather + reduce route through the gather operator."""
+    if features.size(2) > GATHER_MAX_LIMIT:
+        B, C, _ = features.shape
+        _, P, K = indices.shape
+        flat = indices.transpose(1, 2).contiguous().view(B, K * P)
+        return GatherPoints.apply(features, flat).view(B, C, K, P).max(dim=2)[0]
+    return GatherMax.apply(features, indices)
+
+
 def gram_topk(dot, sq, k):
     """Feature-space neighbours: dot (B,N,N) = x^T x, sq (B,N) = |x_i|^2 ->
     idx (B,N,k) int32, per row the k largest of (-sq[j] + 2 dot[i][j]) - sq[i]

@@ -673,6 +673,52 @@ def test_scatter_gradients_hub_graph_and_plain_entry_points(oracle):
     assert _lib.scatter_scratch_bytes(b, 8193, 100, 1) == 0 and _lib.scatter_scratch_bytes(b, 100, 100, 2) == 0
 
 
+@pytest.mark.parametrize("b,c,n,p,k,kind", [(2, 37, 700, 300, 16, "random"), (3, 128, 3072, 1536, 16, "random"),
+                                            (2, 24, 1024, 256, 10, "ties"), (1, 5, 30000, 100, 4, "long_rows"),
+                                            (2, 64, 64, 64, 1, "k1")])
+def test_gather_max_matches_oracle_composition(oracle, b, c, n, p, k, kind):
+    """mvp_gather_max (neighbour max-pool of edge_preserve_sampling, fused) against the oracle's
+    gather followed by NumPy's max / first-argmax: values exact, the recorded winner = the FIRST
+    maximal neighbour (ties: quantised / ReLU-like features), gradient = scatter of grad_out to
+    the winners (float atomics in LDS: 1e-6).  `long_rows`: a row does not fit the LDS staging
+    buffer, the Python wrapper takes the gather + reduce route."""
+    from mvp_benchmark_amd import _lib
+    from mvp_benchmark_amd.mm3d_pn2.functional import gather_max
+    rng = np.random.default_rng(b * 1000 + c)
+    f = rand_clouds(c, b, c, n)
+    if kind == "ties":
+        f = np.maximum(np.round(f * 4) / 4 - 0.5, 0).astype(np.float32)      # many exact zeros and repeats
+    idx = rng.integers(0, n, (b, p, k)).astype(np.int32)
+    gathered = oracle.gather_points(f, idx.reshape(b, p * k)).reshape(b, c, p, k)
+    want = gathered.max(-1)
+    jstar = gathered.argmax(-1)                                             # first maximum
+    want_arg = np.take_along_axis(np.broadcast_to(idx[:, None], (b, c, p, k)), jstar[..., None], -1)[..., 0]
+    tf = dev(f).requires_grad_()
+    out = gather_max(tf, dev(idx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+    go = rand_clouds(7, b, c, p)
+    out.backward(dev(go))
+    wg = np.zeros((b, c, n), np.float32)
+    bi, ci, _ = np.meshgrid(np.arange(b), np.arange(c), np.arange(p), indexing="ij")
+    np.add.at(wg, (bi, ci, want_arg), go)
+    np.testing.assert_allclose(tf.grad.cpu().numpy(), wg, rtol=1e-6, atol=1e-6)
+    if kind != "long_rows":
+        # the C ABI directly: the winner array, and accumulate vs overwrite
+        o2 = torch.empty(b, c, p, device=DEV)
+        a2 = torch.empty(b, c, p, dtype=torch.int32, device=DEV)
+        _lib.call("mvp_gather_max", DEV, b, c, n, p, k, dev(f), dev(idx), o2, a2)
+        np.testing.assert_array_equal(a2.cpu().numpy(), want_arg)
+        acc = torch.full((b, c, n), 2.0, device=DEV)
+        _lib.call("mvp_gather_max_grad", DEV, b, c, n, p, dev(go), a2, acc, 0)
+        np.testing.assert_allclose(acc.cpu().numpy(), wg + 2.0, rtol=1e-6, atol=1e-6)
+        _lib.call("mvp_gather_max_grad", DEV, b, c, n, p, dev(go), a2, acc, 1)
+        np.testing.assert_allclose(acc.cpu().numpy(), wg, rtol=1e-6, atol=1e-6)
+    else:
+        with pytest.raises(_lib.MvpOpsError):
+            _lib.call("mvp_gather_max", DEV, b, c, n, p, k, dev(f), dev(idx), torch.empty(b, c, p, device=DEV),
+                      torch.empty(b, c, p, dtype=torch.int32, device=DEV))
+
+
 def test_scatter_gradient_index_cache(oracle):
     """The autograd Functions keep the inverted index of an index tensor and reuse
     it (several gathers through one neighbour graph; a retained graph
