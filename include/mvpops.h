@@ -175,6 +175,18 @@ int mvp_furthest_point_sampling_with_dist(int b, int n, int m,
                                           const float *points_dist,
                                           float *temp, int *idx, void *stream);
 
+/* The same sampling (same indices, same temp) with w = 2 or 4 workgroups per cloud: a lane owns
+ * 1/w of the points the reference's thread scans, the members exchange their local winners
+ * through memory once per round (csrc/fps.hip: fps_cluster_kernel).  n a multiple of w * 1024,
+ * n <= 16384; scratch of mvp_fps_cluster_scratch_bytes(b) bytes.  MVP_EBADSHAPE when the shape is
+ * not covered or the cooperative launch does not fit the device (the caller then uses
+ * mvp_furthest_point_sampling).  Opt-in: measured slower or on par, see DESIGN.md section 10. */
+long long mvp_fps_cluster_scratch_bytes(int b);
+int mvp_furthest_point_sampling_cluster(int b, int n, int m, int w, const float *points,
+                                        float *temp, int *idx, void *scratch,
+                                        long long scratch_bytes, void *stream);
+
+
 /* ---------------------------------------------------- ball_query/knn/3nn */
 
 /* Replaces ball_query_ext.ball_query_wrapper

@@ -36,6 +36,7 @@ SIGNATURES = {
     "mvp_gather_points": "iiiippp",
     "mvp_gather_points_grad": "iiiippp",
     "mvp_gather_max": "iiiiipppp",
+    "mvp_furthest_point_sampling_cluster": "iiiippppq",
     "mvp_gather_max_grad": "iiiipppi",
     "mvp_group_points": "iiiiippp",
     "mvp_group_points_grad": "iiiiippp",
@@ -83,6 +84,8 @@ def load():
     lib.mvp_emd_configure.restype = ctypes.c_int
     lib.mvp_emd_configure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.mvp_fps_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_fps_cluster_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_fps_cluster_scratch_bytes.argtypes = [ctypes.c_int]
     lib.mvp_fps_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_chamfer_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_chamfer_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -149,6 +152,10 @@ def emd_configure(cluster=-1, same_xcd=-1, split=-1):
         raise MvpOpsError("mvp_emd_configure: %s" % _ERR.get(rc, rc))
 
 
+def fps_cluster_scratch_bytes(b):
+    return int(load().mvp_fps_cluster_scratch_bytes(int(b)))
+
+
 def fps_scratch_bytes(b, n):
     return int(load().mvp_fps_scratch_bytes(int(b), int(n)))
 
@@ -174,6 +181,6 @@ def pointwise_wgrad_mfma_scratch_bytes(b, cin, cout, length, with_bias):
 
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
-    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes",
+    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes", "mvp_fps_cluster_scratch_bytes",
             "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes", "mvp_pointwise_wgrad_mfma_scratch_bytes"] \
         + list(SIGNATURES)

@@ -593,6 +593,161 @@ static int launch_fps(int b, int n, int m, const float *dataset, float *temp,
   return MVP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// W workgroups per cloud (build it and measure it).
+//
+// The register-resident kernel gives a cloud ONE workgroup: 64 clouds occupy 64 of 256 CUs and a
+// lane of a 16384-point cloud owns 16 points.  Here W = 2 or 4 workgroups share a cloud; lane t of
+// member w owns the points k = t + (w + W i) * 1024, i.e. a subset of what the reference's thread
+// t scans, so the per-lane work shrinks by W.  Per round every member finds its local maximum as
+// fps_kernel does, its winning lane resolves the point and publishes {key, x, y, z} as five tagged
+// 8-byte granules (one store each, write-through; the data is the flag, slots double-buffered by
+// round parity -- the exchange of emd.hip's cluster barrier), every member polls all W x 5 words
+// and takes the maximum of
+//     key = value bits << 32 | (1023 - bitrev(t)) << 14 | (16383 - k)
+// = the reference's winner: largest value, then smallest bit-reversed thread slot, then (inside a
+// thread) the lowest k.  Cooperative launch (the members wait for each other).
+// Measured (profiles/r3_fps_cluster.txt): see DESIGN.md section 10.
+constexpr unsigned kFpsSpinLimit = 1u << 24;
+
+template <int PW, int W>
+__global__ __launch_bounds__(1024) void fps_cluster_kernel(
+    int b, int bpad, int n, int m, const float *__restrict__ dataset, float *__restrict__ temp,
+    int *__restrict__ idxs, unsigned long long *__restrict__ granules) {
+  const int cloud = (int)blockIdx.x % bpad;
+  const int w = (int)blockIdx.x / bpad;
+  if (cloud >= b || m <= 0) return;
+  constexpr int bs = 1024;
+  const int t = threadIdx.x;
+  const int lane = t & (kWave - 1);
+  const int wave = t >> 6;
+  dataset += (size_t)cloud * n * 3;
+  temp += (size_t)cloud * n;
+  idxs += (size_t)cloud * m;
+  unsigned long long *slots = granules + (size_t)cloud * (2 * W * 8);   // [parity][member][8 words, 5 used]
+
+  __shared__ unsigned long long s_max[2];
+  __shared__ float s_sel[2][4];
+  __shared__ int s_abort;
+
+  const unsigned rev = __brev((unsigned)t) >> 22;   // 10 bits
+  const unsigned long long tiekey = ((unsigned long long)(1023u - rev) << 20) | (unsigned)t;
+
+  float px[PW], py[PW], pz[PW], pt[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int k = t + (w + W * i) * bs;
+    const bool valid = k < n;
+    px[i] = valid ? dataset[(size_t)k * 3 + 0] : 0.f;
+    py[i] = valid ? dataset[(size_t)k * 3 + 1] : 0.f;
+    pz[i] = valid ? dataset[(size_t)k * 3 + 2] : 0.f;
+    pt[i] = valid ? 1e10f : -__builtin_inff();
+  }
+  if (t < 2) s_max[t] = 0ull;
+  if (t == 0) s_abort = 0;
+  __syncthreads();
+  int old = 0;
+  if (w == 0 && t == 0) idxs[0] = 0;
+  float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+
+  for (int j = 1; j < m; ++j) {
+    const int par = j & 1;
+    float best = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const float d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
+      pt[i] = d < pt[i] ? d : pt[i];
+      best = __builtin_fmaxf(best, pt[i]);
+    }
+    // (a member whose lanes own no point at all cannot happen: n >= W * 1024)
+    unsigned long long key = ((unsigned long long)__float_as_uint(__builtin_fmaxf(best, 0.f)) << 32) | tiekey;
+    if (best < 0.f) key = 0ull;   // padding lane
+    key = wave_max_u64(key);
+    if (lane == 0) atomicMax(&s_max[par], key);
+    lds_barrier();
+    key = s_max[par];
+    if (t == 0) s_max[1 - par] = 0ull;
+    const int tstar = (int)(key & 0xFFFFFu);
+    if (t == tstar) {
+      // first (lowest k) maximum among this lane's points; then the five granules
+      const float vbest = __uint_as_float((unsigned)(key >> 32));
+      int sel = 0;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+      for (int i = PW - 1; i >= 0; --i) {
+        const bool hit = pt[i] == vbest;
+        sel = hit ? t + (w + W * i) * bs : sel;
+        sx = hit ? px[i] : sx;
+        sy = hit ? py[i] : sy;
+        sz = hit ? pz[i] : sz;
+      }
+      const unsigned lo = ((1023u - rev) << 14) | (unsigned)(16383 - sel);
+      unsigned long long *mine = slots + ((size_t)par * W + w) * 8;
+      const unsigned long long tag = (unsigned long long)(unsigned)j << 32;
+      __hip_atomic_store(mine + 0, tag | (unsigned)(key >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 1, tag | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 2, tag | __float_as_uint(sx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 3, tag | __float_as_uint(sy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 4, tag | __float_as_uint(sz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {
+      // all-gather: lane l polls word l % 8 of member l / 8
+      const unsigned long long *base = slots + (size_t)par * W * 8;
+      unsigned long long x = 0ull;
+      bool done = false;
+      for (unsigned spins = 0; spins < kFpsSpinLimit; ++spins) {
+        if (lane < W * 8 && (lane & 7) < 5)
+          x = __hip_atomic_load(base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        done = __all(!(lane < W * 8 && (lane & 7) < 5) || (unsigned)(x >> 32) == (unsigned)j);
+        if (done) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!done && lane == 0) s_abort = 1;
+      const unsigned v = (unsigned)x;
+      unsigned long long bestk = 0ull;
+      int bw = 0;
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const unsigned long long kq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, q * 8) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)v, q * 8 + 1);
+        if (kq > bestk) {
+          bestk = kq;
+          bw = q;
+        }
+      }
+      if (lane == 0) {
+        s_sel[par][0] = __int_as_float(16383 - (int)(bestk & 0x3FFFu));
+      }
+      // coordinates of the winning member: lanes bw*8+2..4
+      const unsigned cx = (unsigned)__builtin_amdgcn_readlane((int)v, bw * 8 + 2 < 64 ? bw * 8 + 2 : 0);
+      const unsigned cy = (unsigned)__builtin_amdgcn_readlane((int)v, bw * 8 + 3 < 64 ? bw * 8 + 3 : 0);
+      const unsigned cz = (unsigned)__builtin_amdgcn_readlane((int)v, bw * 8 + 4 < 64 ? bw * 8 + 4 : 0);
+      if (lane == 0) {
+        s_sel[par][1] = __uint_as_float(cx);
+        s_sel[par][2] = __uint_as_float(cy);
+        s_sel[par][3] = __uint_as_float(cz);
+      }
+    }
+    lds_barrier();
+    if (s_abort) break;
+    old = __builtin_amdgcn_readfirstlane(__float_as_int(s_sel[par][0]));
+    x1 = s_sel[par][1];
+    y1 = s_sel[par][2];
+    z1 = s_sel[par][3];
+    if (w == 0 && t == 0) idxs[j] = old;
+  }
+  if (s_abort) {   // members were not co-resident (cannot happen under a cooperative launch): fail loudly
+    if (w == 0)
+      for (int j = t; j < m; j += bs) idxs[j] = -1;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int k = t + (w + W * i) * bs;
+    if (k < n) temp[k] = pt[i];
+  }
+}
+
 }  // namespace mvp
 
 using namespace mvp;
@@ -649,4 +804,35 @@ extern "C" int mvp_furthest_point_sampling_with_dist(int b, int n, int m,
   int rc = launch_fps<true>(b, n, m, points_dist, temp, idx, as_stream(stream));
   if (rc != MVP_OK) return rc;
   return check_launch("mvp_furthest_point_sampling_with_dist");
+}
+
+extern "C" long long mvp_fps_cluster_scratch_bytes(int b) { return b < 0 ? -1 : (long long)b * (2 * 4 * 8) * 8; }
+
+/* W = 2 or 4 workgroups per cloud; n a multiple of W * 1024, 2048 <= n <= 16384.  scratch:
+ * mvp_fps_cluster_scratch_bytes(b) bytes (zeroed here). */
+extern "C" int mvp_furthest_point_sampling_cluster(int b, int n, int m, int w, const float *points, float *temp,
+                                                   int *idx, void *scratch, long long scratch_bytes, void *stream) {
+  if (b < 0 || n <= 0 || m < 0) return MVP_EBADSHAPE;
+  if (b == 0 || m == 0) return MVP_OK;
+  if ((w != 2 && w != 4) || n % (w * 1024) != 0 || n > 16384) return MVP_EBADSHAPE;
+  if (!points || !temp || !idx || !scratch) return MVP_EBADARG;
+  if (scratch_bytes < mvp_fps_cluster_scratch_bytes(b)) return MVP_EBADARG;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(scratch, 0, (size_t)mvp_fps_cluster_scratch_bytes(b), st) != hipSuccess)
+    return check_launch("mvp_furthest_point_sampling_cluster");
+  int bpad = (b + 7) / 8 * 8;
+  const int pw = n / (w * 1024);
+  unsigned long long *gr = static_cast<unsigned long long *>(scratch);
+  void *args[] = {&b, &bpad, &n, &m, &points, &temp, &idx, &gr};
+  const void *fn = nullptr;
+#define MVP_FPS_CL(PWV, WV) if (pw == PWV && w == WV) fn = reinterpret_cast<const void *>(fps_cluster_kernel<PWV, WV>)
+  MVP_FPS_CL(1, 2); MVP_FPS_CL(2, 2); MVP_FPS_CL(3, 2); MVP_FPS_CL(4, 2); MVP_FPS_CL(5, 2); MVP_FPS_CL(6, 2); MVP_FPS_CL(7, 2); MVP_FPS_CL(8, 2);
+  MVP_FPS_CL(1, 4); MVP_FPS_CL(2, 4); MVP_FPS_CL(3, 4); MVP_FPS_CL(4, 4);
+#undef MVP_FPS_CL
+  if (!fn) return MVP_EBADSHAPE;
+  if (hipLaunchCooperativeKernel(fn, dim3(w * bpad), dim3(1024), args, 0, st) != hipSuccess) {
+    (void)hipGetLastError();
+    return MVP_EBADSHAPE;   // the cluster does not fit this device next to what is running: the caller falls back
+  }
+  return check_launch("mvp_furthest_point_sampling_cluster");
 }

@@ -231,12 +231,22 @@ constexpr int kTrFloats = 12288;  // 48 KiB staging buffer: rows x chunk columns
 // <= 2048 destinations: 2 per thread, 8 rows x 1536 columns; more: up to 8 per thread, 4 rows x 3072 columns
 static int tr_chunk(int n_dst) { return n_dst <= 2 * kScThreads ? 1536 : 3072; }
 
-// grid (chunks, clouds).  offsets: [cloud][chunk][n_dst + 1]; list: [cloud][chunk][chunk * R]
-// of chunk-local column numbers (WEIGHTED: int2 {column, weight bits}).
+// Scratch layout, per (cloud, chunk): offsets u16[n_dst + 1] (padded to 8 bytes; a chunk holds at
+// most 3072 * 3 entries), then the list: u16 chunk-local column numbers (WEIGHTED: int2 {column,
+// weight bits}).  16-bit entries halve what every channel strip re-reads (round 3: the lists and
+// offsets were 19 % of the kernel's HBM-side traffic at the VRCNet shapes).
+typedef unsigned short tr_u16;
+__host__ __device__ inline size_t tr_off_bytes(int n_dst) { return ((size_t)(n_dst + 1) * 2 + 7) & ~(size_t)7; }
+__host__ __device__ inline size_t tr_list_bytes(int chunk, int r) { return (size_t)chunk * r * (r == 3 ? 8 : 2); }
+__host__ __device__ inline size_t tr_chunk_bytes(int n_dst, int chunk, int r) {
+  return (tr_off_bytes(n_dst) + tr_list_bytes(chunk, r) + 7) & ~(size_t)7;
+}
+
+// grid (chunks, clouds).
 template <bool WEIGHTED>
 __global__ __launch_bounds__(kScThreads) void transpose_index_kernel(
     int n_dst, int m_src, int chunk, const int *__restrict__ idx, const float *__restrict__ weight,
-    int *__restrict__ offsets, int *__restrict__ list) {
+    char *__restrict__ scratch) {
   constexpr int R = WEIGHTED ? 3 : 1;
   __shared__ int cnt[kTrMaxDst];
   __shared__ int wtot[kScThreads / kWave];
@@ -268,18 +278,19 @@ __global__ __launch_bounds__(kScThreads) void transpose_index_kernel(
   int base = 0;
   for (int w = 0; w < wave; ++w) base += wtot[w];
   int run = base + incl - sum;
-  int *off = offsets + ((size_t)cloud * nq + q) * (n_dst + 1);
+  char *base_p = scratch + ((size_t)cloud * nq + q) * tr_chunk_bytes(n_dst, chunk, R);
+  tr_u16 *off = reinterpret_cast<tr_u16 *>(base_p);
   for (int i = 0; i < per; ++i) {
     if (j0 + i < n_dst) {
       const int cc = cnt[j0 + i];
       cnt[j0 + i] = run;  // becomes the fill cursor
-      off[j0 + i] = run;
+      off[j0 + i] = (tr_u16)run;
       run += cc;
     }
   }
-  if (t == kScThreads - 1) off[n_dst] = run;
+  if (t == kScThreads - 1) off[n_dst] = (tr_u16)run;
   __syncthreads();
-  int *lst = list + ((size_t)cloud * nq + q) * ((size_t)chunk * R) * (WEIGHTED ? 2 : 1);
+  char *lst = base_p + tr_off_bytes(n_dst);
   const float *w = WEIGHTED ? weight + ((size_t)cloud * m_src + p0) * R : nullptr;
   for (int e = t; e < ne; e += kScThreads) {
     const int j = id[e];
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(kScThreads) void transpose_index_kernel(
       if constexpr (WEIGHTED) {
         reinterpret_cast<int2 *>(lst)[pos] = make_int2(e / 3, __float_as_int(w[e]));
       } else {
-        lst[pos] = e;
+        reinterpret_cast<tr_u16 *>(lst)[pos] = (tr_u16)e;
       }
     }
   }
@@ -298,10 +309,12 @@ __global__ __launch_bounds__(kScThreads) void transpose_index_kernel(
 // CHUNK = columns staged per step (CH * CHUNK floats of LDS).
 // OVERWRITE: grad_points is written (every element), not accumulated into -- no zero fill by
 // the caller, no read of the destination.
+// (Round 3: fetching the NEXT chunk's columns into registers under the current chunk's gather costs the second
+// workgroup per CU -- 12-16 more VGPRs -- and loses: 233 -> 278 us at (64,64,3072) <- 49152, profiles/r3_scatter_grad.txt.)
 template <bool WEIGHTED, int D, int CH, int CHUNK, bool OVERWRITE>
 __global__ __launch_bounds__(kScThreads) __attribute__((amdgpu_waves_per_eu(D == 8 ? 4 : 8, 8))) void transposed_reduce_kernel(
-    int c, int n_dst, int m_src, const float *__restrict__ grad_out, const int *__restrict__ offsets,
-    const int *__restrict__ list, float *__restrict__ grad_points) {
+    int c, int n_dst, int m_src, const float *__restrict__ grad_out, const char *__restrict__ scratch,
+    float *__restrict__ grad_points) {
   constexpr int R = WEIGHTED ? 3 : 1;
   static_assert(CH * CHUNK <= kTrFloats, "staging buffer");
   __shared__ float stage[CH * CHUNK];
@@ -319,8 +332,9 @@ __global__ __launch_bounds__(kScThreads) __attribute__((amdgpu_waves_per_eu(D ==
   for (int q = 0; q < nq; ++q) {
     const int p0 = q * CHUNK;
     const int pn = min(CHUNK, m_src - p0);
-    const int *off = offsets + ((size_t)cloud * nq + q) * (n_dst + 1);
-    const int *lst = list + ((size_t)cloud * nq + q) * ((size_t)CHUNK * R) * (WEIGHTED ? 2 : 1);
+    const char *base_p = scratch + ((size_t)cloud * nq + q) * tr_chunk_bytes(n_dst, CHUNK, R);
+    const tr_u16 *off = reinterpret_cast<const tr_u16 *>(base_p);
+    const char *lst = base_p + tr_off_bytes(n_dst);
     // List reads are unconditional (position clamped into the chunk's list, the
     // result discarded when !live): four of them issue back to back instead of
     // four exec-masked load + wait sequences.
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(kScThreads) __attribute__((amdgpu_waves_per_eu(D ==
         e = live ? ew.x : 0;
         w = live ? __int_as_float(ew.y) : 0.f;
       } else {
-        const int ev = lst[ii];
+        const int ev = reinterpret_cast<const tr_u16 *>(lst)[ii];
         e = live ? ev : 0;
         w = live ? 1.f : 0.f;
       }
@@ -499,8 +513,7 @@ static long long transposed_scratch_bytes(int b, int n_dst, int m_src, int r) {
   const int chunk = tr_chunk(n_dst);
   const long long nq = (m_src + chunk - 1) / chunk;
   if (nq > 65535) return 0;
-  const long long per_cloud = nq * ((long long)(n_dst + 1) * 4 + (long long)chunk * r * (r == 3 ? 8 : 4));
-  return (long long)b * per_cloud;
+  return (long long)b * nq * (long long)tr_chunk_bytes(n_dst, chunk, r);
 }
 
 // mode bit 0 (MVP_SCATTER_OVERWRITE): write instead of accumulate; bit 1 (MVP_SCATTER_INDEX_READY):
@@ -510,19 +523,18 @@ static void transposed_scatter(int b, int c, int n_dst, int m_src, const float *
                                const float *weight, float *grad_points, void *scratch, int mode, hipStream_t stream) {
   const int chunk = tr_chunk(n_dst);
   const int nq = (m_src + chunk - 1) / chunk;
-  int *offsets = static_cast<int *>(scratch);
-  int *list = offsets + (size_t)b * nq * (n_dst + 1);
+  char *sbytes = static_cast<char *>(scratch);
   if (!(mode & MVP_SCATTER_INDEX_READY))
     hipLaunchKernelGGL(transpose_index_kernel<WEIGHTED>, dim3(nq, b), dim3(kScThreads), 0, stream, n_dst, m_src, chunk,
-                       idx, weight, offsets, list);
+                       idx, weight, sbytes);
 #define MVP_TR_LAUNCH(DD, CH, CHUNK)                                                                              \
   do {                                                                                                            \
     if (mode & MVP_SCATTER_OVERWRITE)                                                                             \
       hipLaunchKernelGGL((transposed_reduce_kernel<WEIGHTED, DD, CH, CHUNK, true>), dim3((c + CH - 1) / CH, b),   \
-                         dim3(kScThreads), 0, stream, c, n_dst, m_src, grad_out, offsets, list, grad_points);     \
+                         dim3(kScThreads), 0, stream, c, n_dst, m_src, grad_out, sbytes, grad_points);            \
     else                                                                                                          \
       hipLaunchKernelGGL((transposed_reduce_kernel<WEIGHTED, DD, CH, CHUNK, false>), dim3((c + CH - 1) / CH, b),  \
-                         dim3(kScThreads), 0, stream, c, n_dst, m_src, grad_out, offsets, list, grad_points);     \
+                         dim3(kScThreads), 0, stream, c, n_dst, m_src, grad_out, sbytes, grad_points);            \
   } while (0)
   if (n_dst <= kScThreads) MVP_TR_LAUNCH(1, 8, 1536);
   else if (n_dst <= 2 * kScThreads) MVP_TR_LAUNCH(2, 8, 1536);

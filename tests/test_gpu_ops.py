@@ -518,6 +518,33 @@ def test_fps_sorted_variant_ties(oracle):
         np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample(x, m))
 
 
+@pytest.mark.parametrize("b,n,m,w,kind", [(3, 8192, 400, 2, "random"), (3, 8192, 400, 4, "random"), (2, 16384, 300, 4, "random"),
+                                           (2, 4096, 512, 4, "lattice"), (2, 2048, 2048, 2, "lattice"), (5, 6144, 64, 2, "random")])
+def test_fps_cluster_variant_matches_oracle(oracle, b, n, m, w, kind):
+    """mvp_furthest_point_sampling_cluster: w workgroups per cloud, local winners exchanged through
+    memory every round -- same indices and the same final min-distance array as the oracle, ties
+    included (lattice: the maximum is attained many times in every round, inside one thread's
+    points and across members; m = n: every point is sampled)."""
+    from mvp_benchmark_amd import _lib
+    if kind == "random":
+        x = rand_clouds(n + w, b, n, 3)
+    else:
+        side = round(n ** (1 / 3)) if round(n ** (1 / 3)) ** 3 == n else 16
+        g = np.stack(np.meshgrid(*[np.arange(side, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) / side
+        x = np.tile(g[None], (b, (n + len(g) - 1) // len(g), 1))[:, :n].astype(np.float32)
+    nbytes = _lib.fps_cluster_scratch_bytes(b)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    temp = torch.full((b, n), 1e10, device=DEV)
+    idx = torch.zeros(b, m, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_furthest_point_sampling_cluster", DEV, b, n, m, w, dev(x), temp, idx, scratch, nbytes)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oracle.furthest_point_sample(x, m))
+    # the plain kernel's temp is the reference's: same array
+    temp2 = torch.full((b, n), 1e10, device=DEV)
+    idx2 = torch.zeros(b, m, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_furthest_point_sampling", DEV, b, n, m, dev(x), temp2, idx2)
+    assert torch.equal(temp, temp2)
+
+
 def test_fps_equals_the_grid_emulator():
     """The HIP FPS against the thread-by-thread replay of furthest_point_sampling_kernel
     (oracle/emulator.py: strided per-thread scan, shared-memory tree level by level) on a lattice

@@ -63,9 +63,11 @@ def test_guards_and_scratch_sizes_of_the_widened_entry_points():
     lib = _lib.load()
     null = ctypes.c_void_p(0)
     # transposed scatter gradients: chunk 1536 up to 2048 destinations, 3072 above; not covered beyond 8192
-    assert _lib.scatter_scratch_bytes(2, 1024, 3000, 1) == 2 * 2 * ((1024 + 1) * 4 + 1536 * 4)
-    assert _lib.scatter_scratch_bytes(1, 3072, 49152, 1) == 16 * ((3072 + 1) * 4 + 3072 * 4)
-    assert _lib.scatter_scratch_bytes(1, 1024, 3072, 3) == 2 * ((1024 + 1) * 4 + 1536 * 3 * 8)
+    # per (cloud, chunk): u16 offsets padded to 8 bytes + u16 entries (weighted: {column, weight} pairs of 8 bytes)
+    up8 = lambda v: (v + 7) // 8 * 8
+    assert _lib.scatter_scratch_bytes(2, 1024, 3000, 1) == 2 * 2 * up8(up8((1024 + 1) * 2) + 1536 * 2)
+    assert _lib.scatter_scratch_bytes(1, 3072, 49152, 1) == 16 * up8(up8((3072 + 1) * 2) + 3072 * 2)
+    assert _lib.scatter_scratch_bytes(1, 1024, 3072, 3) == 2 * up8(up8((1024 + 1) * 2) + 1536 * 3 * 8)
     assert _lib.scatter_scratch_bytes(1, 8193, 100, 1) == 0 and _lib.scatter_scratch_bytes(1, 100, 100, 2) == 0
     # ... and the _ws entry points fall back to the plain ones (which accept the empty batch)
     assert lib.mvp_gather_points_grad_ws(0, 3, 8, 8, null, null, null, null, 0, 0, null) == 0

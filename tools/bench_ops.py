@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from mvp_benchmark_amd import _lib as _lib0
+if os.environ.get("MVP_LIB"):          # A/B: another build of the library (make variant ...)
+    _lib0.LIB_PATH = os.path.abspath(os.environ["MVP_LIB"])
 from mvp_benchmark_amd.metrics import cd
 from mvp_benchmark_amd.mm3d_pn2 import (furthest_point_sample, knn, three_nn, three_interpolate,
                                         gather_points, grouping_operation, ball_query)
