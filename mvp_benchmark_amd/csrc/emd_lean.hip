@@ -128,6 +128,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   __shared__ int s_wbusy[kEmdWaves];
   __shared__ unsigned long long s_hist2[4];
   if (threadIdx.x < 4) s_hist2[threadIdx.x] = 0;
+  __shared__ float s_loose[2][3];  // [slow][sum of (seed threshold - final threshold) in cell widths, sum of seed threshold, evicted (no bid last round) count]
+  if (threadIdx.x < 6) s_loose[threadIdx.x / 3][threadIdx.x % 3] = 0.f;
   __shared__ unsigned long long s_slow[2][8];  // [d >= 10k cycles][count, nsub, cells, visit steps, extra member iterations, folds, seed cycles, visit cycles]
   if (threadIdx.x < 16) s_slow[threadIdx.x >> 3][threadIdx.x & 7] = 0;
   __shared__ unsigned long long s_hist[16];  // bids: [0..7] duration buckets, [8] sum nsub, [9] sum cells visited, [10] count, [11] linear scans, [12] sum cycles
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
       }
 #ifdef MVP_EMD_PROFILE
       const long long tb1 = __builtin_readcyclecounter();
+      const float prof_tm_seed = st.tm;
       long long t_visit = 0;
       int n_visit = 0, prof_fold = 0, prof_more = 0;
 #endif
@@ -424,18 +427,17 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
         {
           const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
           const float gm = (float)(gg.g - 1);
-          ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
-          iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
-          iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
-          nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
-          ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
-          nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
-          ix0 = __builtin_amdgcn_readfirstlane(ix0);
-          iy0 = __builtin_amdgcn_readfirstlane(iy0);
-          iz0 = __builtin_amdgcn_readfirstlane(iz0);
-          nx = __builtin_amdgcn_readfirstlane(nx);
-          ny = __builtin_amdgcn_readfirstlane(ny);
-          nz = __builtin_amdgcn_readfirstlane(nz);
+          // the six bounds in six lanes of ONE instruction stream (lane l: axis l % 3, lower bound for
+          // l < 3, upper bound otherwise) instead of six wave-uniform chains on the vector unit
+          const int ax = lane < 3 ? lane : lane - 3;
+          const float f = ax == 0 ? fx : ax == 1 ? fy : fz;
+          const int bound = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(lane < 3 ? f - r : f + r), 0.f), gm);
+          ix0 = __builtin_amdgcn_readlane(bound, 0);
+          iy0 = __builtin_amdgcn_readlane(bound, 1);
+          iz0 = __builtin_amdgcn_readlane(bound, 2);
+          nx = __builtin_amdgcn_readlane(bound, 3) - ix0 + 1;
+          ny = __builtin_amdgcn_readlane(bound, 4) - iy0 + 1;
+          nz = __builtin_amdgcn_readlane(bound, 5) - iz0 + 1;
         }
         const int nxy = nx * ny;
         nsub = nxy * nz;
@@ -515,6 +517,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
         atomicAdd(&s_hist2[1], (unsigned long long)t_visit);
         atomicAdd(&s_hist2[2], (unsigned long long)n_visit);
         atomicAdd(&s_hist2[3], (unsigned long long)prof_fold);
+        atomicAdd(&s_loose[d >= 10000 ? 1 : 0][0], (prof_tm_seed - ((3.0f - st.b2) + kMargin)) * gg.invh);
+        atomicAdd(&s_loose[d >= 10000 ? 1 : 0][1], prof_tm_seed * gg.invh);
         unsigned long long *sl = s_slow[d >= 10000 ? 1 : 0];
         atomicAdd(&sl[0], 1ull);
         atomicAdd(&sl[1], (unsigned long long)nsub);
@@ -905,6 +909,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     if (cloud == 0 && wg == 0)
       for (int k = 0; k < 2; ++k) {
         const double c = (double)s_slow[k][0] + 1e-9;
+        printf("cloud 0 wg 0 searches %s 10k cycles: seed threshold %.3f cell widths, of which %.3f loose (seed - final)\n", k ? ">=" : "<",
+               s_loose[k][1] / c, s_loose[k][0] / c);
         printf("cloud 0 wg 0 searches %s 10k cycles: %llu | mean sub-box %.0f cells, visited %.1f, visit steps %.2f, extra member iterations %.2f, folds %.1f, seed %.0f cycles, visits %.0f cycles\n",
                k ? ">=" : "<", s_slow[k][0], s_slow[k][1] / c, s_slow[k][2] / c, s_slow[k][3] / c, s_slow[k][4] / c, s_slow[k][5] / c, s_slow[k][6] / c, s_slow[k][7] / c);
       }
