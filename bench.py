@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--eps", type=float, default=0.004)
     ap.add_argument("--iters", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the untimed side measurements (tools/profile_round.sh: keeps the kernel trace to the headline shape)")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="clouds in the CPU-baseline sample (0 = min(cores, 64))")
     args = ap.parse_args()
@@ -212,10 +214,10 @@ def _timeit(fn):
 
 
 def committed_counters(B, n, eps, iters):
-    """Per-launch counters of emd_auction_kernel from the committed rocprofv3
+    """Per-call counters of mvp_emd_forward (its two kernels summed) from the committed rocprofv3
     --pmc passes (profiles/traffic.json), only if they were taken on this shape."""
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["emd_auction_kernel"]
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["emd_forward"]
         if (tr["batch"], tr["points"], tr["eps"], tr["iters"]) == (B, n, eps, iters):
             return tr
     except (OSError, KeyError, ValueError):
@@ -340,7 +342,7 @@ def run_eval(args, rank, world, dev):
     handover = {"round_min": int(rec[:, 0].min()), "round_max": int(rec[:, 0].max()),
                 "unassigned_max": int(rec[:, 1].max())}
 
-    side = side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_points)
+    side = {} if args.no_side else side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_points)
 
     pairs = float(B) * n * n
     value = pairs * world / (elapsed / args.steps)

@@ -7,7 +7,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- \
-  python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_traced.json 2> $out/trace.err
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side > $out/bench_traced.json 2> $out/trace.err
 for P in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_SMEM"; do
