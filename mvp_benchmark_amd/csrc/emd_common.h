@@ -33,7 +33,7 @@ constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens 
 // The lean kernel (emd_lean.hip) takes a cloud over once no workgroup has more than kRowModeMin
 // bidders, at most kLeanCap persons are unassigned (their number never grows, so every later
 // list fits the LDS record cache) and at least kLeanMinRounds rounds are left.
-constexpr int kLeanCap = 384;
+constexpr int kLeanCap = 384;   // (tuned with kRowModeMin: 64..160 x 384 / 512 all within 0.2 ms at the headline shape)
 constexpr int kLeanMinRounds = 64;
 static_assert(kLeanCap <= kRecCap, "the lean kernel keeps every list entry's record in LDS");
 
