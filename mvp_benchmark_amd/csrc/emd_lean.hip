@@ -649,10 +649,12 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
           st_i32(&ass[prev], -1);
           const int pos = append();
           if (__builtin_expect(pos >= 0, 1)) {
-            const float4 pa = ld_person(prev, 0);
-            const float4 pb = ld_person(prev, 1);
-            s_rq[nxt][pos] = pa;
-            s_ri[nxt][pos] = make_int4(prev, __float_as_int(pb.y), __float_as_int(pb.z), 0);
+            {
+              const float4 pa = ld_person(prev, 0);
+              const float4 pb = ld_person(prev, 1);
+              s_rq[nxt][pos] = pa;
+              s_ri[nxt][pos] = make_int4(prev, __float_as_int(pb.y), __float_as_int(pb.z), 0);
+            }
           }
         }
 #ifdef MVP_EMD_PROFILE

@@ -37,6 +37,13 @@ MFMA_FWD_MAX_CIN = 256    # wider inputs: a tie with the library (1.0-1.1x), whi
 # 33.1 ms with the library (profiles/r2_bench_models.txt).  So training keeps the library unless this is
 # set; inference (no autograd) uses the MFMA forward.
 MFMA_TRAIN = False
+# Round 3: the library's weight gradient of the >64-channel 1x1 convolutions is an NHWC implicit-GEMM kernel wrapped in
+# layout transposes (VRCNet step: igemm_wrw 3.4 ms x18 + batched_transpose_32x32_dword 1.8 ms x64,
+# tools/profile_kernels.py); mvp_pointwise_wgrad_mfma reads the NCHW operands as they are.  With this flag the layers
+# with at least MFMA_WGRAD_TRAIN_MIN_CIN input channels go through the autograd.Function under training too -- forward
+# and data gradient stay library calls, only the weight (+ bias) gradient changes hands.
+MFMA_WGRAD_TRAIN = False
+MFMA_WGRAD_TRAIN_MIN_CIN = 65
 
 _WGRAD_SCRATCH = {}   # (device, stream) -> one growing workspace for the partial tiles (no allocator churn)
 
@@ -120,7 +127,7 @@ class _PointwiseConv(Function):
         cout, cin = weight.shape[:2]
         ctx.has_bias = bias is not None
         ctx.relu = relu
-        if _mfma_fwd(x, cin, cout, weight):
+        if (MFMA_TRAIN or _covered(x, weight)) and _mfma_fwd(x, cin, cout, weight):
             y = mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
         else:
             y = conv(x, weight, bias)
@@ -139,7 +146,8 @@ class _PointwiseConv(Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         gx_mfma = MFMA_DGRAD and need_x and _mfma_ok(gy, cout, cin, weight) and cin % 4 == 0
-        gw_mfma = (need_w or need_b) and cin >= MFMA_WGRAD_MIN_CIN and _mfma_ok(x, cin, cout, weight) and not _covered(x, weight) \
+        wgrad_min = min(MFMA_WGRAD_MIN_CIN, MFMA_WGRAD_TRAIN_MIN_CIN) if MFMA_WGRAD_TRAIN else MFMA_WGRAD_MIN_CIN
+        gw_mfma = (need_w or need_b) and cin >= wgrad_min and _mfma_ok(x, cin, cout, weight) and not _covered(x, weight) \
             and pointwise_wgrad_mfma_scratch_bytes(x.size(0), cin, cout, x[0, 0].numel(), ctx.has_bias) > 0
         # ReLU'(.): the MFMA kernels mask grad_out by the saved output on load; the other routes get
         # the masked tensor
@@ -183,7 +191,8 @@ def pointwise_conv(x, weight, bias=None, relu=False):
     routed = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() \
         and weight.is_contiguous() and x.numel() > 0 and (_mfma_ok(x, cin, cout, weight) or _covered(x, weight))
     if routed and (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
-        if MFMA_TRAIN or _covered(x, weight):
+        if MFMA_TRAIN or _covered(x, weight) or (MFMA_WGRAD_TRAIN and cin >= MFMA_WGRAD_TRAIN_MIN_CIN
+                                                 and _mfma_ok(x, cin, cout, weight)):
             return _PointwiseConv.apply(x, weight, bias, relu)
         y = conv(x, weight, bias)
         return torch.relu(y) if relu else y

@@ -10,6 +10,8 @@ import train
 import mvp_benchmark_amd.pointwise as pw
 if "MVP_MFMA_TRAIN" in os.environ:                       # A/B of the training-path routing (pointwise.py)
     pw.MFMA_TRAIN = os.environ["MVP_MFMA_TRAIN"] == "1"
+if "MVP_MFMA_WGRAD_TRAIN" in os.environ:                 # A/B: only the weight gradients leave the library
+    pw.MFMA_WGRAD_TRAIN = os.environ["MVP_MFMA_WGRAD_TRAIN"] == "1"
 REPS = int(os.environ.get("MVP_BENCH_REPS", "10"))
 
 dev = "cuda:0"
@@ -48,5 +50,5 @@ for name in ("vrcnet", "ecg"):
         loss.backward()
         opt.step()
     ms = timed(step)
-    print("%s train step (batch 32, 2048 pts, MFMA_TRAIN=%s): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
-        name, pw.MFMA_TRAIN, ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
+    print("%s train step (batch 32, 2048 pts, MFMA_TRAIN=%s, MFMA_WGRAD_TRAIN=%s): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
+        name, pw.MFMA_TRAIN, pw.MFMA_WGRAD_TRAIN, ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
