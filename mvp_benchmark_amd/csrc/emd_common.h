@@ -137,6 +137,14 @@ __device__ __forceinline__ bool emd_band_alarm(u64 old, float inc) {
 // Reference merge order between two candidates (ORIGINAL object indices) of
 // equal value: lexicographically smaller (thread_in_unass, tile, k) wins.
 __device__ __attribute__((noinline)) bool emd_precedes(int ka, int kb, int n, int tpu) {
+  // tpu <= 0: the caller passes -(unassigned persons of the round) and leaves the two integer
+  // divisions behind thread_per_unass (emd_cuda.cu:107-109) to this rare path (lean kernel: they were
+  // ~56 instructions at the top of every round of every wave)
+  if (tpu <= 0) {
+    const int block_cnt = n >> 10;
+    const int upb = (-tpu + block_cnt - 1) / block_cnt;
+    tpu = 1024 / upb;
+  }
   const int tile_a = ka >> 11, tile_b = kb >> 11;
   const int kka = ka & 2047, kkb = kb & 2047;
   const int end_a = min(n - (tile_a << 11), 2048);

@@ -221,7 +221,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   }
 
   // ------------------------------------------------------------ the auction
-  const int block_cnt = n / 1024;
   int cur = 0;
   int Utot = resume->utot;  // unassigned persons of the whole cloud
   long long n_rounds = 0, n_bids = 0;
@@ -250,8 +249,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     const bool last = it == iters - 1;
     // thread_per_unass of the reference (emd_cuda.cu:107-109): fixes the tie
     // order only.
-    const int upb = (Utot + block_cnt - 1) / block_cnt;
-    const int tpu = 1024 / upb;
+    const int tpu = -Utot;   // (resolved inside emd_precedes: only equal values ever need it)
 
 #ifdef MVP_EMD_PROFILE
     const long long tp0 = __builtin_readcyclecounter();
@@ -282,8 +280,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
       int prof_cells = 0;
 #endif
       // grid coordinates of the bidder (emd_cell's arithmetic) and its home cell
-      const float fx = (qx - gg.lox) * gg.invh, fy = (qy - gg.loy) * gg.invh, fz = (qz - gg.loz) * gg.invh;
-      const int cix = min(gg.g - 1, max(0, (int)fx)), ciy = min(gg.g - 1, max(0, (int)fy)), ciz = min(gg.g - 1, max(0, (int)fz));
+      // (wave-uniform work on the vector unit: lane l < 6 takes axis l % 3 -- one chain instead of three here,
+      // and the value the cube's six bounds start from below)
+      const int ax = lane < 3 ? lane : lane - 3;
+      const float f_ax = ((ax == 0 ? qx : ax == 1 ? qy : qz) - (ax == 0 ? gg.lox : ax == 1 ? gg.loy : gg.loz)) * gg.invh;
+      const int ci_ax = min(gg.g - 1, max(0, (int)f_ax));
+      const int cix = __builtin_amdgcn_readlane(ci_ax, 0), ciy = __builtin_amdgcn_readlane(ci_ax, 1),
+                ciz = __builtin_amdgcn_readlane(ci_ax, 2);
       const int c0 = (ciz * gg.g + ciy) * gg.g + cix;
 
       // (1) seed: second-largest exact value among DISTINCT real objects --
@@ -429,9 +432,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
           const float gm = (float)(gg.g - 1);
           // the six bounds in six lanes of ONE instruction stream (lane l: axis l % 3, lower bound for
           // l < 3, upper bound otherwise) instead of six wave-uniform chains on the vector unit
-          const int ax = lane < 3 ? lane : lane - 3;
-          const float f = ax == 0 ? fx : ax == 1 ? fy : fz;
-          const int bound = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(lane < 3 ? f - r : f + r), 0.f), gm);
+          const int bound = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(lane < 3 ? f_ax - r : f_ax + r), 0.f), gm);
           ix0 = __builtin_amdgcn_readlane(bound, 0);
           iy0 = __builtin_amdgcn_readlane(bound, 1);
           iz0 = __builtin_amdgcn_readlane(bound, 2);
