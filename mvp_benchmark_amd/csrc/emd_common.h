@@ -156,8 +156,23 @@ __device__ __attribute__((noinline)) bool emd_precedes(int ka, int kb, int n, in
   return kka < kkb;
 }
 
+// Correctly rounded sqrtf -- the value the CPU's sqrtf gives, which the parity rests on.  hipcc expands
+// __builtin_sqrtf into {scale tiny inputs by 2^32, v_sqrt_f32 (1 ulp), one correction step with two
+// fused residuals, unscale, pass 0 / inf through}: 18 vector instructions + 5 wait states.  Squared
+// distances are never inf and practically never in (0, 2^-96), so the correction step alone (the same
+// one: identical results for x = 0 and x >= 2^-96) runs here, and a wave in which ANY lane holds such a
+// tiny positive input takes the compiler's full expansion instead.
+__device__ __forceinline__ float emd_sqrtf(float x) {
+  if (__builtin_expect(__any((__float_as_uint(x) - 1u) < 0x0F7FFFFFu), 0)) return __builtin_sqrtf(x);   // 0 < x < 2^-96
+  float r = __builtin_amdgcn_sqrtf(x);
+  const float rd = __int_as_float(__float_as_int(r) - 1), ru = __int_as_float(__float_as_int(r) + 1);
+  const float ed = __builtin_fmaf(-rd, r, x), eu = __builtin_fmaf(-ru, r, x);
+  r = ed <= 0.f ? rd : r;   // (x = 0: rd is a NaN pattern, ru the smallest denormal; both comparisons are false)
+  r = eu > 0.f ? ru : r;
+  return r;
+}
 __device__ __forceinline__ float emd_value(float s, float p) {
-  return (float)(3.0 - (double)__builtin_sqrtf(s) - (double)p);
+  return (float)(3.0 - (double)emd_sqrtf(s) - (double)p);
 }
 // the same value from the already rounded distance d = sqrtf(s)
 __device__ __forceinline__ float emd_value_d(float d, float p) {

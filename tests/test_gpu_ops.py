@@ -337,6 +337,25 @@ def test_emd_result_is_a_member_of_the_reference_outcome_set(kind):
         assert info[0]["racy_getmax_launches"] > 0
 
 
+def test_emd_tiny_squared_distances_take_the_full_sqrt_path(oracle):
+    """emd_value's square root is the correction step of the compiler's expansion, which is exact for 0 and for
+    x >= 2^-96; a wave that holds a squared distance in (0, 2^-96) -- points closer than 3.5e-15 without being
+    equal, only possible next to the origin -- must take the full expansion (scaling of denormal-range inputs).
+    A quarter of both clouds is put on a 1e-17-spaced lattice at the origin (squared distances of 1e-34 and
+    below, many of them denormal floats); assignment and distances still equal the CPU's sqrtf bit for bit."""
+    from mvp_benchmark_amd.metrics import emd
+    rng = np.random.default_rng(17)
+    x1, x2 = rand_clouds(301, 2, 1024, 3), rand_clouds(302, 2, 1024, 3)
+    x1[:, :256] = (rng.integers(0, 64, (2, 256, 3)) * 1e-17).astype(np.float32)
+    x2[:, :256] = (rng.integers(0, 64, (2, 256, 3)) * 1e-17).astype(np.float32)
+    d2 = ((x1[:, :256, None] - x2[:, None, :256]) ** 2).sum(-1)
+    assert ((d2 > 0) & (d2 < 2.0 ** -96)).any()
+    dist, ass = emd()(dev(x1), dev(x2), 0.005, 120)
+    od, oa = oracle.emd_forward(x1, x2, 0.005, 120)
+    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
 def test_emd_cluster_widths_agree_at_full_size(cluster_width):
     """16384 points, eval setting: 1 and 4 workgroups per cloud give identical
     assignments (the oracle needs minutes at this size)."""
