@@ -22,11 +22,27 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if _HERE not in sys.path:
-    sys.path.insert(0, _HERE)
 
-from model_utils import get_graph_feature, procrustes  # noqa: E402
-import train_utils as metrics  # noqa: E402
+
+def _sibling(name):
+    """registration/<name>.py under the private module name `registration_<name>`: completion/ has
+    files of the same names, and a process that already imported those (one test session, a tool
+    that touches both trees) must not get them here -- the reference imports them by bare name
+    after a sys.path edit (dcp.py:14-19), which only works in a process of its own."""
+    import importlib.util
+    full = "registration_" + name
+    if full in sys.modules:
+        return sys.modules[full]
+    spec = importlib.util.spec_from_file_location(full, os.path.join(_HERE, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_mu = _sibling("model_utils")
+get_graph_feature, procrustes = _mu.get_graph_feature, _mu.procrustes
+metrics = _sibling("train_utils")
 
 EMB_DIMS, FF_DIMS, HEADS, STACK_DEPTH = 512, 1024, 4, 1
 
