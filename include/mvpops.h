@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 8
+#define MVP_ABI_VERSION 9
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -115,7 +115,12 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * kernel of the same shape (csrc/emd_lean.hip) that takes a cloud over for the
  * rounds in which every workgroup has fewer bidders than four per wave (from
  * round ~100 on at 16384 points); it exits at once for clouds the first kernel
- * finished.
+ * finished.  With split = 2 (the default) and 33..64 clouds on four workgroups
+ * each, that second kernel stops before round 300 and a third launch runs the
+ * rest with the workgroups dealt out again: the clouds with the most persons
+ * still unassigned -- the ones whose rounds cost most -- get 8, the lightest 2
+ * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  Which workgroups serve a cloud
+ * never changes a bit of the result.
  * If a cluster wait is abandoned (members not co-resident for tens of seconds;
  * never seen) dist is filled with NaN, assignment with -1 and the statistics
  * word `rounds` is negative: the host wrapper checks for NaN lazily, and
@@ -129,8 +134,12 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  * negative argument leaves that knob unchanged.
  *   cluster     0 = automatic, or 1|2|4|8: cap of the workgroups per cloud
  *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
- *   split       1 (default): the tail rounds run in the second kernel;
- *               0: the first kernel runs every round
+ *   split       2 (default): the tail rounds run in the second kernel, from round
+ *               300 on with cluster widths by load (8 / 4 / 2 workgroups);
+ *               1: second kernel, fixed widths; 0: the first kernel runs every round
+ *               (environment, read once: MVP_EMD_PLAN_ROUND = 300, MVP_EMD_PLAN_HEAVY = 1
+ *               eighth of an XCD's clouds on 8 workgroups, MVP_EMD_PLAN_EVERY rounds
+ *               between re-plans, default: never again)
  * This is the library's only process-wide state.  Results never depend on it
  * (every setting is bit-identical: tests/test_gpu_ops.py). */
 int mvp_emd_configure(int cluster, int same_xcd, int split);

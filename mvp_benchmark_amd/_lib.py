@@ -53,10 +53,10 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 8   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 9   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
-EMD_DEFAULT_SPLIT = 1
+EMD_DEFAULT_SPLIT = 2
 
 _lib = None
 

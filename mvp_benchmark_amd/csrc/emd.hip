@@ -65,7 +65,8 @@ namespace mvp {
 
 // emd_lean.hip: the kernel that runs the one-bidder-per-wave rounds after the hand-over
 hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps,
-                           int iters, char *scratch, int fast_ok, hipStream_t stream);
+                           int iters, char *scratch, int fast_ok, int plan_round, int plan_every, int plan_heavy,
+                           hipStream_t stream);
 
 template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
@@ -1160,6 +1161,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             resume->cnt[wg] = cntw[wg];
             if (wg == 0) {
               resume->utot = Utot;
+              resume->nlists = W;
+              resume->first_it = it + 1;
               resume->next_it = it + 1;
               stats[0] = n_rounds;
             }
@@ -1322,6 +1325,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           if (s_err) resume->err = 1;
           resume->cnt[0] = Utot;
           resume->utot = Utot;
+          resume->nlists = 1;
+          resume->first_it = it + 1;
           resume->next_it = it + 1;
           stats[0] = n_rounds;
           atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
@@ -1436,14 +1441,18 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
 //                             in the lean kernel (emd_lean.hip); 0: one kernel runs every round
 // The results do not depend on any of them (bit-identical; tests/test_gpu_ops.py).
 struct EmdKnobs {
-  int cluster, same_xcd, split;
+  int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip)
+  int plan_round, plan_every, plan_heavy;   // split == 2: round of the first plan; rounds per planned launch; eighths of an XCD's clouds that get 8 workgroups
 };
 static EmdKnobs &emd_knobs() {
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 1};
+    EmdKnobs v{kMaxCluster, 1, 2, 300, 4096, 1};
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
-    if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) != 0;
+    if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
+    if (const char *e = getenv("MVP_EMD_PLAN_ROUND")) v.plan_round = atoi(e) < 1 ? 1 : atoi(e);
+    if (const char *e = getenv("MVP_EMD_PLAN_EVERY")) v.plan_every = atoi(e) < 64 ? 64 : atoi(e);
+    if (const char *e = getenv("MVP_EMD_PLAN_HEAVY")) v.plan_heavy = atoi(e) < 1 ? 1 : atoi(e);
     return v;
   }();
   return k;
@@ -1496,7 +1505,7 @@ extern "C" int mvp_emd_configure(int cluster, int same_xcd, int split) {
     k.cluster = cluster == 0 ? kMaxCluster : cluster;
   }
   if (same_xcd >= 0) k.same_xcd = same_xcd != 0;
-  if (split >= 0) k.split = split != 0;
+  if (split >= 0) k.split = split > 2 ? 2 : split;
   return MVP_OK;
 }
 
@@ -1534,7 +1543,8 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
     w = 1;
     (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, st);
   }
-  if (lean && emd_lean_launch(b, n, w, xyz1, dist, assignment, eps, iters, sbase, emd_knobs().same_xcd, st) != hipSuccess)
+  if (lean && emd_lean_launch(b, n, w, xyz1, dist, assignment, eps, iters, sbase, emd_knobs().same_xcd,
+                              emd_knobs().plan_round, emd_knobs().split == 2 ? emd_knobs().plan_every : 0, emd_knobs().plan_heavy, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
   return check_launch("mvp_emd_forward");
 }

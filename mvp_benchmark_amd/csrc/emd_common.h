@@ -78,7 +78,12 @@ struct EmdHandover {
   float lox, loy, loz, invh;
   int err;         // the first kernel's internal-error flag
   int cnt[kMaxCluster];   // entries of each member's list
+  int nlists;      // members that left a list (the cluster width of the kernel that wrote the record)
+  int epoch;       // barrier count of the launches so far (launches that share a set of granules go on counting)
+  int first_it;    // round of the FIRST hand-over (kept for the statistics; next_it returns to 0 when the cloud is done)
+  int last_width;  // cluster width of the launch that finished the cloud + 16 * that launch's granule set (1, 2)
 };
+static_assert(sizeof(EmdHandover) % 16 == 0, "the scratch tail stays 16-byte granular");
 
 __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
   // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg + cstart
@@ -86,17 +91,18 @@ __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
 }
 // After the per-cloud areas ("tail" of the scratch buffer, zeroed by the host
 // before the launch): 256 B of barrier granules per cloud for the first
-// kernel, 256 B per cloud for the lean kernel, the hand-over records, then the
-// per-cloud statistics {rounds, bids} (last: read by bench.py).
-constexpr size_t kEmdTailPerCloud = 256 + 256 + sizeof(EmdHandover) + 16;
+// kernel, 256 B per cloud for each of the lean kernel's two launches, the hand-over records, then
+// the per-cloud statistics {rounds, bids} (last: read by bench.py).
+constexpr int kEmdGranuleSets = 3;
+constexpr size_t kEmdTailPerCloud = 256 * kEmdGranuleSets + sizeof(EmdHandover) + 16;
 __host__ __device__ inline unsigned long long *emd_granules(char *tail, int b, int cloud, int which) {
   return reinterpret_cast<unsigned long long *>(tail + (size_t)which * b * 256 + (size_t)cloud * 256);
 }
 __host__ __device__ inline EmdHandover *emd_handover(char *tail, int b, int cloud) {
-  return reinterpret_cast<EmdHandover *>(tail + (size_t)b * 512) + cloud;
+  return reinterpret_cast<EmdHandover *>(tail + (size_t)b * 256 * kEmdGranuleSets) + cloud;
 }
 __host__ __device__ inline long long *emd_stats(char *tail, int b, int cloud) {
-  return reinterpret_cast<long long *>(tail + (size_t)b * (512 + sizeof(EmdHandover))) + 2 * (size_t)cloud;
+  return reinterpret_cast<long long *>(tail + (size_t)b * (256 * kEmdGranuleSets + sizeof(EmdHandover))) + 2 * (size_t)cloud;
 }
 
 __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
@@ -288,17 +294,19 @@ __device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
 // sc1 store and polled with sc1 loads: the data is the flag.  Slots are
 // double-buffered by epoch parity (a workgroup can be at most one epoch ahead
 // of the slowest reader).  Returns false when the wait was abandoned.
-template <int W, bool DRAIN = true>
-__device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned epoch,
-                                                   const int *p0, const int *p1,
-                                                   unsigned *s_gout, int *s_abort, bool same_xcd = false) {
+// (WM: the granule layout's width and the bound of the poll; W <= WM members take part --
+// W is a compile-time constant everywhere but in the lean kernel's planned launch)
+template <int WM, bool DRAIN = true>
+__device__ __forceinline__ bool emd_cluster_gather_n(u64 *slots, int W, int wg, unsigned epoch,
+                                                     const int *p0, const int *p1,
+                                                     unsigned *s_gout, int *s_abort, bool same_xcd = false) {
   // DRAIN = false: nothing stored since the last gather has to be visible to
   // the other workgroups before the NEXT draining gather
   if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x < kWave) {
     const int lane = threadIdx.x;
-    u64 *base = slots + (size_t)(epoch & 1u) * (2 * W);
+    u64 *base = slots + (size_t)(epoch & 1u) * (2 * WM);
     if (lane < 2) {
       const unsigned pv = (unsigned)(lane == 0 ? *p0 : *p1);
       if (same_xcd)  // the pollers share this XCD's L2: no need to write through
@@ -322,6 +330,12 @@ __device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned 
   }
   __syncthreads();
   return *s_abort == 0;
+}
+template <int W, bool DRAIN = true>
+__device__ __forceinline__ bool emd_cluster_gather(u64 *slots, int wg, unsigned epoch,
+                                                   const int *p0, const int *p1,
+                                                   unsigned *s_gout, int *s_abort, bool same_xcd = false) {
+  return emd_cluster_gather_n<W, DRAIN>(slots, W, wg, epoch, p0, p1, s_gout, s_abort, same_xcd);
 }
 
 template <int CTRL>

@@ -18,23 +18,57 @@ namespace mvp {
 
 constexpr int kLeanBid = 512;
 
-template <int W>
-__global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
-    int b, int bpad, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment,
-    float eps, int iters, char *scratch, int fast_ok) {
-  const int cloud = W == 1 ? (int)blockIdx.x : (int)blockIdx.x % bpad;
-  const int wg = W == 1 ? 0 : (int)blockIdx.x / bpad;
-  if (cloud >= b) return;
-  char *cbase = scratch + (size_t)cloud * emd_scratch_per_cloud(n);
-  char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
-  u64 *slots = emd_granules(tail, b, cloud, 1);   // this kernel's own granules (zeroed by the host)
-  EmdHandover *resume = emd_handover(tail, b, cloud);
-  long long *stats = emd_stats(tail, b, cloud);
-  const int it0 = resume->next_it;
-  if (it0 == 0) return;   // the cloud finished in the first kernel (uniform over the cluster)
+// The kernels' LDS, one object per kernel: the tiers kernel holds the round loop three times (one
+// instance per cluster width), all on the same memory.
+struct LeanShared {
+  // (order: what the round loop addresses with an immediate offset comes first -- a DS instruction's
+  // offset field covers 64 KB)
+  float4 c_lo[kMaxCells], c_hi[kMaxCells];
+  int s_cnt[2];
+  int s_next;
+  int s_err, s_abort, s_nchg, s_xcc;
+  int s_alarm[2];
+  unsigned s_gout[2 * kMaxCluster];
+  int c_start[kMaxCells + 1];
+  int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
+  float s_binc[kLeanBid];
+  int s_own_chg[kLeanBid];
+  float4 s_rq[2][kRecCap];
+  int4 s_ri[2][kRecCap];
+  unsigned short w_list[kEmdWaves][4 * kRowListCap];
+#ifdef MVP_EMD_PROFILE
+  int s_wbusy[kEmdWaves];
+  unsigned long long s_hist2[4];
+  float s_loose[2][3];
+  unsigned long long s_slow[2][8];
+  unsigned long long s_hist[16];
+#endif
+};
+
+// The remaining rounds of one cloud on a cluster of WB workgroups, of which this is member `wg`.
+// it_stop < iters: stop before round it_stop and leave the lists for the next launch, as the first
+// kernel left them for this one (`which`: the set of barrier granules this launch uses; launches
+// that share a set go on counting its barriers).  The previous launch's cluster may have
+// had another width: entry p of its lists' concatenation goes to member p % WB.  Which workgroups
+// serve a cloud does not change a bit of the result -- the auction state is in the scratch, the
+// bids of a round do not depend on each other or on their order.
+template <int WB>
+__device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, const int wg, int b,
+                                              int n, const float *__restrict__ xyz1, float *__restrict__ dist,
+                                              int *assignment, float eps, int iters, char *scratch, int fast_ok,
+                                              int it_stop, int which) {
+  constexpr int W = WB, WM = WB;
   const int t = threadIdx.x;
   const int lane = t & (kWave - 1);
   const int wave = t >> 6;
+  char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
+  if (cloud >= b) return;
+  char *cbase = scratch + (size_t)cloud * emd_scratch_per_cloud(n);
+  u64 *slots = emd_granules(tail, b, cloud, which);   // this launch's own granules (zeroed by the host)
+  EmdHandover *resume = emd_handover(tail, b, cloud);
+  long long *stats = emd_stats(tail, b, cloud);
+  const int it0 = resume->next_it;
+  if (it0 == 0 || it0 >= it_stop) return;   // finished already / not this launch's rounds (uniform over the cluster)
   xyz1 += (size_t)cloud * n * 3;
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
@@ -45,7 +79,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   // visible to the other workgroups once the store is acknowledged.
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, (int)emd_scratch_per_cloud(n), 0x00020000);
   auto ld_obj = [&](int s) -> float4 {
-    if constexpr (W == 1) {
+    if constexpr (WB == 1) {
       return sc.obj[s];
     } else {
       const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)s * 16u, 0, 16);
@@ -53,11 +87,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     }
   };
   auto ld_price = [&](int s) -> float {  // obj[s].w alone
-    if constexpr (W == 1) return sc.obj[s].w;
+    if constexpr (WB == 1) return sc.obj[s].w;
     else return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)s * 16u + 12u, 0, 16));
   };
   auto ld_ostate = [&](int s) -> int4 {
-    if constexpr (W == 1) {
+    if constexpr (WB == 1) {
       return sc.ostate[s];
     } else {
       const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((unsigned)n + (unsigned)s) * 16u, 0, 16);
@@ -65,7 +99,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     }
   };
   auto ld_person = [&](int j, int half) -> float4 {  // half 0 = lo, 1 = hi
-    if constexpr (W == 1) {
+    if constexpr (WB == 1) {
       return sc.person[2 * j + half];
     } else {
       const v4u v =
@@ -80,7 +114,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   // stays in L2 instead of being written through to memory and dropped.
   bool same_xcd = false;
   auto st_person_hi = [&](int j, int bid, int p1, int p2, float inc) {
-    if constexpr (W == 1) {
+    if constexpr (WB == 1) {
       sc.person[2 * j + 1] = make_float4(__int_as_float(bid), __int_as_float(p1), __int_as_float(p2), inc);
     } else {
       v4u v;
@@ -90,7 +124,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     }
   };
   auto st_ostate = [&](int s, int owner) {  // key = 0 (no bid), new owner
-    if constexpr (W == 1) {
+    if constexpr (WB == 1) {
       sc.ostate[s] = make_int4(0, 0, owner, 0);
     } else {
       v4u v;
@@ -100,48 +134,48 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     }
   };
   auto st_i32 = [&](int *p, int v) {
-    if constexpr (W == 1) *p = v;
+    if constexpr (WB == 1) *p = v;
     else if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto st_f32 = [&](float *p, float v) {
-    if constexpr (W == 1) *p = v;
+    if constexpr (WB == 1) *p = v;
     else if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto ld_key = [&](int s) -> u64 {
     u64 *p = reinterpret_cast<u64 *>(&sc.ostate[s]);
-    if constexpr (W == 1) return *p;
+    if constexpr (WB == 1) return *p;
     else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
 
-  __shared__ float4 c_lo[kMaxCells], c_hi[kMaxCells];
-  __shared__ int c_start[kMaxCells + 1];
-  __shared__ unsigned short w_list[kEmdWaves][4 * kRowListCap];  // surviving cells of a wave's search
-  __shared__ int s_cnt[2];
-  __shared__ int s_next;             // next undrawn list position of the round
-  __shared__ int s_err, s_abort, s_nchg, s_xcc;
-  __shared__ int s_alarm[2];  // by round parity: set in Bid, read after the barrier, cleared a round later
-  __shared__ unsigned s_gout[2 * kMaxCluster];
+  auto &c_lo = sh.c_lo; auto &c_hi = sh.c_hi;
+  auto &c_start = sh.c_start;
+  auto &w_list = sh.w_list;  // surviving cells of a wave's search
+  auto &s_cnt = sh.s_cnt;
+  auto &s_next = sh.s_next;             // next undrawn list position of the round
+  auto &s_err = sh.s_err; auto &s_abort = sh.s_abort; auto &s_nchg = sh.s_nchg; auto &s_xcc = sh.s_xcc;
+  auto &s_alarm = sh.s_alarm;  // by round parity: set in Bid, read after the barrier, cleared a round later
+  auto &s_gout = sh.s_gout;
 #ifdef MVP_EMD_PROFILE
-  __shared__ int s_wbusy[kEmdWaves];
-  __shared__ unsigned long long s_hist2[4];
+  auto &s_wbusy = sh.s_wbusy;
+  auto &s_hist2 = sh.s_hist2;
   if (threadIdx.x < 4) s_hist2[threadIdx.x] = 0;
-  __shared__ float s_loose[2][3];  // [slow][sum of (seed threshold - final threshold) in cell widths, sum of seed threshold, evicted (no bid last round) count]
+  auto &s_loose = sh.s_loose;  // [slow][sum of (seed threshold - final threshold) in cell widths, sum of seed threshold, evicted (no bid last round) count]
   if (threadIdx.x < 6) s_loose[threadIdx.x / 3][threadIdx.x % 3] = 0.f;
-  __shared__ unsigned long long s_slow[2][8];  // [d >= 10k cycles][count, nsub, cells, visit steps, extra member iterations, folds, seed cycles, visit cycles]
+  auto &s_slow = sh.s_slow;  // [d >= 10k cycles][count, nsub, cells, visit steps, extra member iterations, folds, seed cycles, visit cycles]
   if (threadIdx.x < 16) s_slow[threadIdx.x >> 3][threadIdx.x & 7] = 0;
-  __shared__ unsigned long long s_hist[16];  // bids: [0..7] duration buckets, [8] sum nsub, [9] sum cells visited, [10] count, [11] linear scans, [12] sum cycles
+  auto &s_hist = sh.s_hist;  // bids: [0..7] duration buckets, [8] sum nsub, [9] sum cells visited, [10] count, [11] linear scans, [12] sum cycles
   if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
 #endif
   // this round's bids, by list position
-  __shared__ int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
-  __shared__ float s_binc[kLeanBid];
-  __shared__ int s_own_chg[kLeanBid];   // cells whose cheapest member this workgroup's winners made dearer this round
+  auto &s_bj = sh.s_bj; auto &s_bo = sh.s_bo; auto &s_b2k = sh.s_b2k;
+  auto &s_binc = sh.s_binc;
+  auto &s_own_chg = sh.s_own_chg;   // cells whose cheapest member this workgroup's winners made dearer this round
   // person records {qx,qy,qz,-} / {j, prev1, prev2, -} of the current / next unassigned list
-  __shared__ float4 s_rq[2][kRecCap];
-  __shared__ int4 s_ri[2][kRecCap];
+  auto &s_rq = sh.s_rq;
+  auto &s_ri = sh.s_ri;
   static_assert(kLeanBid == kRecCap, "one LDS slot per list position");
 
   // ------------------------------------------------------------ resume
@@ -180,13 +214,23 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     c_hi[c] = make_float4(bx1, by1, bz1, c_start[c + 1] - c_start[c] > 16 ? 1.f : 0.f);
   }
   // this member's unassigned list, as the first kernel left it
-  int share = n / W;  // n % 1024 == 0
-  int first = wg * share;
   int *my_ulist = sc.ulist + (size_t)wg * 2 * n;
   {
-    const int cnt0 = resume->cnt[wg];
+    // The previous launch left `nlists` lists (its cluster width); entry p of their concatenation
+    // goes to member p % W of this cluster.
+    const int nl = resume->nlists;
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < kMaxCluster; ++w) total += w < nl ? resume->cnt[w] : 0;
+    const int cnt0 = total > wg ? (total - wg + W - 1) / W : 0;
     if (t < cnt0) {
-      const int k = my_ulist[t];
+      int p = wg + t * W, k = -1;
+#pragma unroll
+      for (int w = 0; w < kMaxCluster; ++w) {
+        const int cw = w < nl ? resume->cnt[w] : 0;
+        if (k < 0 && p >= 0 && p < cw) k = sc.ulist[(size_t)w * 2 * n + p];
+        p -= cw;
+      }
       const float4 pa = sc.person[2 * k], pb = sc.person[2 * k + 1];
       s_rq[0][t] = pa;
       s_ri[0][t] = make_int4(k, __float_as_int(pb.y), __float_as_int(pb.z), 0);
@@ -196,18 +240,18 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
       s_cnt[1] = 0;
     }
   }
-  unsigned epoch = 0;
-  if constexpr (W > 1) {
+  unsigned epoch = (unsigned)resume->epoch;   // (launches that share a set of granules go on counting; 0 after the first kernel)
+  if constexpr (WB != 1) {
     __syncthreads();
     if (t == 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       s_xcc = (int)(xcc & 0xFu) + 1;
     }
-    const bool ok = emd_cluster_gather<W>(slots, wg, ++epoch, &s_xcc, &s_xcc, s_gout, &s_abort);
+    const bool ok = emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_xcc, &s_xcc, s_gout, &s_abort);
     same_xcd = fast_ok != 0;
 #pragma unroll
-    for (int w = 1; w < W; ++w) same_xcd &= s_gout[2 * w] == s_gout[0];
+    for (int w = 1; w < WM; ++w) same_xcd &= w >= W || s_gout[2 * w] == s_gout[0];
     if (!ok) {
       if (wg == 0 && t == 0) stats[0] = -2;
       for (int j = t; j < n; j += kEmdThreads) {
@@ -229,12 +273,18 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   // workgroup bids for all of them in a single pass and the cluster's barriers
   // would only add latency: member 0 adopts the others' lists and carries on
   // alone (same code, workgroup barriers), the others leave.
-  bool clustered = W > 1;
+  bool clustered = WB != 1;
+  int stop_cnt = -1;   // >= 0: the loop ended at it_stop with this many entries in this member's next list
 #ifdef MVP_EMD_PROFILE
   long long prof_pg1 = 0, prof_drain = 0, prof_gather = 0, cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0, prof_a1 = 0, prof_an = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0;
 #endif
 #ifdef MVP_EMD_PROFILE
   const long long t_loop0 = __builtin_readcyclecounter();
+#endif
+#ifdef MVP_EMD_CLOUDTIME
+  const long long ct0 = wall_clock64();
+  int ct_u[6] = {0, 0, 0, 0, 0, 0};
+  long long ct_t[6] = {0, 0, 0, 0, 0, 0}, ct_b[6] = {0, 0, 0, 0, 0, 0};
 #endif
   for (int it = it0; it < iters; ++it) {
     if (Utot == 0) break;
@@ -242,6 +292,14 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     if (cloud == 0 && wg == 0 && t == 0 && (it == 25 || it == 50 || it == 100 || it == 150 || it == 250 || it == 500 || it == 750 ||
                                            it == 1000 || it == 1500 || it == 2000 || it == 2500 || it == iters - 1))
       printf("head cloud 0: round %d starts at %lld cycles, unassigned %d\n", it, __builtin_readcyclecounter() - t_loop0, Utot);
+#endif
+#ifdef MVP_EMD_CLOUDTIME
+    {
+      const int marks[6] = {150, 200, 300, 500, 1000, 2000};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        if (it == marks[q]) { ct_u[q] = Utot; ct_t[q] = wall_clock64() - ct0; ct_b[q] = n_bids; }
+    }
 #endif
     const int U = s_cnt[cur];  // this workgroup's bidders
     n_rounds += 1;
@@ -565,13 +623,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     if (clustered) {
       // The bids themselves are complete (their atomics have returned); the
       // bidders' hint records are only read after the next draining gather.
-      if (!emd_cluster_gather<W, false>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort, same_xcd)) {
+      if (!emd_cluster_gather_n<WM, false>(slots, W, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort, same_xcd)) {
         aborted = true;
         break;
       }
       any_alarm = false;
 #pragma unroll
-      for (int w = 0; w < W; ++w) any_alarm |= s_gout[2 * w] != 0u;
+      for (int w = 0; w < WM; ++w) any_alarm |= w < W && s_gout[2 * w] != 0u;
     } else {
       __syncthreads();
       any_alarm = *my_alarm != 0;
@@ -593,7 +651,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
           atomicMax(reinterpret_cast<u64 *>(&sc.ostate[o]), (key & 0xFFFFFFFF00000000ull) | (u64)((unsigned)j + 1u));
       }
       if (clustered) {
-        if (!emd_cluster_gather<W>(slots, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort, same_xcd)) {
+        if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort, same_xcd)) {
           aborted = true;
           break;
         }
@@ -700,7 +758,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const long long tpd = __builtin_readcyclecounter();
 #endif
-      if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort, same_xcd)) {
+      if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort, same_xcd)) {
         aborted = true;
         break;
       }
@@ -711,19 +769,24 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
 #endif
       Utot = 0;
       bool overflow = false;
-      int cntw[W], chgw[W];  // (the same for every lane: kept in scalar registers, the arithmetic on them is SALU work)
+      int cntw[WM], chgw[WM];  // (the same for every lane: kept in scalar registers, the arithmetic on them is SALU work)
 #pragma unroll
-      for (int w = 0; w < W; ++w) {
-        cntw[w] = __builtin_amdgcn_readfirstlane((int)s_gout[2 * w]);
-        chgw[w] = __builtin_amdgcn_readfirstlane((int)s_gout[2 * w + 1]);
+      for (int w = 0; w < WM; ++w) {
+        cntw[w] = w < W ? __builtin_amdgcn_readfirstlane((int)s_gout[2 * w]) : 0;
+        chgw[w] = w < W ? __builtin_amdgcn_readfirstlane((int)s_gout[2 * w + 1]) : 0;
         Utot += cntw[w];
         if (w != wg) overflow |= chgw[w] > kChgCap;
+      }
+      if (__builtin_expect(it + 1 == it_stop && it + 1 < iters && Utot > 0, 0)) {
+        // ---- this launch's last round: the lists are left for the next launch below the loop
+        stop_cnt = cntw[wg];
+        break;
       }
       if (__builtin_expect(Utot > 0 && Utot <= kSoloMax && it + 1 < iters, 0)) {
         // ---- hand everything to member 0 (lists of <= kSoloMax persons live
         // in LDS only: publish the person ids; their records are in memory)
         if (wg != 0 && t < cntw[wg]) st_i32(my_ulist + t, s_ri[nxt][t].x);
-        if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
+        if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
           aborted = true;
           break;
         }
@@ -733,7 +796,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
         }
         int idx = t;
 #pragma unroll
-        for (int w = 1; w < W; ++w) {
+        for (int w = 1; w < WM; ++w) {
           if (idx >= 0 && idx < cntw[w]) {
             const int jj = __hip_atomic_load(sc.ulist + (size_t)w * 2 * n + idx, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
@@ -746,8 +809,6 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
           idx -= cntw[w];
         }
         clustered = false;
-        first = 0;
-        share = n;
         if (t == 0) s_nchg = 0;
         __syncthreads();
       } else {
@@ -759,17 +820,17 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
         // counts; the ids travel through the donors' dead current lists.
         int maxc = 0;
 #pragma unroll
-        for (int w = 0; w < W; ++w) maxc = max(maxc, cntw[w]);
+        for (int w = 0; w < WM; ++w) maxc = max(maxc, cntw[w]);
         const int even = (Utot + W - 1) / W;
         const int cap = (even + 15) / 16 * 16;
         if (__builtin_expect(maxc > cap && it + 1 < iters, 0)) {
           const int base = Utot / W, rem = Utot % W;
-          int exc[W], dfc[W], exoff = 0, dfoff = 0, my_exoff = 0, my_dfoff = 0;
+          int exc[WM], dfc[WM], exoff = 0, dfoff = 0, my_exoff = 0, my_dfoff = 0;
 #pragma unroll
-          for (int w = 0; w < W; ++w) {
+          for (int w = 0; w < WM; ++w) {
             const int tgt = base + (w < rem ? 1 : 0);
-            exc[w] = max(0, cntw[w] - tgt);
-            dfc[w] = max(0, tgt - cntw[w]);
+            exc[w] = w < W ? max(0, cntw[w] - tgt) : 0;
+            dfc[w] = w < W ? max(0, tgt - cntw[w]) : 0;
             if (w == wg) { my_exoff = exoff; my_dfoff = dfoff; }
             exoff += exc[w];
             dfoff += dfc[w];
@@ -781,14 +842,14 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
             const int pos = my_cnt - my_exc + i;
             st_i32(dead + i, s_ri[nxt][pos].x);
           }
-          if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
+          if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
             aborted = true;
             break;
           }
           for (int i = t; i < my_dfc; i += kEmdThreads) {
             int p = my_dfoff + i, jj = -1;   // p-th entry of the pool = donors' surpluses in order
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
+            for (int w = 0; w < WM; ++w) {
               if (p >= 0 && p < exc[w])
                 jj = __hip_atomic_load(sc.ulist + (size_t)w * 2 * n + (size_t)cur * n + p, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
@@ -822,7 +883,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
         idx -= own_cnt;
         // (also in the round the cluster collapses to member 0: the others' last reports count)
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
+        for (int w = 0; w < WM; ++w) {
           if (w == wg) continue;
           const int cnt = min(chgw[w], kChgCap);
           if (cell < 0 && idx >= 0 && idx < cnt)
@@ -853,6 +914,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     } else {
       __syncthreads();
       Utot = s_cnt[nxt];
+      if (__builtin_expect(it + 1 == it_stop && it + 1 < iters && Utot > 0, 0)) {   // (member 0 alone)
+        stop_cnt = Utot;
+        break;
+      }
       {
         const int own_cnt = min(s_nchg, kLeanBid);
         __syncthreads();
@@ -881,11 +946,45 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   if (clustered && !aborted) {  // cost of the bare all-gather
     const long long tg0 = __builtin_readcyclecounter();
     for (int g = 0; g < 256; ++g)
-      if (!emd_cluster_gather<W>(slots, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) break;
+      if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) break;
     if (t == 0 && cloud < 2 && wg == 0)
       printf("cloud %d: bare cluster all-gather %lld cycles each (W = %d, same_xcd %d)\n", cloud,
              (__builtin_readcyclecounter() - tg0) / 256, W, (int)same_xcd);
   }
+#endif
+  if (stop_cnt >= 0) {
+    // ---- stopped before round it_stop: leave the lists for the next launch, as the first kernel
+    // left them for this one (the prices, owners and bid hints are in the scratch already).  The
+    // record's address is derived again here (from a value the compiler cannot trace back) so that
+    // nothing of it stays in registers through the round loop.
+    int cloud2 = cloud;
+    asm volatile("" : "+s"(cloud2));
+    char *tail2 = scratch + (size_t)b * emd_scratch_per_cloud(n);
+    EmdHandover *rs = emd_handover(tail2, b, cloud2);
+    long long *st2 = emd_stats(tail2, b, cloud2);
+    int *ul2 = emd_carve(scratch + (size_t)cloud2 * emd_scratch_per_cloud(n), n).ulist + (size_t)wg * 2 * n;
+    const int nx = cur ^ 1;
+    if (t < stop_cnt) ul2[t] = s_ri[nx][t].x;
+    if (t == 0) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&st2[1]), (unsigned long long)n_bids);
+      if (s_err) rs->err = 1;
+      rs->cnt[wg] = stop_cnt;
+#ifdef MVP_EMD_CLOUDTIME
+      if (wg == 0) sc.chg[(size_t)kMaxCluster * kChgCap - 64 + (it_stop >> 6)] = ((u64)W << 48) | ((u64)Utot << 32) | (u64)(unsigned)(wall_clock64() - ct0);
+#endif
+      if (wg == 0) {
+        rs->utot = Utot;
+        rs->nlists = clustered ? W : 1;
+        rs->epoch = (int)epoch;
+        rs->next_it = it_stop;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&st2[0]), (unsigned long long)n_rounds);
+      }
+    }
+    return;
+  }
+#ifdef MVP_EMD_CLOUDTIME
+  if (wg == 0 && t == 0)   // 100 MHz constant clock
+    sc.chg[(size_t)kMaxCluster * kChgCap - 64 + 63] = ((u64)W << 48) | (u64)(unsigned)(wall_clock64() - ct0);
 #endif
   if (aborted) {
     // A cluster wait ran into its bound (the members were not co-resident for
@@ -899,7 +998,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   }
   if (t == 0) {
     // rounds: added to the first kernel's count; an internal error drives the sum far below zero
-    if (wg == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)n_rounds);
+    if (wg == 0) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)n_rounds);
+      resume->next_it = 0;   // finished: nothing for a later launch
+      resume->last_width = W + 16 * which;   // (which: 1 = the launch after the first kernel, 2 = the tiered launch)
+    }
     if (s_err) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)(-(1ll << 40)));
     atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
 #ifdef MVP_EMD_PROFILE
@@ -935,9 +1038,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   }
   // ---------------- CalcDist (emd_cuda.cu:217-226); slots -> object indices
   __syncthreads();
-  for (int j = first + t; j < first + share; j += kEmdThreads) {
+  // CalcDist: member w takes the blocks w, w + W, ... of 1024 persons (a collapsed cluster: member 0 all)
+  for (int j = (clustered ? wg : 0) * kEmdThreads + t; j < n; j += (clustered ? W : 1) * kEmdThreads) {
     int s;
-    if constexpr (W == 1) s = ass[j];
+    if constexpr (WB == 1) s = ass[j];
     else s = __hip_atomic_load(&ass[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float4 o = sc.obj[s];  // coordinates never change
     const float dx = xyz1[j * 3 + 0] - o.x;
@@ -948,29 +1052,95 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   }
 }
 
-template <int W>
+// Every cloud on a cluster of WT workgroups (grid WT * bpad, laid out as the first kernel's).
+template <int WT>
+__global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
+    int b, int bpad, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment,
+    float eps, int iters, char *scratch, int fast_ok, int it_stop, int which) {
+  __shared__ LeanShared sh;
+  const int cloud = WT == 1 ? (int)blockIdx.x : (int)blockIdx.x % bpad;
+  const int wg = WT == 1 ? 0 : (int)blockIdx.x / bpad;
+  emd_lean_body<WT>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
+}
+
+// TIERED widths (grid 4 * bpad, 24 <= bpad <= 64).  The clouds' rounds differ in cost -- a cloud with
+// more unassigned persons places more bids per round, for all 3000 rounds: +-25 % in time
+// (profiles/r3_emd_cloud_times.txt) -- and a launch lasts as long as its slowest cloud.  The number
+// of persons still unassigned at round 300 predicts the time the rest takes (correlation 0.96), so
+// the clouds are ranked by it and, per XCD, the `heavy` heaviest get 8 workgroups, the 2 * heavy
+// lightest 2, the others 4.  A cluster lives inside one XCD (its members' plain stores meet in that
+// XCD's L2): workgroup blockIdx is on XCD blockIdx % 8 (dispatch order; checked by the members'
+// first gather as in the other launches).
+__global__ __launch_bounds__(kEmdThreads) void emd_lean_tiers_kernel(
+    int b, int bpad, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment,
+    float eps, int iters, char *scratch, int fast_ok, int it_stop, int which, int heavy) {
+  __shared__ LeanShared sh;
+  const int lane = threadIdx.x & (kWave - 1);
+  char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
+  const int x = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;   // XCD, index inside it
+  const int c = bpad >> 3;                                          // clouds per XCD
+  const int n8 = 8 * heavy, n4 = 4 * (c - 3 * heavy);
+  int W, slot, wg;
+  if (q < n8) { W = 8; slot = q >> 3; wg = q & 7; }
+  else if (q < n8 + n4) { W = 4; slot = heavy + ((q - n8) >> 2); wg = (q - n8) & 3; }
+  else { W = 2; slot = c - 2 * heavy + ((q - n8 - n4) >> 1); wg = (q - n8 - n4) & 1; }
+  const int rank_wanted = slot * 8 + x;   // ranks 0..7: the heaviest cloud of each XCD, 8..15 the next, ...
+  // every workgroup ranks the clouds itself, from the same 64 words: unassigned persons (0: finished), ties by index
+  int key = -1;
+  if (lane < bpad) {
+    const EmdHandover *h = emd_handover(tail, b, lane < b ? lane : 0);
+    key = lane < b ? ((h->next_it ? h->utot : 0) << 8) | (255 - lane) : (255 - lane) - 65536;
+  }
+  int rank = 0;
+  for (int o = 0; o < bpad; ++o) rank += __builtin_amdgcn_readlane(key, o) > key ? 1 : 0;
+  const unsigned long long hit = __ballot(lane < bpad && rank == rank_wanted);
+  const int cloud = hit ? __builtin_ctzll(hit) : b;
+  if (W == 8) emd_lean_body<8>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
+  else if (W == 4) emd_lean_body<4>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
+  else emd_lean_body<2>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
+}
+
+template <int WT>
 static hipError_t emd_lean_launch_w(int b, int n, const float *xyz1, float *dist, int *assignment, float eps,
-                                    int iters, char *scratch, int fast_ok, hipStream_t stream) {
-  int bpad = W == 1 ? b : (b + 7) / 8 * 8;
-  if (W == 1) {
+                                    int iters, char *scratch, int fast_ok, int it_stop, int which,
+                                    hipStream_t stream) {
+  int bpad = WT == 1 ? b : (b + 7) / 8 * 8;
+  if (WT == 1) {
     hipLaunchKernelGGL(emd_lean_kernel<1>, dim3(b), dim3(kEmdThreads), 0, stream, b, bpad, n, xyz1, dist,
-                       assignment, eps, iters, scratch, 0);
+                       assignment, eps, iters, scratch, 0, it_stop, which);
     return hipSuccess;
   }
-  void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok};
-  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_kernel<W>), dim3(W * bpad),
+  void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &it_stop, &which};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_kernel<WT>), dim3(WT * bpad),
                                     dim3(kEmdThreads), args, 0, stream);
 }
 
-// Runs the rounds the first kernel handed over, with the cluster width `w` the first kernel ran
-// with (the lists are per member).  Clouds that were not handed over exit at once.
+// Runs the rounds the first kernel handed over.  Clouds that were not handed over exit at once.
+// plan_every = 0: one launch with the cluster width `w` the first kernel ran with.  Otherwise (and
+// w = 4, 24 <= b <= 64, enough rounds): that width up to round `plan_round`, then launches of
+// `plan_every` rounds each with TIERED widths (emd_lean_tiers_kernel; about plan_heavy eighths of an
+// XCD's clouds get 8 workgroups).
 hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps,
-                           int iters, char *scratch, int fast_ok, hipStream_t stream) {
-  if (w == 8) return emd_lean_launch_w<8>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, stream);
-  if (w == 4) return emd_lean_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, stream);
-  if (w == 2) return emd_lean_launch_w<2>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, stream);
-  return emd_lean_launch_w<1>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, stream);
+                           int iters, char *scratch, int fast_ok, int plan_round, int plan_every, int plan_heavy,
+                           hipStream_t stream) {
+  int bpad = (b + 7) / 8 * 8;
+  int heavy = ((bpad / 8) * plan_heavy + 4) / 8;   // b = 64: plan_heavy of the 8 clouds of an XCD
+  if (w == 4 && b >= 32 && b <= 64 && plan_every > 0 && heavy >= 1 && 3 * heavy <= bpad / 8 && iters >= plan_round + 256) {
+    hipError_t e = emd_lean_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, plan_round, 1, stream);
+    for (int r = plan_round; e == hipSuccess && r < iters; r += plan_every) {
+      int stop = r + plan_every + 256 > iters ? iters : r + plan_every;   // (no short last launch)
+      int which = 2;
+      void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &stop, &which, &heavy};
+      e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_tiers_kernel), dim3(4 * bpad),
+                                     dim3(kEmdThreads), args, 0, stream);
+      if (stop == iters) break;
+    }
+    return e;
+  }
+  if (w == 8) return emd_lean_launch_w<8>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream);
+  if (w == 4) return emd_lean_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream);
+  if (w == 2) return emd_lean_launch_w<2>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream);
+  return emd_lean_launch_w<1>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream);
 }
 
 }  // namespace mvp
-

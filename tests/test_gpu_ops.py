@@ -176,7 +176,8 @@ def cluster_width():
 @pytest.fixture
 def emd_split():
     """Selects whether the tail rounds run in the lean second kernel (mvp_emd_configure(split));
-    default restored afterwards."""
+    0: never; 1: yes, fixed cluster widths; 2: yes, widths dealt out again at round 300 when the batch
+    allows it); default restored afterwards."""
     from mvp_benchmark_amd import _lib
     yield lambda split: _lib.emd_configure(split=split)
     _lib.emd_configure(split=_lib.EMD_DEFAULT_SPLIT)
@@ -277,15 +278,16 @@ def test_emd_second_kernel_really_runs(emd_split):
         _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
         torch.cuda.synchronize()
         stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()
-        # hand-over records: b records of 16 ints right before the statistics
-        rec = scratch[nbytes - b * 16 - b * 64: nbytes - b * 16].view(torch.int32).view(b, 16).cpu().numpy()
+        # hand-over records: b records of 20 ints right before the statistics ([18]: round of the first hand-over)
+        rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()
         out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), stats, rec)
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2], out[1][2])          # same rounds, same bids
-    assert (out[0][3][:, 0] == 0).all()                           # split off: nothing handed over
-    assert (out[1][3][:, 0] > 0).all() and (out[1][3][:, 0] < 1500).all()   # split on: round of the hand-over
+    assert (out[0][3][:, 18] == 0).all()                          # split off: nothing handed over
+    assert (out[1][3][:, 18] > 0).all() and (out[1][3][:, 18] < 1500).all()   # split on: round of the hand-over
     assert (out[1][3][:, 1] <= 384).all()
+    assert (out[1][3][:, 0] == 0).all() and (out[1][3][:, 19] == 16 + 8).all()   # finished, by the clusters of 8 a batch of 2 gets
 
 
 def test_emd_headline_cloud_matches_oracle(oracle, emd_split):
@@ -296,23 +298,74 @@ def test_emd_headline_cloud_matches_oracle(oracle, emd_split):
     from mvp_benchmark_amd.metrics import emd
     x1, x2 = rand_clouds(41, 2, 16384, 3), rand_clouds(42, 2, 16384, 3)
     od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
-    for split in (1, 0):
+    for split in (2, 0):
         emd_split(split)
         dist, ass = emd()(dev(x1), dev(x2), 0.004, 3000)
         np.testing.assert_array_equal(ass.cpu().numpy(), oa)
         np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
-def test_emd_cfg4_full_batch_matches_oracle(oracle):
+@pytest.mark.parametrize("b,split", [(64, 2), (64, 1), (61, 2), (40, 2), (33, 2)])
+def test_emd_cfg4_full_batch_matches_oracle(oracle, emd_split, b, split):
     """BASELINE cfg 4 at its FULL batch: 64 clouds of 1024 points, eval setting (eps 0.004,
     3000 rounds), every cloud against the oracle (cfg 4 was only ever compared at
-    B <= 3 below the headline size).  64 clouds -> four workgroups per cloud."""
-    from mvp_benchmark_amd.metrics import emd
-    x1, x2 = rand_clouds(91, 64, 1024, 3), rand_clouds(92, 64, 1024, 3)
-    dist, ass = emd()(dev(x1), dev(x2), 0.004, 3000)
+    B <= 3 below the headline size).  33..64 clouds -> four workgroups per cloud, and with
+    split = 2 the workgroups are dealt out again at round 300 (8 / 4 / 2 per cloud by the number of
+    persons still unassigned; 61 and 33 clouds leave some of the grid's cloud slots empty): the
+    hand-over records must show that launch's widths, the results the oracle's bits."""
+    from mvp_benchmark_amd import _lib
+    emd_split(split)
+    x1, x2 = rand_clouds(91, 64, 1024, 3)[:b], rand_clouds(92, 64, 1024, 3)[:b]
+    nbytes = _lib.emd_scratch_bytes(b, 1024)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    dist = torch.zeros(b, 1024, device=DEV)
+    ass = torch.zeros(b, 1024, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_emd_forward", DEV, b, 1024, dev(x1), dev(x2), dist, ass, 0.004, 3000, scratch, nbytes)
+    torch.cuda.synchronize()
     od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
     np.testing.assert_array_equal(ass.cpu().numpy(), oa)
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
+    rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()
+    assert (rec[:, 0] == 0).all()                                   # every cloud finished
+    running = rec[:, 18] > 0                                        # handed over at all (else: done in the first kernel)
+    tiered = running & ((rec[:, 19] >> 4) == 2)                     # finished by the tiered launch (still running at round 300)
+    assert set((rec[running & ~tiered, 19] & 15).tolist()) <= {4}
+    if split == 2:
+        assert set((rec[tiered, 19] & 15).tolist()) <= {2, 4, 8}
+    else:
+        assert tiered.sum() == 0
+
+
+def test_emd_tiered_widths_match_the_single_kernel(emd_split):
+    """64 clouds of 4096 points: most are still running at round 300, where the default (split = 2)
+    deals the 256 workgroups out again -- per XCD the heaviest cloud gets 8, the two lightest 2, the
+    other five 4.  Same bits as the first kernel running every round alone (which the tests above
+    pin to the oracle at this size), same statistics, and the records show the three widths."""
+    from mvp_benchmark_amd import _lib
+    b, n = 64, 4096
+    x1, x2 = dev(rand_clouds(95, b, n, 3)), dev(rand_clouds(96, b, n, 3))
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    out = {}
+    for split in (0, 2):
+        emd_split(split)
+        scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        dist = torch.zeros(b, n, device=DEV)
+        ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+        _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
+        torch.cuda.synchronize()
+        stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()
+        rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()
+        out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), stats, rec)
+    np.testing.assert_array_equal(out[0][0], out[2][0])
+    np.testing.assert_array_equal(out[0][1], out[2][1])
+    np.testing.assert_array_equal(out[0][2], out[2][2])          # same rounds, same bids
+    rec = out[2][3]
+    tiered = (rec[:, 19] >> 4) == 2
+    assert tiered.sum() >= 48, rec[:, 19]
+    w = rec[tiered, 19] & 15
+    assert (w == 8).sum() == 8 and (w == 2).sum() <= 16 and (w == 4).sum() >= 24, np.bincount(w)
+    # the eight clouds on 8 workgroups are the ones with the most persons unassigned at round 300
+    assert rec[tiered][w == 8][:, 1].min() >= rec[tiered][w == 4][:, 1].max()
 
 
 @pytest.mark.parametrize("kind", ["random", "tie_heavy"])

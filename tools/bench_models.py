@@ -13,6 +13,8 @@ if "MVP_MFMA_TRAIN" in os.environ:                       # A/B of the training-p
 if "MVP_MFMA_WGRAD_TRAIN" in os.environ:                 # A/B: only the weight gradients leave the library
     pw.MFMA_WGRAD_TRAIN = os.environ["MVP_MFMA_WGRAD_TRAIN"] == "1"
 REPS = int(os.environ.get("MVP_BENCH_REPS", "10"))
+if os.environ.get("MVP_CUDNN_BENCHMARK") == "1":          # A/B: MIOpen picks its convolution solvers by measuring them
+    torch.backends.cudnn.benchmark = True
 
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
@@ -49,6 +51,8 @@ for name in ("vrcnet", "ecg"):
         _, _, loss = net(partial, gt, alpha=0.5)
         loss.backward()
         opt.step()
+    if torch.backends.cudnn.benchmark:
+        for _ in range(3): step()       # the solver search happens in the first steps
     ms = timed(step)
-    print("%s train step (batch 32, 2048 pts, MFMA_TRAIN=%s, MFMA_WGRAD_TRAIN=%s): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
-        name, pw.MFMA_TRAIN, pw.MFMA_WGRAD_TRAIN, ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
+    print("%s train step (batch 32, 2048 pts, MFMA_TRAIN=%s, MFMA_WGRAD_TRAIN=%s%s): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
+        name, pw.MFMA_TRAIN, pw.MFMA_WGRAD_TRAIN, ", solver search on" if torch.backends.cudnn.benchmark else "", ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
