@@ -385,9 +385,10 @@ def run_eval(args, rank, world, dev):
         # latency of its dependent bid chain, hence bound = "latency" and the
         # issue-side roof next to it
         # kernel: one mvp_emd_forward call = emd_auction_kernel (the rounds with four bidders per wave,
-        # ~100 of 3000) followed by emd_lean_kernel (the rest); the events bracket the call, the
-        # rocprofv3 kernel trace lists the two durations, whose sum must agree
-        "roofline": {"kernel": "emd_auction_kernel + emd_lean_kernel (one mvp_emd_forward)", "bound": "latency", "achieved": achieved,
+        # ~100 of 3000), emd_lean_kernel (to round 300) and emd_lean_tiers_kernel (the rest, cluster
+        # widths by load); the events bracket the call, the rocprofv3 kernel trace lists the three
+        # durations, whose sum must agree
+        "roofline": {"kernel": "emd_auction_kernel + emd_lean_kernel + emd_lean_tiers_kernel (one mvp_emd_forward)", "bound": "latency", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "issue": issue,
                      "us_per_round": emd_ms * 1e3 / max(rounds, 1)},

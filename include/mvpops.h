@@ -115,8 +115,8 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * kernel of the same shape (csrc/emd_lean.hip) that takes a cloud over for the
  * rounds in which every workgroup has fewer bidders than four per wave (from
  * round ~100 on at 16384 points); it exits at once for clouds the first kernel
- * finished.  With split = 2 (the default) and 33..64 clouds on four workgroups
- * each, that second kernel stops before round 300 and a third launch runs the
+ * finished.  With split = 2 (the default), 33..64 clouds of at least 4096 points on
+ * four workgroups each, that second kernel stops before round 300 and a third launch runs the
  * rest with the workgroups dealt out again: the clouds with the most persons
  * still unassigned -- the ones whose rounds cost most -- get 8, the lightest 2
  * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  Which workgroups serve a cloud

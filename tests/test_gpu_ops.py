@@ -309,10 +309,9 @@ def test_emd_headline_cloud_matches_oracle(oracle, emd_split):
 def test_emd_cfg4_full_batch_matches_oracle(oracle, emd_split, b, split):
     """BASELINE cfg 4 at its FULL batch: 64 clouds of 1024 points, eval setting (eps 0.004,
     3000 rounds), every cloud against the oracle (cfg 4 was only ever compared at
-    B <= 3 below the headline size).  33..64 clouds -> four workgroups per cloud, and with
-    split = 2 the workgroups are dealt out again at round 300 (8 / 4 / 2 per cloud by the number of
-    persons still unassigned; 61 and 33 clouds leave some of the grid's cloud slots empty): the
-    hand-over records must show that launch's widths, the results the oracle's bits."""
+    B <= 3 below the headline size).  33..64 clouds -> four workgroups per cloud; clouds this small
+    are not dealt out again at round 300 whatever `split` says (the records show it); the tiered
+    launch is compared with the oracle at 4096 points below."""
     from mvp_benchmark_amd import _lib
     emd_split(split)
     x1, x2 = rand_clouds(91, 64, 1024, 3)[:b], rand_clouds(92, 64, 1024, 3)[:b]
@@ -330,10 +329,42 @@ def test_emd_cfg4_full_batch_matches_oracle(oracle, emd_split, b, split):
     running = rec[:, 18] > 0                                        # handed over at all (else: done in the first kernel)
     tiered = running & ((rec[:, 19] >> 4) == 2)                     # finished by the tiered launch (still running at round 300)
     assert set((rec[running & ~tiered, 19] & 15).tolist()) <= {4}
-    if split == 2:
-        assert set((rec[tiered, 19] & 15).tolist()) <= {2, 4, 8}
-    else:
-        assert tiered.sum() == 0
+    assert tiered.sum() == 0
+
+
+@pytest.mark.parametrize("b", [33, 40, 61])
+def test_emd_tiered_widths_ragged_batches_match_oracle(oracle, b):
+    """The tiered launch with cloud slots left empty (33, 40, 61 clouds in grids laid out for 40 / 40 /
+    64): all clouds equal the first kernel alone, six of them (the heaviest, the lightest, four
+    others) the exhaustive oracle.  4096 points: ~4 s of CPU per cloud."""
+    from mvp_benchmark_amd import _lib
+    n = 4096
+    x1n, x2n = rand_clouds(97, b, n, 3), rand_clouds(98, b, n, 3)
+    x1, x2 = dev(x1n), dev(x2n)
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    out = {}
+    try:
+        for split in (0, 2):
+            _lib.emd_configure(split=split)
+            scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+            dist = torch.zeros(b, n, device=DEV)
+            ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+            _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
+            torch.cuda.synchronize()
+            rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()
+            out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), rec)
+    finally:
+        _lib.emd_configure(split=_lib.EMD_DEFAULT_SPLIT)
+    np.testing.assert_array_equal(out[0][0], out[2][0])
+    np.testing.assert_array_equal(out[0][1], out[2][1])
+    rec = out[2][2]
+    tiered = (rec[:, 19] >> 4) == 2
+    assert tiered.sum() >= b - 8 and set((rec[tiered, 19] & 15).tolist()) == {2, 4, 8}, rec[:, 19]
+    order = np.argsort(rec[:, 1])
+    pick = sorted(set([int(order[0]), int(order[-1]), 1, b // 3, b // 2, b - 2]))
+    od, oa = oracle.emd_forward(x1n[pick], x2n[pick], 0.004, 3000)
+    np.testing.assert_array_equal(out[2][1][pick], oa)
+    np.testing.assert_array_equal(out[2][0][pick], od)
 
 
 def test_emd_tiered_widths_match_the_single_kernel(emd_split):
