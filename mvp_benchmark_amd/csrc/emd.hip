@@ -65,8 +65,8 @@ namespace mvp {
 
 // emd_lean.hip: the kernel that runs the one-bidder-per-wave rounds after the hand-over
 hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps,
-                           int iters, char *scratch, int fast_ok, int plan_round, int plan_every, int plan_heavy,
-                           hipStream_t stream);
+                           int iters, char *scratch, int fast_ok, int plan_round, int plan_every,
+                           unsigned long long plan_widths, hipStream_t stream);
 
 template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
@@ -1442,17 +1442,27 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
 // The results do not depend on any of them (bit-identical; tests/test_gpu_ops.py).
 struct EmdKnobs {
   int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip)
-  int plan_round, plan_every, plan_heavy;   // split == 2: round of the first plan; rounds per planned launch; eighths of an XCD's clouds that get 8 workgroups
+  int plan_round, plan_every;     // split == 2: round of the first plan; rounds per planned launch
+  unsigned long long plan_widths; // widths of an XCD's 8 cloud slots, heaviest first, 4 bits each
 };
 static EmdKnobs &emd_knobs() {
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 2, 300, 4096, 1};
+    EmdKnobs v{kMaxCluster, 1, 2, 300, 4096, 0x23334458ull};   // 8,5,4,4,3,3,3,2 (profiles/r3_emd_cloud_times.txt)
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
     if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_ROUND")) v.plan_round = atoi(e) < 1 ? 1 : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_EVERY")) v.plan_every = atoi(e) < 64 ? 64 : atoi(e);
-    if (const char *e = getenv("MVP_EMD_PLAN_HEAVY")) v.plan_heavy = atoi(e) < 1 ? 1 : atoi(e);
+    if (const char *e = getenv("MVP_EMD_PLAN_WIDTHS")) {   // e.g. 8,6,4,4,3,3,2,2
+      unsigned long long pat = 0ull;
+      int s = 0;
+      for (const char *q = e; *q && s < 16; ++s) {
+        pat |= (unsigned long long)(atoi(q) & 15) << (4 * s);
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+      v.plan_widths = pat;
+    }
     return v;
   }();
   return k;
@@ -1544,7 +1554,7 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
     (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, st);
   }
   if (lean && emd_lean_launch(b, n, w, xyz1, dist, assignment, eps, iters, sbase, emd_knobs().same_xcd,
-                              emd_knobs().plan_round, emd_knobs().split == 2 ? emd_knobs().plan_every : 0, emd_knobs().plan_heavy, st) != hipSuccess)
+                              emd_knobs().plan_round, emd_knobs().split == 2 ? emd_knobs().plan_every : 0, emd_knobs().plan_widths, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
   return check_launch("mvp_emd_forward");
 }

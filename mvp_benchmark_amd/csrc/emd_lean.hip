@@ -1063,28 +1063,30 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
   emd_lean_body<WT>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
 }
 
-// TIERED widths (grid 4 * bpad, 24 <= bpad <= 64).  The clouds' rounds differ in cost -- a cloud with
+// TIERED widths (grid 4 * bpad, 40 <= bpad <= 64).  The clouds' rounds differ in cost -- a cloud with
 // more unassigned persons places more bids per round, for all 3000 rounds: +-25 % in time
 // (profiles/r3_emd_cloud_times.txt) -- and a launch lasts as long as its slowest cloud.  The number
 // of persons still unassigned at round 300 predicts the time the rest takes (correlation 0.96), so
-// the clouds are ranked by it and, per XCD, the `heavy` heaviest get 8 workgroups, the 2 * heavy
-// lightest 2, the others 4.  A cluster lives inside one XCD (its members' plain stores meet in that
-// XCD's L2): workgroup blockIdx is on XCD blockIdx % 8 (dispatch order; checked by the members'
-// first gather as in the other launches).
+// the clouds are ranked by it and dealt out to the XCDs (ranks 0..7: the heaviest cloud of each XCD,
+// 8..15 the next, ...); `pattern` holds the widths of an XCD's cloud slots, heaviest first, 4 bits
+// each (e.g. 8,4,4,4,4,4,2,2), their sum = the XCD's 4 * bpad / 8 workgroups.  A cluster lives inside
+// one XCD (its members' plain stores meet in that XCD's L2): workgroup blockIdx is on XCD
+// blockIdx % 8 (dispatch order; checked by the members' first gather as in the other launches).
 __global__ __launch_bounds__(kEmdThreads) void emd_lean_tiers_kernel(
     int b, int bpad, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment,
-    float eps, int iters, char *scratch, int fast_ok, int it_stop, int which, int heavy) {
+    float eps, int iters, char *scratch, int fast_ok, int it_stop, int which, unsigned long long pattern) {
   __shared__ LeanShared sh;
   const int lane = threadIdx.x & (kWave - 1);
   char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
   const int x = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;   // XCD, index inside it
-  const int c = bpad >> 3;                                          // clouds per XCD
-  const int n8 = 8 * heavy, n4 = 4 * (c - 3 * heavy);
-  int W, slot, wg;
-  if (q < n8) { W = 8; slot = q >> 3; wg = q & 7; }
-  else if (q < n8 + n4) { W = 4; slot = heavy + ((q - n8) >> 2); wg = (q - n8) & 3; }
-  else { W = 2; slot = c - 2 * heavy + ((q - n8 - n4) >> 1); wg = (q - n8 - n4) & 1; }
-  const int rank_wanted = slot * 8 + x;   // ranks 0..7: the heaviest cloud of each XCD, 8..15 the next, ...
+  const int c = bpad >> 3;                                          // cloud slots per XCD
+  int W = 0, slot = 0, wg = 0, off = 0;
+  for (int s = 0; s < c; ++s) {
+    const int w = (int)((pattern >> (4 * s)) & 15ull);
+    if (q >= off && q < off + w) { W = w; slot = s; wg = q - off; }
+    off += w;
+  }
+  const int rank_wanted = slot * 8 + x;
   // every workgroup ranks the clouds itself, from the same 64 words: unassigned persons (0: finished), ties by index
   int key = -1;
   if (lane < bpad) {
@@ -1094,10 +1096,18 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_tiers_kernel(
   int rank = 0;
   for (int o = 0; o < bpad; ++o) rank += __builtin_amdgcn_readlane(key, o) > key ? 1 : 0;
   const unsigned long long hit = __ballot(lane < bpad && rank == rank_wanted);
-  const int cloud = hit ? __builtin_ctzll(hit) : b;
-  if (W == 8) emd_lean_body<8>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
-  else if (W == 4) emd_lean_body<4>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
-  else emd_lean_body<2>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
+  const int cloud = (hit && W) ? __builtin_ctzll(hit) : b;
+#define MVP_LEAN_BODY(WB) emd_lean_body<WB>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which)
+  switch (W) {
+    case 8: MVP_LEAN_BODY(8); break;
+    case 6: MVP_LEAN_BODY(6); break;
+    case 5: MVP_LEAN_BODY(5); break;
+    case 4: MVP_LEAN_BODY(4); break;
+    case 3: MVP_LEAN_BODY(3); break;
+    case 2: MVP_LEAN_BODY(2); break;
+    default: break;
+  }
+#undef MVP_LEAN_BODY
 }
 
 template <int WT>
@@ -1118,20 +1128,34 @@ static hipError_t emd_lean_launch_w(int b, int n, const float *xyz1, float *dist
 // Runs the rounds the first kernel handed over.  Clouds that were not handed over exit at once.
 // plan_every = 0: one launch with the cluster width `w` the first kernel ran with.  Otherwise (and
 // w = 4, 33 <= b <= 64, n >= 4096, enough rounds): that width up to round `plan_round`, then launches of
-// `plan_every` rounds each with TIERED widths (emd_lean_tiers_kernel; about plan_heavy eighths of an
-// XCD's clouds get 8 workgroups).
+// `plan_every` rounds each with TIERED widths (emd_lean_tiers_kernel; plan_widths: the widths of an
+// XCD's 8 cloud slots, heaviest first, 4 bits each).
 hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps,
-                           int iters, char *scratch, int fast_ok, int plan_round, int plan_every, int plan_heavy,
-                           hipStream_t stream) {
+                           int iters, char *scratch, int fast_ok, int plan_round, int plan_every,
+                           unsigned long long plan_widths, hipStream_t stream) {
   int bpad = (b + 7) / 8 * 8;
-  int heavy = ((bpad / 8) * plan_heavy + 4) / 8;   // b = 64: plan_heavy of the 8 clouds of an XCD
+  const int c = bpad / 8;
+  // widths of an XCD's cloud slots, heaviest first, 4 bits each: the caller's for 8 slots, else 8,4,..,4,2,2
+  unsigned long long pattern = plan_widths;
+  if (c != 8 || pattern == 0ull) {
+    pattern = 8ull;
+    for (int s = 1; s < c; ++s) pattern |= (unsigned long long)(s >= c - 2 ? 2 : 4) << (4 * s);
+  }
+  int sum = 0;
+  bool ok = true;
+  for (int s = 0; s < c; ++s) {
+    const int ws = (int)((pattern >> (4 * s)) & 15ull);
+    ok = ok && (ws == 2 || ws == 3 || ws == 4 || ws == 5 || ws == 6 || ws == 8);
+    sum += ws;
+  }
+  ok = ok && sum == 4 * c;
   // (below 4096 points a cloud has a few dozen bidders left at round 300: nothing to deal out -- measured: 2048 points +0.7 ms)
-  if (w == 4 && n >= 4096 && b >= 32 && b <= 64 && plan_every > 0 && heavy >= 1 && 3 * heavy <= bpad / 8 && iters >= plan_round + 256) {
+  if (w == 4 && n >= 4096 && b >= 33 && b <= 64 && plan_every > 0 && ok && iters >= plan_round + 256) {
     hipError_t e = emd_lean_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, plan_round, 1, stream);
     for (int r = plan_round; e == hipSuccess && r < iters; r += plan_every) {
       int stop = r + plan_every + 256 > iters ? iters : r + plan_every;   // (no short last launch)
       int which = 2;
-      void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &stop, &which, &heavy};
+      void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &stop, &which, &pattern};
       e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_tiers_kernel), dim3(4 * bpad),
                                      dim3(kEmdThreads), args, 0, stream);
       if (stop == iters) break;

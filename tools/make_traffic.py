@@ -5,7 +5,7 @@ import json, sys
 prefix, outp = sys.argv[1], sys.argv[2]
 kernels = ["emd_auction_kernel", "emd_lean_kernel", "emd_lean_tiers_kernel"]
 labels = ["emd_auction_kernel<4> (rounds 0..~100)", "emd_lean_kernel<4> (to round 300)",
-          "emd_lean_tiers_kernel (the rest, 8 / 4 / 2 workgroups per cloud by load)"]
+          "emd_lean_tiers_kernel (the rest, 8 .. 2 workgroups per cloud by load)"]
 per, tot = {}, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0, "SQ_INSTS_SALU": 0.0, "SQ_WAIT_ANY": 0.0, "SQ_WAVE_CYCLES": 0.0}
 for k in kernels:
     d = json.load(open(prefix + k + ".json"))
