@@ -12,6 +12,8 @@
 // works for the one path that matters here.  Results are bit-identical to running every round
 // in emd_auction_kernel (and to the oracle): the state it resumes from is the complete auction
 // state (prices, owners, bid hints, assignment) in the per-cloud scratch.
+#include <cstdlib>
+
 #include "emd_common.h"
 
 namespace mvp {
@@ -1156,8 +1158,15 @@ hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, 
       int stop = r + plan_every + 256 > iters ? iters : r + plan_every;   // (no short last launch)
       int which = 2;
       void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &stop, &which, &pattern};
-      e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_tiers_kernel), dim3(4 * bpad),
-                                     dim3(kEmdThreads), args, 0, stream);
+      static const bool refuse = std::getenv("MVP_EMD_TIERS_FAIL") != nullptr;   // (test hook: behave as if it did not fit)
+      e = refuse ? hipErrorCooperativeLaunchTooLarge
+                 : hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_tiers_kernel), dim3(4 * bpad),
+                                              dim3(kEmdThreads), args, 0, stream);
+      if (e != hipSuccess) {
+        // (the tiered kernel does not fit this device: the fixed-width kernel finishes what the first launch left)
+        (void)hipGetLastError();
+        return emd_lean_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 2, stream);
+      }
       if (stop == iters) break;
     }
     return e;

@@ -368,6 +368,34 @@ def test_emd_tiered_widths_ragged_batches_match_oracle(oracle, b):
     np.testing.assert_array_equal(out[2][0][pick], od)
 
 
+def test_emd_tiered_launch_refused_falls_back_to_fixed_widths():
+    """A device the tiered kernel's grid does not fit on: the launcher must finish the auction with the
+    fixed-width kernel from the round the first lean launch stopped at.  Simulated in a child process
+    (MVP_EMD_TIERS_FAIL is read once per process); digest of the results against this process's."""
+    import hashlib, subprocess, sys, os
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from mvp_benchmark_amd import _lib\n"
+        "rng = np.random.default_rng(123)\n"
+        "b, n = 40, 4096\n"
+        "x1 = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32)).cuda(); x2 = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32)).cuda()\n"
+        "nbytes = _lib.emd_scratch_bytes(b, n); scratch = torch.zeros(nbytes, dtype=torch.uint8, device='cuda')\n"
+        "dist = torch.zeros(b, n, device='cuda'); ass = torch.zeros(b, n, dtype=torch.int32, device='cuda')\n"
+        "_lib.call('mvp_emd_forward', dist.device, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes); torch.cuda.synchronize()\n"
+        "rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()\n"
+        "print(hashlib.sha1(dist.cpu().numpy().tobytes() + ass.cpu().numpy().tobytes()).hexdigest(), sorted(set((rec[:, 19]).tolist())))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ({}, {"MVP_EMD_TIERS_FAIL": "1"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0].split()[0] == outs[1].split()[0], outs
+    assert "[36]" in outs[1] and "[36]" not in outs[0], outs        # refused: every cloud finished by a 4-wide launch on granule set 2
+
+
 def test_emd_tiered_widths_match_the_single_kernel(emd_split):
     """64 clouds of 4096 points: most are still running at round 300, where the default (split = 2)
     deals the 256 workgroups out again -- per XCD the heaviest cloud gets 8, the next 5, then 4, 4, 3, 3, 3
