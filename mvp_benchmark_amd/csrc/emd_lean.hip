@@ -4,14 +4,18 @@
 // workgroup has more bidders than waves and four bidders share a wave.  Once every workgroup of
 // a cloud is below that threshold (round ~100 of 3000 at the headline shape; the number of
 // unassigned persons never grows) it hands the cloud over -- lists of unassigned persons, round
-// counter, grid geometry -- and THIS kernel runs the remaining rounds (95 % of them) with the
-// same cluster of W workgroups, the same two all-gathers per round and the same exact, lossless
-// search (see emd.hip for the design notes, the proofs and the reference citations:
-// utils/metrics/EMD/emd_cuda.cu:95-215).  What it does not carry: the four-bidders-per-wave
-// schedule, the grid build, lists longer than the LDS record cache -- so the register allocator
-// works for the one path that matters here.  Results are bit-identical to running every round
-// in emd_auction_kernel (and to the oracle): the state it resumes from is the complete auction
-// state (prices, owners, bid hints, assignment) in the per-cloud scratch.
+// counter, grid geometry -- and the kernels of THIS file run the remaining rounds (95 % of them)
+// with the same two all-gathers per round and the same exact, lossless search (see emd.hip for the
+// design notes, the proofs and the reference citations: utils/metrics/EMD/emd_cuda.cu:95-215).
+// What they do not carry: the four-bidders-per-wave schedule, the grid build, lists longer than the
+// LDS record cache -- so the register allocator works for the one path that matters here.  Results
+// are bit-identical to running every round in emd_auction_kernel (and to the oracle): the state a
+// launch resumes from is the complete auction state (prices, owners, bid hints, assignment) in the
+// per-cloud scratch.
+//   emd_lean_body<W>        the rounds of one cloud on a cluster of W workgroups (device function)
+//   emd_lean_kernel<W>      every cloud on the cluster width the first kernel ran with
+//   emd_lean_tiers_kernel   from round 300 on: the workgroups dealt out again, 8 .. 2 per cloud by the
+//                           clouds' load (a launch lasts as long as its slowest cloud)
 #include <cstdlib>
 
 #include "emd_common.h"
