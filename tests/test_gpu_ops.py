@@ -368,7 +368,7 @@ def test_emd_tiered_widths_ragged_batches_match_oracle(oracle, b):
     np.testing.assert_array_equal(out[2][0][pick], od)
 
 
-def test_emd_tiered_launch_refused_falls_back_to_fixed_widths():
+def test_emd_tiered_launch_refused_late_or_repeated_gives_the_same_bits():
     """A device the tiered kernel's grid does not fit on: the launcher must finish the auction with the
     fixed-width kernel from the round the first lean launch stopped at.  Simulated in a child process
     (MVP_EMD_TIERS_FAIL is read once per process); digest of the results against this process's."""
@@ -387,12 +387,15 @@ def test_emd_tiered_launch_refused_falls_back_to_fixed_widths():
         "print(hashlib.sha1(dist.cpu().numpy().tobytes() + ass.cpu().numpy().tobytes()).hexdigest(), sorted(set((rec[:, 19]).tolist())))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for extra in ({}, {"MVP_EMD_TIERS_FAIL": "1"}):
+    # also: the plan made late (round 1500: clouds that collapsed to one workgroup are stopped and resumed), and made
+    # three times (rounds 600, 1300, 2000: the tiered launch itself stops and hands over to the next one)
+    for extra in ({}, {"MVP_EMD_TIERS_FAIL": "1"}, {"MVP_EMD_PLAN_ROUND": "1500"},
+                  {"MVP_EMD_PLAN_ROUND": "600", "MVP_EMD_PLAN_EVERY": "700"}, {"MVP_EMD_SPLIT": "0"}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
-    assert outs[0].split()[0] == outs[1].split()[0], outs
+    assert len(set(o.split()[0] for o in outs)) == 1, outs
     assert "[36]" in outs[1] and "[36]" not in outs[0], outs        # refused: every cloud finished by a 4-wide launch on granule set 2
 
 
