@@ -224,6 +224,76 @@ def edge_preserve_sampling(feature_input, point_input, num_samples, k=10):
     return net, p_idx, pn_idx, point_output
 
 
+def edge_preserve_geometry(point_input, num_samples, k=10):
+    """The index half of edge_preserve_sampling: FPS centres, their coordinates and the k nearest
+    input points of every centre -> p_idx (B,S) int32, pn_idx (B,S,pk) int32, point_output (B,S,3).
+    Coordinates only: a caller can run it ahead of the features (GeometryAhead below)."""
+    num_points = point_input.size(1)
+    p_idx = furthest_point_sample(point_input, num_samples)
+    point_output = gather_points(point_input.transpose(1, 2).contiguous(), p_idx).transpose(1, 2).contiguous()
+    pk = int(min(k, num_points))
+    pn_idx = knn_point_idx(pk, point_input, point_output).detach().int()
+    return p_idx, pn_idx, point_output
+
+
+def edge_preserve_features(feature_input, p_idx, pn_idx):
+    """The feature half of edge_preserve_sampling for precomputed indices -> net (B,2C,S)."""
+    batch_size, feature_size, _ = feature_input.size()
+    num_samples, pk = pn_idx.size(1), pn_idx.size(2)
+    if feature_input.is_cuda and feature_input.dtype == torch.float32 and not os.environ.get("MVP_NO_GATHER_MAX"):
+        neighbor_feature = gather_max(feature_input.contiguous(), pn_idx.contiguous())
+    else:
+        nbr_major = pn_idx.transpose(1, 2).contiguous().view(batch_size, pk * num_samples)
+        neighbor_feature = gather_points(feature_input, nbr_major)
+        neighbor_feature = neighbor_feature.view(batch_size, feature_size, pk, num_samples).max(dim=2)[0]
+    center_feature = grouping_operation(feature_input, p_idx.unsqueeze(2)).view(batch_size, -1, num_samples)
+    return torch.cat((center_feature, neighbor_feature), 1)
+
+
+class GeometryAhead:
+    """Runs the coordinate-only part of a point U-Net -- FPS, kNN graphs, three_nn weights of every
+    level: latency-bound kernels on a quarter of the CUs, none of them differentiable -- on a SIDE
+    stream while the main stream runs the levels' convolutions; `take(key)` makes the main stream wait
+    for exactly the item it needs next.  On the CPU (or with MVP_NO_SIDE_STREAM) everything runs in
+    line.  The reference computes the same items at the same places in its forward
+    (completion/models/vrcnet.py:236-296); only the order of independent launches differs."""
+
+    _streams = {}
+
+    def __init__(self, device):
+        self.items, self.events = {}, {}
+        self.main = self.side = None
+        if device.type == "cuda" and not os.environ.get("MVP_NO_SIDE_STREAM"):
+            self.main = torch.cuda.current_stream(device)
+            self.side = GeometryAhead._streams.get(device)
+            if self.side is None:
+                self.side = GeometryAhead._streams[device] = torch.cuda.Stream(device)
+            self.side.wait_stream(self.main)          # the coordinates are the main stream's
+
+    def run(self, key, fn):
+        """value of fn() under `key`, computed (without autograd) on the side stream."""
+        with torch.no_grad():
+            if self.side is None:
+                self.items[key] = fn()
+                return self.items[key]
+            with torch.cuda.stream(self.side):
+                value = fn()
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+        self.items[key], self.events[key] = value, ev
+        return value     # (for the side stream's own next step; the main stream goes through take())
+
+    def take(self, key):
+        value = self.items[key]
+        if self.side is not None:
+            self.main.wait_event(self.events[key])
+            for t in (value if isinstance(value, (tuple, list)) else (value,)):
+                for u in (t if isinstance(t, (tuple, list)) else (t,)):
+                    if torch.is_tensor(u):
+                        u.record_stream(self.main)   # allocated on the side stream's pool, used here
+        return value
+
+
 def three_nn_upsampling(target_points, source_points):
     """Inverse-distance weights of the 3 nearest source points of every target
     point (model_utils.py:286-293) -> idx (B,N,3) int32, weight (B,N,3)."""

@@ -14,7 +14,8 @@ down, three_nn + three_interpolate on the way up.
 import torch
 import torch.nn as nn
 
-from model_utils import aggregate_shared, edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling
+from model_utils import (GeometryAhead, aggregate_shared, edge_preserve_features, edge_preserve_geometry,
+                         edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling)
 from mm3d_pn2 import three_interpolate
 from models._common import dense, pointwise2d
 
@@ -151,15 +152,28 @@ class SA_SKN_Res_encoder(nn.Module):
 
     def forward(self, features):
         batch_size = features.size(0)
-        xyz = features[:, 0:3, :]
-        pts = [xyz.transpose(1, 2).contiguous()]                   # (B, N, 3) per level
+        xyz = features[:, 0:3, :].detach()
         units = [self.sam_res1, self.sam_res2, self.sam_res3, self.sam_res4]
 
-        skips = [self.af(units[0](features.unsqueeze(2), self._graphs(xyz)))]
+        # Everything that depends on the coordinates alone -- the kNN graphs of the four resolutions, the
+        # FPS + kNN pooling indices between them, the three_nn weights of the way up -- is issued first, on a
+        # side stream; the main stream waits per item (model_utils.GeometryAhead).  Same launches, same
+        # values as the in-line order of the reference; none of these operators is differentiable.
+        geo = GeometryAhead(features.device)
+        pts = [geo.run(("pts", 0), lambda: xyz.transpose(1, 2).contiguous())]       # (B, N, 3) per level
+        geo.run(("graph", 0), lambda: self._graphs(xyz))
         for level in range(1, 4):
-            x, _, _, p = self._edge_pooling(skips[-1], pts[-1], self.rate, self.pk, self.pts_num[level])
-            pts.append(p)
-            skips.append(self.af(units[level](x, self._graphs(p.transpose(1, 2).contiguous()))))
+            pool = geo.run(("pool", level), lambda: edge_preserve_geometry(pts[-1], self.pts_num[level], self.pk))
+            pts.append(pool[2])
+            geo.run(("graph", level), lambda: self._graphs(pts[-1].transpose(1, 2).contiguous()))
+        for level in (2, 1, 0):
+            geo.run(("up", level), lambda: three_nn_upsampling(pts[level], pts[level + 1]))
+
+        skips = [self.af(units[0](features.unsqueeze(2), geo.take(("graph", 0))))]
+        for level in range(1, 4):
+            p_idx, pn_idx, _ = geo.take(("pool", level))
+            x = edge_preserve_features(skips[-1].squeeze(2).contiguous(), p_idx, pn_idx).unsqueeze(2)
+            skips.append(self.af(units[level](x, geo.take(("graph", level)))))
 
         g = self.conv5(skips[3]).max(dim=-1)[0].view(batch_size, -1)
         g = self.dropout(self.af(self.fc2(self.dropout(self.af(self.fc1(g))))))
@@ -167,6 +181,7 @@ class SA_SKN_Res_encoder(nn.Module):
 
         x = self.conv6(torch.cat([g, skips[3]], 1), relu=True)
         for level, conv in ((2, self.conv7), (1, self.conv8), (0, self.conv9)):
-            x = self._edge_unpooling(x, pts[level + 1], pts[level])
+            idx, weight = geo.take(("up", level))
+            x = three_interpolate(x.squeeze(2).contiguous(), idx, weight).unsqueeze(2)
             x = conv(torch.cat([x, skips[level]], 1), relu=True)
         return self.conv_out(x).squeeze(2)

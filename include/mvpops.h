@@ -361,12 +361,17 @@ int mvp_share_weighted_sum_grad(int b, int share, int cw, int k, int n,
  *   gb[co]     = sum_{b,l} gy[b][co][l]                 (overwritten; gb may be NULL)
  * cout <= 64, len % 4 == 0, x and gy 16-byte aligned.  scratch:
  * mvp_pointwise_wgrad_scratch_bytes(b, cin, cout, len) bytes of per-workgroup
- * partial sums (0 = shape not covered), added up in a fixed order.  Forward and
- * data gradient are not provided (the library convolution handles them well). */
+ * partial sums (0 = shape not covered), added up in a fixed order. */
 long long mvp_pointwise_wgrad_scratch_bytes(int b, int cin, int cout, int len);
 int mvp_pointwise_wgrad(int b, int cin, int cout, int len, const float *x,
                         const float *gy, float *gw, float *gb, void *scratch,
                         long long scratch_bytes, void *stream);
+
+/* Data gradient of the same layers:  gx[b][ci][l] = sum_co weight[co][ci] * gy[b][co][l]
+ * (overwritten); cin, cout <= 64, len % 4 == 0, gy and gx 16-byte aligned.  The callers'
+ * ReLU mask is applied to gy beforehand (mvp_benchmark_amd/pointwise.py). */
+int mvp_pointwise_dgrad(int b, int cin, int cout, int len, const float *weight,
+                        const float *gy, float *gx, void *stream);
 
 /* ------------------------------------------- grouped-feature MLP on MFMA */
 

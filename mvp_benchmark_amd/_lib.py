@@ -46,6 +46,7 @@ SIGNATURES = {
     "mvp_share_weighted_sum": "iiiiippp",
     "mvp_share_weighted_sum_grad": "iiiiippppp",
     "mvp_pointwise_wgrad": "iiiipppppq",
+    "mvp_pointwise_dgrad": "iiiippp",
     "mvp_kabsch_svd3": "ipppppp",
     "mvp_pointwise_mfma": "iiiipppippiip",
     "mvp_pointwise_wgrad_mfma": "iiiippppppq",

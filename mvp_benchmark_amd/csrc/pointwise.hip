@@ -152,6 +152,52 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(int nelem, 
   if (e < nelem && lane == 0) out[e] = s;
 }
 
+// Data gradient of the same layers (cin, cout <= 64):  gx[b][ci][l] = sum_co w[co][ci] * gy[b][co][l].
+// A thread owns two neighbouring positions and CI input channels (accumulators in registers), the
+// weights are wave-uniform operands; gy is read once (8 B per lane and output channel, coalesced),
+// gx written once: the op is bound by those 4 (cin + cout) bytes per position.  The library's
+// implicit-GEMM kernel for these shapes wraps the same arithmetic in NCHW <-> NHWC transposes -- and
+// one of its variants reads out of bounds (a cold-cache MIOpen picked
+// igemm_bwd_gtcx35_nhwc_fp32_bx0_ex1_bt256x64x4 for ECG's 24-channel edge convolutions and faulted,
+// depending on what the allocator had mapped behind the tensor; rocgdb trace in DESIGN.md section 10).
+template <int CI>
+__global__ __launch_bounds__(256) void pointwise_dgrad_kernel(int cin, int cout, int len, const float *__restrict__ w,
+                                                               const float *__restrict__ gy, float *__restrict__ gx) {
+  // the weights, zero-padded to rows of 64: every lane reads the same words (LDS broadcast, 16 bytes per read)
+  __shared__ float4 sw[64 * 16];
+  for (int i = threadIdx.x; i < cout * 64; i += 256) {
+    const int co = i >> 6, ci = i & 63;
+    reinterpret_cast<float *>(sw)[i] = ci < cin ? w[(size_t)co * cin + ci] : 0.f;
+  }
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int l = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (l >= len) return;
+  gy += (size_t)b * cout * len + l;
+  gx += (size_t)b * cin * len + l;
+  for (int c0 = 0; c0 < cin; c0 += CI) {
+    float2 acc[CI];
+#pragma unroll
+    for (int i = 0; i < CI; ++i) acc[i] = make_float2(0.f, 0.f);
+    float2 g = *reinterpret_cast<const float2 *>(gy);
+    for (int co = 0; co < cout; ++co) {
+      const float2 gn = co + 1 < cout ? *reinterpret_cast<const float2 *>(gy + (size_t)(co + 1) * len) : g;   // next row in flight
+#pragma unroll
+      for (int i = 0; i < CI; i += 4) {
+        const float4 w4 = sw[co * 16 + ((c0 + i) >> 2)];
+        acc[i + 0].x = __builtin_fmaf(w4.x, g.x, acc[i + 0].x); acc[i + 0].y = __builtin_fmaf(w4.x, g.y, acc[i + 0].y);
+        acc[i + 1].x = __builtin_fmaf(w4.y, g.x, acc[i + 1].x); acc[i + 1].y = __builtin_fmaf(w4.y, g.y, acc[i + 1].y);
+        acc[i + 2].x = __builtin_fmaf(w4.z, g.x, acc[i + 2].x); acc[i + 2].y = __builtin_fmaf(w4.z, g.y, acc[i + 2].y);
+        acc[i + 3].x = __builtin_fmaf(w4.w, g.x, acc[i + 3].x); acc[i + 3].y = __builtin_fmaf(w4.w, g.y, acc[i + 3].y);
+      }
+      g = gn;
+    }
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+      if (c0 + i < cin) *reinterpret_cast<float2 *>(gx + (size_t)(c0 + i) * len) = acc[i];
+  }
+}
+
 static long long pw_blocks(int b, int len) { return (long long)b * ((len + kPwTile * kPwRun - 1) / (kPwTile * kPwRun)); }
 
 }  // namespace mvp
@@ -163,6 +209,22 @@ extern "C" long long mvp_pointwise_wgrad_scratch_bytes(int b, int cin, int cout,
   const PwPlan pl = pw_plan(cin, cout);
   if (pl.chunks > 65535) return 0;
   return pw_blocks(b, len) * ((long long)cout * cin + cout) * 4;
+}
+
+extern "C" int mvp_pointwise_dgrad(int b, int cin, int cout, int len, const float *weight, const float *gy, float *gx,
+                                   void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || cin > 64 || cout > 64 || len <= 0 || len % 4 != 0 || b > 65535) return MVP_EBADSHAPE;
+  if (!weight || !gy || !gx) return MVP_EBADARG;
+  if (((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) != 0) return MVP_EBADARG;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((len / 2 + 255) / 256, b), block(256);
+  // (one pass over gy when all input channels fit the accumulators; 64 channels take two)
+  if (cin <= 8) hipLaunchKernelGGL(pointwise_dgrad_kernel<8>, grid, block, 0, st, cin, cout, len, weight, gy, gx);
+  else if (cin <= 16) hipLaunchKernelGGL(pointwise_dgrad_kernel<16>, grid, block, 0, st, cin, cout, len, weight, gy, gx);
+  else if (cin <= 24) hipLaunchKernelGGL(pointwise_dgrad_kernel<24>, grid, block, 0, st, cin, cout, len, weight, gy, gx);
+  else if (cin <= 48) hipLaunchKernelGGL(pointwise_dgrad_kernel<48>, grid, block, 0, st, cin, cout, len, weight, gy, gx);
+  else hipLaunchKernelGGL(pointwise_dgrad_kernel<32>, grid, block, 0, st, cin, cout, len, weight, gy, gx);
+  return check_launch("mvp_pointwise_dgrad");
 }
 
 extern "C" int mvp_pointwise_wgrad(int b, int cin, int cout, int len, const float *x, const float *gy, float *gw,

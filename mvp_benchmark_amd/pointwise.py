@@ -160,6 +160,11 @@ class _PointwiseConv(Function):
         if need_x:
             if gx_mfma:
                 gx = mfma_linear(gy, weight.view(cout, cin), w_kmajor=True, xmask=mask)       # W^T (gy . relu')
+            elif _covered(x, weight) and gy_masked.data_ptr() % 16 == 0:
+                # few channels: W^T gy in one pass over gy (mvp_pointwise_dgrad) -- not the library's implicit-GEMM
+                # kernel, one variant of which reads out of bounds on these shapes (csrc/pointwise.hip)
+                gx = torch.empty_like(x)
+                call("mvp_pointwise_dgrad", x.device, x.size(0), cin, cout, x[0, 0].numel(), weight, gy_masked, gx)
             else:
                 gx = torch.ops.aten.convolution_backward(gy_masked, x, weight, None, [1] * nd, [0] * nd, [1] * nd,
                                                          False, [0] * nd, 1, [True, False, False])[0]

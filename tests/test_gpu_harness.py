@@ -418,7 +418,8 @@ def test_share_weighted_sum_matches_torch(B, share, Cw, k, N):
 @pytest.mark.parametrize("shape,cout,bias", [((32, 48, 16, 1024), 24, True), ((4, 24, 16, 3072), 24, False),
                                              ((8, 256, 1, 768), 16, True), ((8, 64, 3072), 4, True),
                                              ((3, 16, 1, 300), 64, True), ((2, 512, 1, 384), 32, False),
-                                             ((2, 130, 5, 44), 33, True), ((1, 1, 4), 1, True), ((2, 7, 1028), 5, True)])
+                                             ((2, 130, 5, 44), 33, True), ((1, 1, 4), 1, True), ((2, 7, 1028), 5, True),
+                                             ((3, 64, 16, 516), 64, True), ((2, 33, 2052), 49, False), ((5, 17, 3, 8), 9, True)])
 def test_pointwise_conv_weight_gradient(shape, cout, bias):
     """Per-point / per-edge linear maps: weight and bias gradients from
     mvp_pointwise_wgrad against PyTorch's fp32 convolution_backward at 1e-4 of
@@ -463,8 +464,15 @@ def test_pointwise_conv_weight_gradient(shape, cout, bias):
     got = torch.autograd.grad(y, params, go)
     if mfma:
         assert close(y, ref) and close(got[0], want[0])
+    elif small:
+        # few channels: the data gradient is mvp_pointwise_dgrad (fp32, another summation order over <= 64 terms)
+        assert torch.equal(y, ref) and close(got[0], want[0])
     else:
         assert torch.equal(y, ref) and torch.equal(got[0], want[0])
+    if cin <= 64 and cout <= 64 and length % 4 == 0:
+        gx = torch.full_like(x, float("nan"))
+        _lib.call("mvp_pointwise_dgrad", DEV, B, cin, cout, length, w.detach(), go, gx)
+        assert close(gx, want[0])
     for a_, b_ in zip(got[1:], want[1:]):
         assert close(a_, b_)
     # a length that is not a multiple of 4 is outside the kernel's cover: library gradient
