@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from model_utils import edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling
+from model_utils import (GeometryAhead, edge_preserve_features, edge_preserve_geometry, edge_preserve_sampling,
+                         get_edge_features, knn, three_nn_upsampling)
 from mm3d_pn2 import three_interpolate
 from models._common import dense, pointwise1d, pointwise2d
 from mvp_benchmark_amd.pointwise import pointwise_conv
@@ -134,7 +135,16 @@ class EF_encoder(nn.Module):
         self.conv8 = pointwise1d(c1 + 512, output_size)
 
     def forward(self, x):
-        pts = [x[:, 0:3, :].transpose(1, 2).contiguous()]       # level-0 coordinates (B,N,3)
+        # Everything that depends on the coordinates alone -- the FPS + kNN pooling indices of the three levels,
+        # the three_nn weights of the way up -- is issued first, on a side stream; the main stream waits per item
+        # (model_utils.GeometryAhead).  Same launches and values as in line; none of these is differentiable.
+        xyz = x[:, 0:3, :].detach()
+        geo = GeometryAhead(x.device)
+        pts = [geo.run(("pts", 0), lambda: xyz.transpose(1, 2).contiguous())]       # level-0 coordinates (B,N,3)
+        for level in range(3):
+            pts.append(geo.run(("pool", level), lambda: edge_preserve_geometry(pts[level], self.hierarchy[level], self.k))[2])
+        for level in (2, 1, 0):
+            geo.run(("up", level), lambda: three_nn_upsampling(pts[level], pts[level + 1]))
 
         # ---- down: level features f[l] (before pooling), pooled inputs
         x0 = F.relu(self.conv1(x))
@@ -142,8 +152,8 @@ class EF_encoder(nn.Module):
         squeeze = [self.conv2, self.conv3, self.conv4]
         dense = [self.dense_conv2, self.dense_conv3, self.dense_conv4]
         for level in range(3):
-            pooled, _, _, p_next = edge_preserve_sampling(f[level], pts[level], self.hierarchy[level], self.k)
-            pts.append(p_next)
+            p_idx, pn_idx, _ = geo.take(("pool", level))
+            pooled = edge_preserve_features(f[level], p_idx, pn_idx)
             y = F.relu(dense[level](F.relu(squeeze[level](pooled))))
             f.append(torch.cat((y, pooled), 1))
 
@@ -154,9 +164,9 @@ class EF_encoder(nn.Module):
 
         # ---- up: interpolate to the finer level, fuse with its skip features
         for level, conv in ((2, self.conv6), (1, self.conv7)):
-            idx, weight = three_nn_upsampling(pts[level], pts[level + 1])
+            idx, weight = geo.take(("up", level))
             up = three_interpolate(up.contiguous(), idx, weight)
             up = F.relu(conv(torch.cat((f[level], up), 1)))
-        idx, weight = three_nn_upsampling(pts[0], pts[1])
+        idx, weight = geo.take(("up", 0))
         up = three_interpolate(up.contiguous(), idx, weight)
         return self.conv8(torch.cat((f[0], up), 1))
