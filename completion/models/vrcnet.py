@@ -12,6 +12,8 @@ score-ranked gathers, and 4 Chamfer distances.
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -235,7 +237,16 @@ class Model(nn.Module):
         if train:
             # the reconstruction path sees the (sub-sampled) complete shape; both paths are decoded
             # in ONE doubled batch (:450-455)
-            y = gather_points(gt.transpose(1, 2).contiguous(), furthest_point_sample(gt, x.size(2)))
+            if gt.size(1) == x.size(2) and os.environ.get("MVP_VRCNET_SKIP_FULL_FPS"):
+                # OPT-IN.  The reference samples x.size(2) of gt's points in FPS order (:451); when that is ALL of
+                # them the result is a permutation of gt, and the encoder that consumes it -- per-point maps and
+                # max-pools (PCN_encoder) -- computes the same feature for any order of the points (to the last
+                # bits: the GEMMs' tiles see the points in another order; tests/test_gpu_harness.py::
+                # test_vrcnet_full_fps_of_gt_changes_nothing).  Skipping those 2047 sequential FPS rounds saves
+                # 1.1 ms of a 30 ms step; the default keeps the reference's launch sequence.
+                y = gt.transpose(1, 2).contiguous()
+            else:
+                y = gather_points(gt.transpose(1, 2).contiguous(), furthest_point_sample(gt, x.size(2)))
             feat_x, feat_y = self.encoder(torch.cat([x, y], dim=0)).chunk(2)
             q = self._posterior(feat_x)
             p = _normal_dist(*self._normal(self.prior_infer(feat_y)))

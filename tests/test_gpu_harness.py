@@ -388,6 +388,48 @@ def test_ecg_vrcnet_train_val_test_steps(name):
         assert r[k].shape == (2,) and torch.isfinite(r[k]).all(), k
 
 
+def test_vrcnet_full_fps_of_gt_changes_nothing(monkeypatch):
+    """VRCNet's training path feeds its PointNet encoder with gt re-ordered by an FPS of ALL its points
+    (reference completion/models/vrcnet.py:451).  Shown here: (i) that FPS returns a permutation; (ii) the
+    encoder's output for gt, for gt in FPS order and for a random permutation agree to float32 rounding
+    (per-point maps and max-pools cannot see the order; the GEMM tiles can, in the last bits); (iii) a training
+    forward with the opt-in shortcut (MVP_VRCNET_SKIP_FULL_FPS) and one with the reference's sequence return the
+    same loss and CD to 1e-4 / 1e-3 and the same fine clouds as point sets (same seed for the latent samples)."""
+    import importlib
+    import train
+    from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample, gather_points
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", "vrcnet.yaml"))
+    args.update(load_model=None)
+    torch.manual_seed(5)
+    net = importlib.import_module("models.vrcnet").Model(args).to(DEV).train()
+    g = torch.Generator().manual_seed(1)
+    gt = torch.rand(4, 2048, 3, generator=g).to(DEV)
+    partial = gt[:, torch.randperm(2048, generator=g)].transpose(2, 1).contiguous()
+    with torch.no_grad():
+        plain = net.encoder(gt.transpose(1, 2).contiguous())
+        order = furthest_point_sample(gt, 2048)
+        assert sorted(order[0].tolist()) == list(range(2048))                       # a permutation
+        by_fps = net.encoder(gather_points(gt.transpose(1, 2).contiguous(), order))
+        shuffled = net.encoder(gt[:, torch.randperm(2048, generator=g)].transpose(1, 2).contiguous())
+    scale = float(plain.abs().max())
+    assert float((plain - by_fps).abs().max()) <= 2e-6 * scale and float((plain - shuffled).abs().max()) <= 2e-6 * scale
+    outs = []
+    for skip in (False, True):
+        if skip:
+            monkeypatch.setenv("MVP_VRCNET_SKIP_FULL_FPS", "1")
+        else:
+            monkeypatch.delenv("MVP_VRCNET_SKIP_FULL_FPS", raising=False)
+        torch.manual_seed(11)
+        with torch.no_grad():
+            outs.append(net(partial, gt, alpha=0.5))
+    # (the network amplifies the encoder's last-bit differences, and an index decision -- the decoder's own FPS, a
+    # top-k -- may flip for single points: compare in the mean)
+    (fine_a, cd_a, loss_a), (fine_b, cd_b, loss_b) = outs
+    assert torch.allclose(cd_a, cd_b, rtol=1e-3) and abs(float(loss_a) - float(loss_b)) <= 1e-4 * abs(float(loss_a))
+    from model_utils import calc_cd
+    assert float(calc_cd(fine_a, fine_b)[0].max()) <= 1e-3 * float(cd_a.min())      # the same clouds, as point sets
+
+
 @pytest.mark.parametrize("B,share,Cw,k,N", [(2, 8, 2, 16, 3072), (3, 8, 16, 10, 384), (1, 4, 3, 5, 77), (2, 1, 5, 3, 300),
                                             (2, 16, 1, 20, 257), (1, 2, 7, 1, 64)])
 def test_share_weighted_sum_matches_torch(B, share, Cw, k, N):
