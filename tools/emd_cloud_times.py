@@ -30,7 +30,7 @@ for c in range(b):
             rows.setdefault(k, []).append((c, v >> 48, (v >> 32) & 0xFFFF, (v & 0xFFFFFFFF) * 0.01))
 for k in sorted(rows):
     a = np.array(rows[k])
-    name = "last launch" if k == 63 else "launch ending at round ~%d" % (k * 64)
+    name = "last launch" if k == 63 else "first kernel (to the hand-over)" if k == 62 else "launch ending at round ~%d" % (k * 64)
     print("%s: %d clouds, time mean %.0f max %.0f us" % (name, len(a), a[:, 3].mean(), a[:, 3].max()))
     for w in sorted(set(a[:, 1].astype(int))):
         z = a[a[:, 1] == w]
