@@ -119,7 +119,8 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * four workgroups each, that second kernel stops before round 300 and a third launch runs the
  * rest with the workgroups dealt out again: the clouds with the most persons
  * still unassigned -- the ones whose rounds cost most -- get 8, the lightest 2
- * (64 clouds: 8,5,4,4,3,3,3,2 over the eight clouds of an XCD)
+ * (64 uniform clouds: 8,5,4,4,3,3,3,2 over the eight clouds of an XCD; equally
+ * loaded clouds keep 4 each)
  * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  Which workgroups serve a cloud
  * never changes a bit of the result.
  * If a cluster wait is abandoned (members not co-resident for tens of seconds;
@@ -138,9 +139,10 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  *   split       2 (default): the tail rounds run in the second kernel, from round
  *               300 on with cluster widths by load (8 / 4 / 2 workgroups);
  *               1: second kernel, fixed widths; 0: the first kernel runs every round
- *               (environment, read once: MVP_EMD_PLAN_ROUND = 300, MVP_EMD_PLAN_WIDTHS =
- *               8,5,4,4,3,3,3,2 -- the widths of an XCD's eight clouds, heaviest first, sum
- *               32 --, MVP_EMD_PLAN_EVERY rounds between re-plans, default: never again)
+ *               (environment, read once: MVP_EMD_PLAN_ROUND = 300; MVP_EMD_PLAN_WIDTHS, e.g.
+ *               8,5,4,4,3,3,3,2, fixes the widths of an XCD's eight clouds, heaviest first, sum
+ *               32, instead of deriving them from the loads; MVP_EMD_PLAN_EVERY rounds between
+ *               re-plans, default: never again)
  * This is the library's only process-wide state.  Results never depend on it
  * (every setting is bit-identical: tests/test_gpu_ops.py). */
 int mvp_emd_configure(int cluster, int same_xcd, int split);

@@ -1453,7 +1453,7 @@ struct EmdKnobs {
 };
 static EmdKnobs &emd_knobs() {
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 2, 300, 4096, 0x23334458ull};   // 8,5,4,4,3,3,3,2 (profiles/r3_emd_cloud_times.txt)
+    EmdKnobs v{kMaxCluster, 1, 2, 300, 4096, 0ull};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
     if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);

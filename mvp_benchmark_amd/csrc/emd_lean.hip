@@ -1074,8 +1074,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
 // (profiles/r3_emd_cloud_times.txt) -- and a launch lasts as long as its slowest cloud.  The number
 // of persons still unassigned at round 300 predicts the time the rest takes (correlation 0.96), so
 // the clouds are ranked by it and dealt out to the XCDs (ranks 0..7: the heaviest cloud of each XCD,
-// 8..15 the next, ...); `pattern` holds the widths of an XCD's cloud slots, heaviest first, 4 bits
-// each (e.g. 8,4,4,4,4,4,2,2), their sum = the XCD's 4 * bpad / 8 workgroups.  A cluster lives inside
+// 8..15 the next, ...); the widths of an XCD's cloud slots follow from the loads (below), or `pattern`
+// gives them, heaviest first, 4 bits each (e.g. 8,4,4,4,4,4,2,2; sum = the XCD's 4 * bpad / 8 workgroups).  A cluster lives inside
 // one XCD (its members' plain stores meet in that XCD's L2): workgroup blockIdx is on XCD
 // blockIdx % 8 (dispatch order; checked by the members' first gather as in the other launches).
 __global__ __launch_bounds__(kEmdThreads) void emd_lean_tiers_kernel(
@@ -1086,23 +1086,87 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_tiers_kernel(
   char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
   const int x = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;   // XCD, index inside it
   const int c = bpad >> 3;                                          // cloud slots per XCD
-  int W = 0, slot = 0, wg = 0, off = 0;
-  for (int s = 0; s < c; ++s) {
-    const int w = (int)((pattern >> (4 * s)) & 15ull);
-    if (q >= off && q < off + w) { W = w; slot = s; wg = q - off; }
-    off += w;
-  }
-  const int rank_wanted = slot * 8 + x;
-  // every workgroup ranks the clouds itself, from the same 64 words: unassigned persons (0: finished), ties by index
-  int key = -1;
+  // Every workgroup ranks the clouds itself, from the same 64 words: unassigned persons (0: finished), ties by index;
+  // ranks 0..7 are the heaviest cloud of each XCD, 8..15 the next, ...: slot s of XCD x holds the cloud of rank 8 s + x.
+  int key = -1, u = 0;
   if (lane < bpad) {
     const EmdHandover *h = emd_handover(tail, b, lane < b ? lane : 0);
-    key = lane < b ? ((h->next_it ? h->utot : 0) << 8) | (255 - lane) : (255 - lane) - 65536;
+    u = (lane < b && h->next_it) ? h->utot : 0;
+    key = lane < b ? (u << 8) | (255 - lane) : (255 - lane) - 65536;
   }
   int rank = 0;
   for (int o = 0; o < bpad; ++o) rank += __builtin_amdgcn_readlane(key, o) > key ? 1 : 0;
-  const unsigned long long hit = __ballot(lane < bpad && rank == rank_wanted);
-  const int cloud = (hit && W) ? __builtin_ctzll(hit) : b;
+  // slot s in lane s: its cloud and load
+  int my_cloud = b, us = 0;
+  for (int s = 0; s < c; ++s) {
+    const unsigned long long hit = __ballot(lane < bpad && rank == s * 8 + x);
+    const int src = hit ? (int)__builtin_ctzll(hit) : 0;
+    const int uu = hit ? __builtin_amdgcn_readlane(u, src) : 0;
+    if (lane == s) { my_cloud = hit ? src : b; us = uu; }
+  }
+  // The widths of this XCD's slots (lanes 0..7; sum = its 4 c workgroups).  pattern != 0: given (an experiment's, or
+  // 8,4,..,4,2,2 for fewer than 8 slots).  Otherwise from the loads themselves: workgroups in proportion to the SQUARE of
+  // the unassigned counts -- a heavy cloud stays heavy for all remaining rounds while a light one converges --, rounded
+  // greedily to the widths the round loop is instantiated for (used when a slot is empty or the XCD has fewer than 8
+  // slots).  With all 8 slots active the pattern is one of three, by the ratio of the heaviest to the lightest load:
+  // >= 1.6 (the headline's uniform clouds: 100..222 unassigned at round 300): 8,5,4,4,3,3,3,2, the best of sixteen
+  // measured (the greedy rule finds it in 7 of 8 XCDs there and a worse one in the eighth: +0.6 ms); < 1.25 (clouds of
+  // equal load): 4 each -- a skewed pattern costs 13 % there; between: 6,5,4,4,4,3,3,3 (profiles/r3_emd_cloud_times.txt).
+  int w = 0;
+  // (c == 8, every slot active: one of three measured patterns, by the spread of the loads)
+  const int u_first = __builtin_amdgcn_readlane(us, 0), u_last = __builtin_amdgcn_readlane(us, 7);
+  if (pattern == 0ull && c == 8 && u_last > 0) {
+    const float spread = (float)u_first / (float)u_last;
+    pattern = spread < 1.25f ? 0x44444444ull : spread < 1.6f ? 0x33344456ull : 0x23334458ull;
+  }
+  if (pattern != 0ull) {
+    w = lane < c ? (int)((pattern >> (4 * lane)) & 15ull) : 0;
+  } else {
+    const bool act = lane < c && us > 0;
+    const float sq = act ? (float)us * (float)us : 0.f;
+    float tot = sq;
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+    const float target = tot > 0.f ? (float)(4 * c) * sq / tot : 0.f;
+    w = act ? 2 : 0;
+    int budget = 4 * c;
+    {
+      int ws = lane < 8 ? w : 0;
+#pragma unroll
+      for (int o = 4; o >= 1; o >>= 1) ws += __shfl_xor(ws, o);
+      budget -= __builtin_amdgcn_readlane(ws, 0);
+    }
+    for (int guard = 0; guard < 64 && budget > 0; ++guard) {
+      const int step = w == 6 ? 2 : 1;                       // 2, 3, 4, 5, 6, 8
+      const bool ok = act && w < 8 && step <= budget;
+      const float d = ok ? target - (float)w : -1.0e30f;
+      float m = lane < 8 ? d : -1.0e30f;
+#pragma unroll
+      for (int o = 4; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+      m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0));
+      if (m < -1.0e29f) break;
+      const unsigned long long win = __ballot(lane < 8 && ok && d == m);
+      const int wl = (int)__builtin_ctzll(win);
+      budget -= __builtin_amdgcn_readlane(step, wl);
+      if (lane == wl) w += step;
+    }
+  }
+  // offsets of the slots inside the XCD's workgroups, this workgroup's slot
+  int off = lane < 8 ? w : 0;
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    const int up = __shfl_up(off, o);
+    if ((lane & 7) >= o) off += up;
+  }
+  off -= lane < 8 ? w : 0;   // exclusive
+  const unsigned long long mine = __ballot(lane < 8 && w > 0 && q >= off && q < off + w);
+  int W = 0, wg = 0, cloud = b;
+  if (mine) {
+    const int sl = (int)__builtin_ctzll(mine);
+    W = __builtin_amdgcn_readlane(w, sl);
+    wg = q - __builtin_amdgcn_readlane(off, sl);
+    cloud = __builtin_amdgcn_readlane(my_cloud, sl);
+  }
 #define MVP_LEAN_BODY(WB) emd_lean_body<WB>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which)
   switch (W) {
     case 8: MVP_LEAN_BODY(8); break;
@@ -1141,20 +1205,18 @@ hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, 
                            unsigned long long plan_widths, hipStream_t stream) {
   int bpad = (b + 7) / 8 * 8;
   const int c = bpad / 8;
-  // widths of an XCD's cloud slots, heaviest first, 4 bits each: the caller's for 8 slots, else 8,4,..,4,2,2
-  unsigned long long pattern = plan_widths;
-  if (c != 8 || pattern == 0ull) {
-    pattern = 8ull;
-    for (int s = 1; s < c; ++s) pattern |= (unsigned long long)(s >= c - 2 ? 2 : 4) << (4 * s);
-  }
-  int sum = 0;
+  // widths of an XCD's cloud slots: 0 = from the loads (the kernel), else the caller's, heaviest first, 4 bits each
+  unsigned long long pattern = c == 8 ? plan_widths : 0ull;
   bool ok = true;
-  for (int s = 0; s < c; ++s) {
-    const int ws = (int)((pattern >> (4 * s)) & 15ull);
-    ok = ok && (ws == 2 || ws == 3 || ws == 4 || ws == 5 || ws == 6 || ws == 8);
-    sum += ws;
+  if (pattern != 0ull) {
+    int sum = 0;
+    for (int s = 0; s < c; ++s) {
+      const int ws = (int)((pattern >> (4 * s)) & 15ull);
+      ok = ok && (ws == 2 || ws == 3 || ws == 4 || ws == 5 || ws == 6 || ws == 8);
+      sum += ws;
+    }
+    ok = ok && sum == 4 * c;
   }
-  ok = ok && sum == 4 * c;
   // (below 4096 points a cloud has a few dozen bidders left at round 300: nothing to deal out -- measured: 2048 points +0.7 ms)
   if (w == 4 && n >= 4096 && b >= 33 && b <= 64 && plan_every > 0 && ok && iters >= plan_round + 256) {
     hipError_t e = emd_lean_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, plan_round, 1, stream);

@@ -359,8 +359,10 @@ def test_emd_tiered_widths_ragged_batches_match_oracle(oracle, b):
     np.testing.assert_array_equal(out[0][1], out[2][1])
     rec = out[2][2]
     tiered = (rec[:, 19] >> 4) == 2
-    # 40 cloud slots (5 per XCD): widths 8,4,4,2,2; 64 slots (8 per XCD): 8,5,4,4,3,3,3,2
-    assert tiered.sum() >= b - 8 and set((rec[tiered, 19] & 15).tolist()) == ({2, 4, 8} if b <= 40 else {2, 3, 4, 5, 8}), rec[:, 19]
+    # empty slots (or fewer than 8 per XCD): the widths follow the loads' squares, from the instantiated set; they fill the grid
+    wd = rec[tiered, 19] & 15
+    assert tiered.sum() >= b - 8 and set(wd.tolist()) <= {2, 3, 4, 5, 6, 8} and len(set(wd.tolist())) >= 3, rec[:, 19]
+    assert 4 * ((b + 7) // 8 * 8) - 16 <= int(wd.sum()) <= 4 * ((b + 7) // 8 * 8), int(wd.sum())
     order = np.argsort(rec[:, 1])
     pick = sorted(set([int(order[0]), int(order[-1]), 1, b // 3, b // 2, b - 2]))
     od, oa = oracle.emd_forward(x1n[pick], x2n[pick], 0.004, 3000)
