@@ -336,13 +336,13 @@ def run_eval(args, rank, world, dev):
     stats = scratch[nbytes - B * 16:].view(torch.int64).view(B, 2).cpu()
     rounds, bids = int(stats[:, 0].max()), float(stats[:, 1].double().mean())
 
-    # the hand-over records (20 ints per cloud, right before the statistics): round at which the
+    # the hand-over records (per cloud, right before the statistics; _lib.emd_records): round at which the
     # lean kernel took the cloud over (0: never), persons unassigned at the LAST hand-over (round 300
     # when the cluster widths are dealt out again), cluster width of the launch that finished the cloud
-    rec = scratch[nbytes - B * 16 - B * 80: nbytes - B * 16].view(torch.int32).view(B, 20).cpu()
-    handover = {"round_min": int(rec[:, 18].min()), "round_max": int(rec[:, 18].max()),
-                "unassigned_max_at_last_handover": int(rec[:, 1].max()),
-                "clouds_by_final_width": {str(w): int(((rec[:, 19] & 15) == w).sum()) for w in sorted(set((rec[:, 19] & 15).tolist()))}}
+    rec = _lib.emd_records(scratch, nbytes, B)
+    handover = {"round_min": int(rec["first_handover"].min()), "round_max": int(rec["first_handover"].max()),
+                "unassigned_max_at_last_handover": int(rec["unassigned"].max()),
+                "clouds_by_final_width": {str(int(w)): int((rec["final_width"] == w).sum()) for w in sorted(set(rec["final_width"].tolist()))}}
 
     # (N > 1: the other ranks are already waiting to leave -- two passes only)
     side = {} if args.no_side else side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_points,

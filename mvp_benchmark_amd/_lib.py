@@ -153,6 +153,26 @@ def emd_configure(cluster=-1, same_xcd=-1, split=-1):
         raise MvpOpsError("mvp_emd_configure: %s" % _ERR.get(rc, rc))
 
 
+EMD_RECORD_INTS = 32     # csrc/emd_common.h: struct EmdHandover (128 bytes per cloud, right before the statistics)
+
+
+def emd_records(scratch, nbytes, b):
+    """The per-cloud hand-over records and statistics mvp_emd_forward left at the end of its scratch buffer
+    (`scratch`: uint8 tensor of `nbytes` bytes, as passed to the call) -> dict of numpy arrays:
+      rounds, bids          the statistics words
+      first_handover        round at which the first kernel handed the cloud over (0: it never did)
+      next_round            0 once the cloud is finished
+      unassigned            persons unassigned at the LAST hand-over
+      final_width           cluster width of the launch that finished the cloud (0: the first kernel did)
+      final_launch          that launch's set of barrier granules: 1 = the launch after the first kernel, 2 = the tiered one"""
+    import torch
+    rb = EMD_RECORD_INTS * 4
+    stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()
+    rec = scratch[nbytes - b * 16 - b * rb: nbytes - b * 16].view(torch.int32).view(b, EMD_RECORD_INTS).cpu().numpy()
+    return {"rounds": stats[:, 0], "bids": stats[:, 1], "next_round": rec[:, 0], "unassigned": rec[:, 1],
+            "first_handover": rec[:, 26], "final_width": rec[:, 27] & 31, "final_launch": rec[:, 27] >> 5}
+
+
 def fps_cluster_scratch_bytes(b):
     return int(load().mvp_fps_cluster_scratch_bytes(int(b)))
 

@@ -278,16 +278,16 @@ def test_emd_second_kernel_really_runs(emd_split):
         _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
         torch.cuda.synchronize()
         stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()
-        # hand-over records: b records of 20 ints right before the statistics ([18]: round of the first hand-over)
-        rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()
+        rec = _lib.emd_records(scratch, nbytes, b)                     # hand-over records + statistics
         out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), stats, rec)
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2], out[1][2])          # same rounds, same bids
-    assert (out[0][3][:, 18] == 0).all()                          # split off: nothing handed over
-    assert (out[1][3][:, 18] > 0).all() and (out[1][3][:, 18] < 1500).all()   # split on: round of the hand-over
-    assert (out[1][3][:, 1] <= 384).all()
-    assert (out[1][3][:, 0] == 0).all() and (out[1][3][:, 19] == 16 + 8).all()   # finished, by the clusters of 8 a batch of 2 gets
+    assert (out[0][3]["first_handover"] == 0).all()               # split off: nothing handed over
+    assert (out[1][3]["first_handover"] > 0).all() and (out[1][3]["first_handover"] < 1500).all()   # split on: round of the hand-over
+    assert (out[1][3]["unassigned"] <= 384).all()
+    r1 = out[1][3]
+    assert (r1["next_round"] == 0).all() and (r1["final_width"] == 8).all() and (r1["final_launch"] == 1).all()   # finished, by the clusters of 8 a batch of 2 gets
 
 
 def test_emd_headline_cloud_matches_oracle(oracle, emd_split):
@@ -324,11 +324,11 @@ def test_emd_cfg4_full_batch_matches_oracle(oracle, emd_split, b, split):
     od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
     np.testing.assert_array_equal(ass.cpu().numpy(), oa)
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
-    rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()
-    assert (rec[:, 0] == 0).all()                                   # every cloud finished
-    running = rec[:, 18] > 0                                        # handed over at all (else: done in the first kernel)
-    tiered = running & ((rec[:, 19] >> 4) == 2)                     # finished by the tiered launch (still running at round 300)
-    assert set((rec[running & ~tiered, 19] & 15).tolist()) <= {4}
+    rec = _lib.emd_records(scratch, nbytes, b)
+    assert (rec["next_round"] == 0).all()                           # every cloud finished
+    running = rec["first_handover"] > 0                             # handed over at all (else: done in the first kernel)
+    tiered = running & (rec["final_launch"] == 2)                   # finished by the tiered launch (still running at round 300)
+    assert set(rec["final_width"][running & ~tiered].tolist()) <= {4}
     assert tiered.sum() == 0
 
 
@@ -351,19 +351,18 @@ def test_emd_tiered_widths_ragged_batches_match_oracle(oracle, b):
             ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
             _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
             torch.cuda.synchronize()
-            rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()
-            out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), rec)
+            out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), _lib.emd_records(scratch, nbytes, b))
     finally:
         _lib.emd_configure(split=_lib.EMD_DEFAULT_SPLIT)
     np.testing.assert_array_equal(out[0][0], out[2][0])
     np.testing.assert_array_equal(out[0][1], out[2][1])
     rec = out[2][2]
-    tiered = (rec[:, 19] >> 4) == 2
+    tiered = rec["final_launch"] == 2
     # empty slots (or fewer than 8 per XCD): the widths follow the loads' squares, from the instantiated set; they fill the grid
-    wd = rec[tiered, 19] & 15
-    assert tiered.sum() >= b - 8 and set(wd.tolist()) <= {2, 3, 4, 5, 6, 8} and len(set(wd.tolist())) >= 3, rec[:, 19]
+    wd = rec["final_width"][tiered]
+    assert tiered.sum() >= b - 8 and set(wd.tolist()) <= {2, 3, 4, 5, 6, 8} and len(set(wd.tolist())) >= 3, rec["final_width"]
     assert 4 * ((b + 7) // 8 * 8) - 16 <= int(wd.sum()) <= 4 * ((b + 7) // 8 * 8), int(wd.sum())
-    order = np.argsort(rec[:, 1])
+    order = np.argsort(rec["unassigned"])
     pick = sorted(set([int(order[0]), int(order[-1]), 1, b // 3, b // 2, b - 2]))
     od, oa = oracle.emd_forward(x1n[pick], x2n[pick], 0.004, 3000)
     np.testing.assert_array_equal(out[2][1][pick], oa)
@@ -385,8 +384,8 @@ def test_emd_tiered_launch_refused_late_or_repeated_gives_the_same_bits():
         "nbytes = _lib.emd_scratch_bytes(b, n); scratch = torch.zeros(nbytes, dtype=torch.uint8, device='cuda')\n"
         "dist = torch.zeros(b, n, device='cuda'); ass = torch.zeros(b, n, dtype=torch.int32, device='cuda')\n"
         "_lib.call('mvp_emd_forward', dist.device, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes); torch.cuda.synchronize()\n"
-        "rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()\n"
-        "print(hashlib.sha1(dist.cpu().numpy().tobytes() + ass.cpu().numpy().tobytes()).hexdigest(), sorted(set((rec[:, 19]).tolist())))\n"
+        "rec = _lib.emd_records(scratch, nbytes, b)\n"
+        "print(hashlib.sha1(dist.cpu().numpy().tobytes() + ass.cpu().numpy().tobytes()).hexdigest(), sorted(set((rec['final_launch'] * 100 + rec['final_width']).tolist())))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     # also: the plan made late (round 1500: clouds that collapsed to one workgroup are stopped and resumed), and made
@@ -398,7 +397,7 @@ def test_emd_tiered_launch_refused_late_or_repeated_gives_the_same_bits():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert len(set(o.split()[0] for o in outs)) == 1, outs
-    assert "[36]" in outs[1] and "[36]" not in outs[0], outs        # refused: every cloud finished by a 4-wide launch on granule set 2
+    assert "[204]" in outs[1] and "[204]" not in outs[0], outs      # refused: every cloud finished by a 4-wide launch on granule set 2
 
 
 def test_emd_tiered_widths_match_the_single_kernel(emd_split):
@@ -419,18 +418,18 @@ def test_emd_tiered_widths_match_the_single_kernel(emd_split):
         _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
         torch.cuda.synchronize()
         stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()
-        rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu().numpy()
-        out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), stats, rec)
+        out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), stats, _lib.emd_records(scratch, nbytes, b))
     np.testing.assert_array_equal(out[0][0], out[2][0])
     np.testing.assert_array_equal(out[0][1], out[2][1])
     np.testing.assert_array_equal(out[0][2], out[2][2])          # same rounds, same bids
     rec = out[2][3]
-    tiered = (rec[:, 19] >> 4) == 2
-    assert tiered.sum() >= 48, rec[:, 19]
-    w = rec[tiered, 19] & 15
+    tiered = rec["final_launch"] == 2
+    assert tiered.sum() >= 48, rec["final_launch"]
+    w = rec["final_width"][tiered]
     assert (w == 8).sum() == 8 and (w == 5).sum() == 8 and (w == 4).sum() == 16 and set(w.tolist()) <= {2, 3, 4, 5, 8}, np.bincount(w)
     # the wider a cloud's cluster, the more persons it had unassigned at round 300
-    assert rec[tiered][w == 8][:, 1].min() >= rec[tiered][w == 5][:, 1].max() >= rec[tiered][w == 5][:, 1].min() >= rec[tiered][w == 4][:, 1].max()
+    un = rec["unassigned"][tiered]
+    assert un[w == 8].min() >= un[w == 5].max() >= un[w == 5].min() >= un[w == 4].max()
 
 
 @pytest.mark.parametrize("kind", ["random", "tie_heavy"])

@@ -15,8 +15,7 @@ def run(x1, x2, eps, iters, split):
     dist = torch.zeros(b, n, device=dev); ass = torch.zeros(b, n, dtype=torch.int32, device=dev)
     _lib.call("mvp_emd_forward", dev, b, n, x1, x2, dist, ass, eps, iters, scratch, nbytes); torch.cuda.synchronize()
     stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu()
-    rec = scratch[nbytes - b * 16 - b * 80: nbytes - b * 16].view(torch.int32).view(b, 20).cpu()
-    return dist.cpu(), ass.cpu(), stats, rec
+    return dist.cpu(), ass.cpu(), stats, _lib.emd_records(scratch, nbytes, b)
 bad = 0
 try:
     for c in range(cases):
@@ -36,8 +35,8 @@ try:
         d0, a0, s0, _ = run(x1, x2, eps, iters, 0)
         d2, a2, s2, rec = run(x1, x2, eps, iters, 2)
         ok = torch.equal(d0, d2) and torch.equal(a0, a2) and torch.equal(s0, s2)
-        tiered = ((rec[:, 19] >> 4) == 2)
-        widths = sorted(set((rec[tiered, 19] & 15).tolist()))
+        tiered = rec["final_launch"] == 2
+        widths = sorted(set(rec["final_width"][tiered].tolist()))
         print("case %2d: b %2d n %5d iters %4d eps %.3f %-7s -> %s; %2d clouds finished by the tiered launch, widths %s" % (
             c, b, n, iters, eps, kind, "identical" if ok else "MISMATCH", int(tiered.sum()), widths), flush=True)
         bad += 0 if ok else 1
