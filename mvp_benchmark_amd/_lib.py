@@ -153,7 +153,7 @@ def emd_configure(cluster=-1, same_xcd=-1, split=-1):
         raise MvpOpsError("mvp_emd_configure: %s" % _ERR.get(rc, rc))
 
 
-EMD_RECORD_INTS = 32     # csrc/emd_common.h: struct EmdHandover (128 bytes per cloud, right before the statistics)
+EMD_RECORD_INTS = 20     # csrc/emd_common.h: struct EmdHandover (80 bytes per cloud, right before the statistics)
 
 
 def emd_records(scratch, nbytes, b):
@@ -170,7 +170,7 @@ def emd_records(scratch, nbytes, b):
     stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()
     rec = scratch[nbytes - b * 16 - b * rb: nbytes - b * 16].view(torch.int32).view(b, EMD_RECORD_INTS).cpu().numpy()
     return {"rounds": stats[:, 0], "bids": stats[:, 1], "next_round": rec[:, 0], "unassigned": rec[:, 1],
-            "first_handover": rec[:, 26], "final_width": rec[:, 27] & 31, "final_launch": rec[:, 27] >> 5}
+            "first_handover": rec[:, 18], "final_width": rec[:, 19] & 15, "final_launch": rec[:, 19] >> 4}
 
 
 def fps_cluster_scratch_bytes(b):

@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               resume->next_it = it + 1;
               stats[0] = n_rounds;
 #ifdef MVP_EMD_CLOUDTIME
-              sc.chg[(size_t)kMaxMembers * kChgCap - 64 + 62] = ((u64)W << 48) | ((u64)Utot << 32) | (u64)(unsigned)(wall_clock64() - ct_a0);
+              sc.chg[(size_t)kMaxCluster * kChgCap - 64 + 62] = ((u64)W << 48) | ((u64)Utot << 32) | (u64)(unsigned)(wall_clock64() - ct_a0);
 #endif
             }
           }

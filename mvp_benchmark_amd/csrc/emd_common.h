@@ -21,9 +21,7 @@ constexpr int kRecCap = 512;     // list positions whose person record is cached
 #endif
 constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 bidders share a wave
 constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
-constexpr int kMaxCluster = 8;   // workgroups per cloud (W) of the first kernel and of the fixed-width launches
-constexpr int kMaxMembers = 16;  // ... of a cluster in the tiered launch: sizes the per-member list / broadcast areas of the scratch,
-                                 // the hand-over record and the barrier granules
+constexpr int kMaxCluster = 8;   // workgroups per cloud (W)
 constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
 #ifndef MVP_EMD_SOLO
 #define MVP_EMD_SOLO 16
@@ -79,34 +77,32 @@ struct EmdHandover {
   int g;           // grid geometry (same arithmetic in both kernels)
   float lox, loy, loz, invh;
   int err;         // the first kernel's internal-error flag
-  int cnt[kMaxMembers];   // entries of each member's list
+  int cnt[kMaxCluster];   // entries of each member's list
   int nlists;      // members that left a list (the cluster width of the kernel that wrote the record)
   int epoch;       // barrier count of the launches so far (launches that share a set of granules go on counting)
   int first_it;    // round of the FIRST hand-over (kept for the statistics; next_it returns to 0 when the cloud is done)
-  int last_width;  // cluster width of the launch that finished the cloud + 32 * that launch's granule set (1, 2)
-  int pad[4];
+  int last_width;  // cluster width of the launch that finished the cloud + 16 * that launch's granule set (1, 2)
 };
 static_assert(sizeof(EmdHandover) % 16 == 0, "the scratch tail stays 16-byte granular");
 
 __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
-  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxMembers, + chg + cstart
-  return (size_t)n * (68 + 8 * kMaxMembers) + (size_t)kMaxMembers * kChgCap * 8 + (size_t)(kMaxCells + 4) * 4;
+  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg + cstart
+  return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8 + (size_t)(kMaxCells + 4) * 4;
 }
 // After the per-cloud areas ("tail" of the scratch buffer, zeroed by the host
-// before the launch): 512 B of barrier granules per cloud (two parities x two words x kMaxMembers) for the first
-// kernel, 512 B per cloud for each of the lean kernel's two launches, the hand-over records, then
+// before the launch): 256 B of barrier granules per cloud for the first
+// kernel, 256 B per cloud for each of the lean kernel's two launches, the hand-over records, then
 // the per-cloud statistics {rounds, bids} (last: read by bench.py).
 constexpr int kEmdGranuleSets = 3;
-constexpr size_t kEmdGranuleBytes = 2 * 2 * kMaxMembers * 8;   // 512
-constexpr size_t kEmdTailPerCloud = kEmdGranuleBytes * kEmdGranuleSets + sizeof(EmdHandover) + 16;
+constexpr size_t kEmdTailPerCloud = 256 * kEmdGranuleSets + sizeof(EmdHandover) + 16;
 __host__ __device__ inline unsigned long long *emd_granules(char *tail, int b, int cloud, int which) {
-  return reinterpret_cast<unsigned long long *>(tail + (size_t)which * b * kEmdGranuleBytes + (size_t)cloud * kEmdGranuleBytes);
+  return reinterpret_cast<unsigned long long *>(tail + (size_t)which * b * 256 + (size_t)cloud * 256);
 }
 __host__ __device__ inline EmdHandover *emd_handover(char *tail, int b, int cloud) {
-  return reinterpret_cast<EmdHandover *>(tail + (size_t)b * kEmdGranuleBytes * kEmdGranuleSets) + cloud;
+  return reinterpret_cast<EmdHandover *>(tail + (size_t)b * 256 * kEmdGranuleSets) + cloud;
 }
 __host__ __device__ inline long long *emd_stats(char *tail, int b, int cloud) {
-  return reinterpret_cast<long long *>(tail + (size_t)b * (kEmdGranuleBytes * kEmdGranuleSets + sizeof(EmdHandover))) + 2 * (size_t)cloud;
+  return reinterpret_cast<long long *>(tail + (size_t)b * (256 * kEmdGranuleSets + sizeof(EmdHandover))) + 2 * (size_t)cloud;
 }
 
 __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
@@ -116,8 +112,8 @@ __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
   s.person = reinterpret_cast<float4 *>(base + (size_t)n * 32);
   s.perm = reinterpret_cast<int *>(base + (size_t)n * 64);
   s.ulist = reinterpret_cast<int *>(base + (size_t)n * 68);
-  s.chg = reinterpret_cast<u64 *>(base + (size_t)n * (68 + 8 * kMaxMembers));
-  s.cstart = reinterpret_cast<int *>(base + (size_t)n * (68 + 8 * kMaxMembers) + (size_t)kMaxMembers * kChgCap * 8);
+  s.chg = reinterpret_cast<u64 *>(base + (size_t)n * (68 + 8 * kMaxCluster));
+  s.cstart = reinterpret_cast<int *>(base + (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8);
   return s;
 }
 

@@ -34,7 +34,7 @@ struct LeanShared {
   int s_next;
   int s_err, s_abort, s_nchg, s_xcc;
   int s_alarm[2];
-  unsigned s_gout[2 * kMaxMembers];
+  unsigned s_gout[2 * kMaxCluster];
   int c_start[kMaxCells + 1];
   int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
   float s_binc[kLeanBid];
@@ -227,12 +227,12 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
     const int nl = resume->nlists;
     int total = 0;
 #pragma unroll
-    for (int w = 0; w < kMaxMembers; ++w) total += w < nl ? resume->cnt[w] : 0;
+    for (int w = 0; w < kMaxCluster; ++w) total += w < nl ? resume->cnt[w] : 0;
     const int cnt0 = total > wg ? (total - wg + W - 1) / W : 0;
     if (t < cnt0) {
       int p = wg + t * W, k = -1;
 #pragma unroll
-      for (int w = 0; w < kMaxMembers; ++w) {
+      for (int w = 0; w < kMaxCluster; ++w) {
         const int cw = w < nl ? resume->cnt[w] : 0;
         if (k < 0 && p >= 0 && p < cw) k = sc.ulist[(size_t)w * 2 * n + p];
         p -= cw;
@@ -976,7 +976,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
       if (s_err) rs->err = 1;
       rs->cnt[wg] = stop_cnt;
 #ifdef MVP_EMD_CLOUDTIME
-      if (wg == 0) sc.chg[(size_t)kMaxMembers * kChgCap - 64 + (it_stop >> 6)] = ((u64)W << 48) | ((u64)Utot << 32) | (u64)(unsigned)(wall_clock64() - ct0);
+      if (wg == 0) sc.chg[(size_t)kMaxCluster * kChgCap - 64 + (it_stop >> 6)] = ((u64)W << 48) | ((u64)Utot << 32) | (u64)(unsigned)(wall_clock64() - ct0);
 #endif
       if (wg == 0) {
         rs->utot = Utot;
@@ -990,7 +990,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
   }
 #ifdef MVP_EMD_CLOUDTIME
   if (wg == 0 && t == 0)   // 100 MHz constant clock
-    sc.chg[(size_t)kMaxMembers * kChgCap - 64 + 63] = ((u64)W << 48) | (u64)(unsigned)(wall_clock64() - ct0);
+    sc.chg[(size_t)kMaxCluster * kChgCap - 64 + 63] = ((u64)W << 48) | (u64)(unsigned)(wall_clock64() - ct0);
 #endif
   if (aborted) {
     // A cluster wait ran into its bound (the members were not co-resident for
@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
     if (wg == 0) {
       atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)n_rounds);
       resume->next_it = 0;   // finished: nothing for a later launch
-      resume->last_width = W + 32 * which;   // (which: 1 = the launch after the first kernel, 2 = the tiered launch)
+      resume->last_width = W + 16 * which;   // (which: 1 = the launch after the first kernel, 2 = the tiered launch)
     }
     if (s_err) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)(-(1ll << 40)));
     atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);

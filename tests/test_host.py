@@ -24,10 +24,10 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.mvp_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MVP_ABI_VERSION (\d+)", header).group(1))
-    # per cloud: state 196 B/pt (68 + list areas of up to 16 members) + their bound broadcast buffers + cell offsets +
-    # barrier granules (3 x 512 B), hand-over record (128 B), statistics (16 B)
-    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * 196 + 16 * 2048 * 8 + 1732 * 4 + 1536 + 128 + 16)
-    assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 196 + 16 * 2048 * 8 + 1732 * 4 + 1536 + 128 + 16)
+    # per cloud: state 132 B/pt + bound broadcast buffers + cell offsets + barrier granules (3 x 256 B),
+    # hand-over record (80 B), statistics (16 B)
+    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * 132 + 8 * 2048 * 8 + 1732 * 4 + 768 + 80 + 16)
+    assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 768 + 80 + 16)
     # the knobs are process-wide: restore what is touched
     try:
         assert lib.mvp_emd_configure(-1, -1, 0) == 0

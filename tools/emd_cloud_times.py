@@ -19,11 +19,11 @@ for _ in range(2):
     e0.record(); _lib.call("mvp_emd_forward", dev, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes); e1.record()
     torch.cuda.synchronize()
 print("call: %.2f ms" % e0.elapsed_time(e1))
-per = n * 196 + 262144 + (1728 + 4) * 4
+per = n * 132 + 131072 + (1728 + 4) * 4
 raw = scratch.cpu().numpy()
 rows = {}
 for c in range(b):
-    dbg = raw[c * per + n * 196 + 262144 - 512: c * per + n * 196 + 262144].view(np.uint64)
+    dbg = raw[c * per + n * 132 + 131072 - 512: c * per + n * 132 + 131072].view(np.uint64)
     for k in range(64):
         v = int(dbg[k])
         if v:
