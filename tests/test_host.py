@@ -205,3 +205,23 @@ def test_emd_lazy_status_check_raises_one_call_late():
         emd_module.check(block=True)
     assert not emd_module._PENDING
     emd_module.check()                            # nothing pending: no-op
+
+
+def test_emd_records_reads_the_scratch_tail():
+    """_lib.emd_records: per-cloud hand-over records (20 ints) + statistics (2 int64) at the END of the scratch
+    buffer, whatever its size -- the layout csrc/emd_common.h writes (no GPU needed: a synthetic buffer)."""
+    import numpy as np
+    import torch
+    from mvp_benchmark_amd import _lib
+    b, nbytes = 3, 4096
+    buf = np.zeros(nbytes, np.uint8)
+    stats = np.array([[3000, 111], [2999, 222], [-2, 0]], np.int64)
+    rec = np.zeros((b, _lib.EMD_RECORD_INTS), np.int32)
+    rec[:, 0] = [0, 0, 300]; rec[:, 1] = [150, 90, 201]; rec[:, 18] = [70, 0, 101]; rec[:, 19] = [2 * 16 + 8, 0, 1 * 16 + 4]
+    buf[nbytes - b * 16:] = stats.view(np.uint8).ravel()
+    buf[nbytes - b * 16 - rec.nbytes: nbytes - b * 16] = rec.view(np.uint8).ravel()
+    got = _lib.emd_records(torch.from_numpy(buf), nbytes, b)
+    assert got["rounds"].tolist() == [3000, 2999, -2] and got["bids"].tolist() == [111, 222, 0]
+    assert got["next_round"].tolist() == [0, 0, 300] and got["unassigned"].tolist() == [150, 90, 201]
+    assert got["first_handover"].tolist() == [70, 0, 101]
+    assert got["final_width"].tolist() == [8, 0, 4] and got["final_launch"].tolist() == [2, 0, 1]
