@@ -475,3 +475,19 @@ def test_uniform_loss_second_neighbour_equals_topk():
     first = pairwise.argmax(dim=-1, keepdim=True)
     got = pairwise.scatter(-1, first, float('-inf')).max(dim=-1, keepdim=True)[0]
     assert torch.equal(got, want)
+
+
+def test_geometry_ahead_runs_in_line_without_a_gpu():
+    """model_utils.GeometryAhead on the CPU: no side stream, run() evaluates at once (without autograd), take() hands
+    the stored value back -- the encoders' coordinate-only work is scheduled the same way with or without a GPU."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "completion"))
+    import torch
+    from model_utils import GeometryAhead
+    geo = GeometryAhead(torch.device("cpu"))
+    assert geo.side is None
+    x = torch.arange(6.0, requires_grad=True)
+    a = geo.run("a", lambda: (x * 2, [x + 1, x + 2]))
+    assert not a[0].requires_grad and torch.equal(a[0], torch.arange(6.0) * 2)
+    got = geo.take("a")
+    assert got is a and torch.equal(got[1][1], torch.arange(6.0) + 2)
