@@ -400,6 +400,32 @@ def test_emd_tiered_launch_refused_late_or_repeated_gives_the_same_bits():
     assert "[204]" in outs[1] and "[204]" not in outs[0], outs      # refused: every cloud finished by a 4-wide launch on granule set 2
 
 
+def test_emd_headline_batch_tiered_equals_single_kernel(emd_split):
+    """The headline shape itself (64 x 16384, eps 0.004, 3000 rounds): the default's three launches against the first
+    kernel running every round alone -- distances, assignments, rounds and bids identical; the records show the tiers
+    (two of these clouds' single-kernel results are pinned to the exhaustive oracle in
+    test_emd_headline_cloud_matches_oracle)."""
+    from mvp_benchmark_amd import _lib
+    b, n = 64, 16384
+    g = torch.Generator().manual_seed(0)
+    x1, x2 = torch.rand(b, n, 3, generator=g).to(DEV), torch.rand(b, n, 3, generator=g).to(DEV)
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    out = {}
+    for split in (0, 2):
+        emd_split(split)
+        scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        dist = torch.zeros(b, n, device=DEV)
+        ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+        _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
+        torch.cuda.synchronize()
+        out[split] = (dist.clone(), ass.clone(), _lib.emd_records(scratch, nbytes, b))
+    assert torch.equal(out[0][0], out[2][0]) and torch.equal(out[0][1], out[2][1])
+    r0, r2 = out[0][2], out[2][2]
+    assert (r0["rounds"] == r2["rounds"]).all() and (r0["bids"] == r2["bids"]).all() and (r2["rounds"] == 3000).all()
+    assert (r0["first_handover"] == 0).all() and (r2["final_launch"] == 2).all()
+    assert sorted(set(r2["final_width"].tolist())) == [2, 3, 4, 5, 8] and (r2["final_width"] == 8).sum() == 8
+
+
 def test_emd_tiered_widths_match_the_single_kernel(emd_split):
     """64 clouds of 4096 points: most are still running at round 300, where the default (split = 2)
     deals the 256 workgroups out again -- per XCD the heaviest cloud gets 8, the next 5, then 4, 4, 3, 3, 3
