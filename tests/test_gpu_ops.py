@@ -400,11 +400,10 @@ def test_emd_tiered_launch_refused_late_or_repeated_gives_the_same_bits():
     assert "[204]" in outs[1] and "[204]" not in outs[0], outs      # refused: every cloud finished by a 4-wide launch on granule set 2
 
 
-def test_emd_headline_batch_tiered_equals_single_kernel(emd_split):
+def test_emd_headline_batch_tiered_equals_single_kernel_and_oracle(oracle, emd_split):
     """The headline shape itself (64 x 16384, eps 0.004, 3000 rounds): the default's three launches against the first
-    kernel running every round alone -- distances, assignments, rounds and bids identical; the records show the tiers
-    (two of these clouds' single-kernel results are pinned to the exhaustive oracle in
-    test_emd_headline_cloud_matches_oracle)."""
+    kernel running every round alone -- distances, assignments, rounds and bids identical; the records show the tiers;
+    the heaviest and one of the lightest clouds also against the exhaustive oracle."""
     from mvp_benchmark_amd import _lib
     b, n = 64, 16384
     g = torch.Generator().manual_seed(0)
@@ -424,6 +423,13 @@ def test_emd_headline_batch_tiered_equals_single_kernel(emd_split):
     assert (r0["rounds"] == r2["rounds"]).all() and (r0["bids"] == r2["bids"]).all() and (r2["rounds"] == 3000).all()
     assert (r0["first_handover"] == 0).all() and (r2["final_launch"] == 2).all()
     assert sorted(set(r2["final_width"].tolist())) == [2, 3, 4, 5, 8] and (r2["final_width"] == 8).sum() == 8
+    # ... and the oracle itself for one cloud that finished on 8 workgroups and one that finished on 2 (~70 s of CPU)
+    heavy = int(np.argmax(r2["unassigned"])); light = int(np.argmin(np.where(r2["final_width"] == 2, r2["unassigned"], 1 << 30)))
+    assert r2["final_width"][heavy] == 8 and r2["final_width"][light] == 2
+    pick = [heavy, light]
+    od, oa = oracle.emd_forward(x1[pick].cpu().numpy(), x2[pick].cpu().numpy(), 0.004, 3000)
+    np.testing.assert_array_equal(out[2][1][pick].cpu().numpy(), oa)
+    np.testing.assert_array_equal(out[2][0][pick].cpu().numpy(), od)
 
 
 def test_emd_tiered_widths_match_the_single_kernel(emd_split):
