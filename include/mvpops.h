@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 9
+#define MVP_ABI_VERSION 10
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -121,8 +121,14 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * still unassigned -- the ones whose rounds cost most -- get 8, the lightest 2
  * (64 uniform clouds: 8,5,4,4,3,3,3,2 over the eight clouds of an XCD; equally
  * loaded clouds keep 4 each)
- * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  Which workgroups serve a cloud
- * never changes a bit of the result.
+ * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  With split = 3 (the default)
+ * clouds of at most 4096 points leave the clustered kernels as soon as at most
+ * `resident_cap` (64) persons are unassigned -- round ~30 of 3000 at 1024
+ * points, ~100 at 2048, 200-350 at 4096 -- and a last, plain launch
+ * (csrc/emd_resident.hip, one workgroup per cloud) runs the remaining rounds
+ * with the whole auction state in that workgroup's LDS: no global memory access
+ * inside a round.  Which workgroups serve a cloud, and in which launch, never
+ * changes a bit of the result.
  * If a cluster wait is abandoned (members not co-resident for tens of seconds;
  * never seen) dist is filled with NaN, assignment with -1 and the statistics
  * word `rounds` is negative: the host wrapper checks for NaN lazily, and
@@ -136,16 +142,20 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  * negative argument leaves that knob unchanged.
  *   cluster     0 = automatic, or 1|2|4|8: cap of the workgroups per cloud
  *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
- *   split       2 (default): the tail rounds run in the second kernel, from round
- *               300 on with cluster widths by load (8 / 4 / 2 workgroups);
+ *   split       3 (default): as 2, and clouds of <= 4096 points finish LDS-resident
+ *               (csrc/emd_resident.hip); 2: the tail rounds run in the second kernel, from
+ *               round 300 on with cluster widths by load (8 .. 2 workgroups);
  *               1: second kernel, fixed widths; 0: the first kernel runs every round
  *               (environment, read once: MVP_EMD_PLAN_ROUND = 300; MVP_EMD_PLAN_WIDTHS, e.g.
  *               8,5,4,4,3,3,3,2, fixes the widths of an XCD's eight clouds, heaviest first, sum
  *               32, instead of deriving them from the loads; MVP_EMD_PLAN_EVERY rounds between
  *               re-plans, default: never again)
- * This is the library's only process-wide state.  Results never depend on it
+ *   resident_cap  1..128 (default 64): unassigned persons at which a cloud of <= 4096
+ *               points moves into LDS (split = 3)
+ * This is the library's only process-wide state (kept under a mutex; a call of
+ * mvp_emd_forward reads one consistent copy).  Results never depend on it
  * (every setting is bit-identical: tests/test_gpu_ops.py). */
-int mvp_emd_configure(int cluster, int same_xcd, int split);
+int mvp_emd_configure(int cluster, int same_xcd, int split, int resident_cap);
 
 /* Replaces emd.backward = emd_backward (emd.cpp:22-25,30) ->
  * emd_cuda_backward (emd_cuda.cu:302-316) -> NmDistanceGradKernel (:284-300).

@@ -54,10 +54,10 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 9   # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 10  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
-EMD_DEFAULT_SPLIT = 2
+EMD_DEFAULT_SPLIT = 3
 
 _lib = None
 
@@ -83,7 +83,7 @@ def load():
     lib.mvp_emd_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_emd_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_emd_configure.restype = ctypes.c_int
-    lib.mvp_emd_configure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.mvp_emd_configure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.mvp_fps_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_fps_cluster_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_fps_cluster_scratch_bytes.argtypes = [ctypes.c_int]
@@ -145,10 +145,10 @@ def emd_scratch_bytes(b, n, iters=None):
     return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
 
 
-def emd_configure(cluster=-1, same_xcd=-1, split=-1):
+def emd_configure(cluster=-1, same_xcd=-1, split=-1, resident_cap=-1):
     """Process-wide tuning knobs of mvp_emd_forward (negative = unchanged;
     cluster = 0: automatic).  Results do not depend on them."""
-    rc = load().mvp_emd_configure(int(cluster), int(same_xcd), int(split))
+    rc = load().mvp_emd_configure(int(cluster), int(same_xcd), int(split), int(resident_cap))
     if rc != MVP_OK:
         raise MvpOpsError("mvp_emd_configure: %s" % _ERR.get(rc, rc))
 
@@ -164,7 +164,7 @@ def emd_records(scratch, nbytes, b):
       next_round            0 once the cloud is finished
       unassigned            persons unassigned at the LAST hand-over
       final_width           cluster width of the launch that finished the cloud (0: the first kernel did)
-      final_launch          that launch's set of barrier granules: 1 = the launch after the first kernel, 2 = the tiered one"""
+      final_launch          1 = the launch after the first kernel, 2 = the tiered one, 3 = the LDS-resident one"""
     import torch
     rb = EMD_RECORD_INTS * 4
     stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()

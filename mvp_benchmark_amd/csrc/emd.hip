@@ -59,6 +59,8 @@
 //     different increment within that band was bid on the same object, and
 //     only rounds where that happened (a few per 10^5 bids) run the explicit
 //     GetMax pass and its extra barrier.
+#include <mutex>
+
 #include "emd_common.h"
 
 namespace mvp {
@@ -66,7 +68,7 @@ namespace mvp {
 // emd_lean.hip: the kernel that runs the one-bidder-per-wave rounds after the hand-over
 hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps,
                            int iters, char *scratch, int fast_ok, int plan_round, int plan_every,
-                           unsigned long long plan_widths, hipStream_t stream);
+                           unsigned long long plan_widths, int res_cap, hipStream_t stream);
 
 template <int W>
 __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
@@ -1443,20 +1445,25 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
 // environment ONCE (first use), mvp_emd_configure() overrides them at run time:
 //   MVP_EMD_CLUSTER=1|2|4|8   cap of the workgroups per cloud
 //   MVP_EMD_SAME_XCD=0        keep the write-through stores even when a cluster shares an XCD
-//   MVP_EMD_SPLIT=0|1         1 (default): the rounds after the last four-bidders-per-wave round run
-//                             in the lean kernel (emd_lean.hip); 0: one kernel runs every round
+//   MVP_EMD_SPLIT=0|1|2|3     0: one kernel runs every round; 1: the rounds after the last four-bidders-per-wave
+//                             round run in the lean kernel (emd_lean.hip); 2: + cluster widths dealt out by load
+//                             at round 300 (33..64 clouds of >= 4096 points); 3 (default): + clouds of <= 4096
+//                             points finish LDS-resident on one workgroup (emd_resident.hip)
 // The results do not depend on any of them (bit-identical; tests/test_gpu_ops.py).
 struct EmdKnobs {
-  int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip)
+  int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip), 3 + resident tail
   int plan_round, plan_every;     // split == 2: round of the first plan; rounds per planned launch
   unsigned long long plan_widths; // widths of an XCD's 8 cloud slots, heaviest first, 4 bits each
+  int res_cap;                    // split == 3: unassigned persons at which a cloud of <= 4096 points moves into LDS (emd_resident.hip)
 };
-static EmdKnobs &emd_knobs() {
+static std::mutex g_knob_mutex;
+static EmdKnobs &emd_knobs_locked() {   // (callers hold g_knob_mutex)
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 2, 300, 4096, 0ull};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
+    EmdKnobs v{kMaxCluster, 1, 3, 300, 4096, 0ull, 64};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
-    if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
+    if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 3 ? 3 : atoi(e);
+    if (const char *e = getenv("MVP_EMD_RESIDENT_CAP")) v.res_cap = atoi(e) < 1 ? 1 : atoi(e) > kResList ? kResList : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_ROUND")) v.plan_round = atoi(e) < 1 ? 1 : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_EVERY")) v.plan_every = atoi(e) < 64 ? 64 : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_WIDTHS")) {   // e.g. 8,6,4,4,3,3,2,2
@@ -1473,15 +1480,19 @@ static EmdKnobs &emd_knobs() {
   }();
   return k;
 }
+// One consistent copy of the knobs (a call of mvp_emd_forward takes it once).
+static EmdKnobs emd_knobs() {
+  std::lock_guard<std::mutex> g(g_knob_mutex);
+  return emd_knobs_locked();
+}
 
 // Workgroups per cloud: as many (1, 2, 4, 8) as keep b*W workgroups co-resident,
 // one per CU.  MVP_EMD_CLUSTER=1|2|4|8 overrides (still capped by the CU count).
-static int emd_cluster_width(int b) {
+static int emd_cluster_width(int b, int want) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 1;
-  const int want = emd_knobs().cluster;
   int w = 1;
   while (w * 2 <= want && w * 2 <= kMaxCluster && (long long)b * w * 2 <= cus) w *= 2;
   return w;
@@ -1489,7 +1500,7 @@ static int emd_cluster_width(int b) {
 
 template <int W>
 static hipError_t emd_launch(int b, int n, const float *xyz1, const float *xyz2, float *dist,
-                             int *assignment, float eps, int iters, char *scratch, int lean,
+                             int *assignment, float eps, int iters, char *scratch, int lean, int fast_ok,
                              hipStream_t stream) {
   int bpad = W == 1 ? b : (b + 7) / 8 * 8;
   if (W == 1) {
@@ -1499,7 +1510,6 @@ static hipError_t emd_launch(int b, int n, const float *xyz1, const float *xyz2,
   }
   // cluster members wait for each other: the launch must be checked against
   // the device's residency (cooperative launch does exactly that)
-  int fast_ok = emd_knobs().same_xcd;
   void *args[] = {&b, &bpad, &n, &xyz1, &xyz2, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &lean};
   return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_auction_kernel<W>),
                                     dim3(W * bpad), dim3(kEmdThreads), args, 0, stream);
@@ -1514,14 +1524,17 @@ extern "C" long long mvp_emd_scratch_bytes(int b, int n) {
   return (long long)b * ((long long)emd_scratch_per_cloud(n) + (long long)kEmdTailPerCloud);  // a multiple of 16
 }
 
-extern "C" int mvp_emd_configure(int cluster, int same_xcd, int split) {
-  EmdKnobs &k = emd_knobs();
+extern "C" int mvp_emd_configure(int cluster, int same_xcd, int split, int resident_cap) {
+  std::lock_guard<std::mutex> g(g_knob_mutex);
+  EmdKnobs &k = emd_knobs_locked();
+  if (resident_cap == 0 || resident_cap > kResList) return MVP_EBADARG;
+  if (resident_cap > 0) k.res_cap = resident_cap;
   if (cluster >= 0) {
     if (cluster != 0 && cluster != 1 && cluster != 2 && cluster != 4 && cluster != 8) return MVP_EBADARG;
     k.cluster = cluster == 0 ? kMaxCluster : cluster;
   }
   if (same_xcd >= 0) k.same_xcd = same_xcd != 0;
-  if (split >= 0) k.split = split > 2 ? 2 : split;
+  if (split >= 0) k.split = split > 3 ? 3 : split;
   return MVP_OK;
 }
 
@@ -1545,22 +1558,24 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
   // barrier granules, hand-over records and statistics start from zero on every call
   if (hipMemsetAsync(sbase + (size_t)b * emd_scratch_per_cloud(n), 0, (size_t)b * kEmdTailPerCloud, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
-  int w = emd_cluster_width(b);
+  const EmdKnobs knobs = emd_knobs();
+  int w = emd_cluster_width(b, knobs.cluster);
   // Two launches when the auction is long enough to have a tail: the first kernel hands a cloud
   // over when at least `lean` rounds are left (0: never); the second exits at once for clouds
   // that were not handed over.
-  const int lean = emd_knobs().split && iters > kLeanMinRounds ? kLeanMinRounds : 0;
+  const int lean = knobs.split && iters > kLeanMinRounds ? kLeanMinRounds : 0;
   hipError_t err = hipErrorUnknown;
-  if (w == 8) err = emd_launch<8>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, st);
-  else if (w == 4) err = emd_launch<4>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, st);
-  else if (w == 2) err = emd_launch<2>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, st);
+  if (w == 8) err = emd_launch<8>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, knobs.same_xcd, st);
+  else if (w == 4) err = emd_launch<4>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, knobs.same_xcd, st);
+  else if (w == 2) err = emd_launch<2>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, knobs.same_xcd, st);
   if (err != hipSuccess) {  // w == 1, or the cluster does not fit this device
     (void)hipGetLastError();
     w = 1;
-    (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, st);
+    (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, 0, st);
   }
-  if (lean && emd_lean_launch(b, n, w, xyz1, dist, assignment, eps, iters, sbase, emd_knobs().same_xcd,
-                              emd_knobs().plan_round, emd_knobs().split == 2 ? emd_knobs().plan_every : 0, emd_knobs().plan_widths, st) != hipSuccess)
+  if (lean && emd_lean_launch(b, n, w, xyz1, dist, assignment, eps, iters, sbase, knobs.same_xcd,
+                              knobs.plan_round, knobs.split >= 2 ? knobs.plan_every : 0, knobs.plan_widths,
+                              knobs.split >= 3 ? knobs.res_cap : 0, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
   return check_launch("mvp_emd_forward");
 }

@@ -36,6 +36,12 @@ constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens 
 constexpr int kLeanCap = 384;   // (tuned with kRowModeMin: 64..160 x 384 / 512 all within 0.2 ms at the headline shape)
 constexpr int kLeanMinRounds = 64;
 static_assert(kLeanCap <= kRecCap, "the lean kernel keeps every list entry's record in LDS");
+// The resident kernel (emd_resident.hip) takes a cloud of at most kResMaxN points over once at most
+// `res_cap` <= kResList persons are unassigned and at least kResMinRounds rounds are left: the whole
+// auction state then lives in one workgroup's LDS.
+constexpr int kResMaxN = 4096;
+constexpr int kResList = 128;
+constexpr int kResMinRounds = 32;
 
 // Filter slack.  An object is skipped only if
 //   s > fl(tq*tq),  tq = fl(fl(fl(3 - B2) + kMargin) - price)   (or tq < 0)

@@ -24,6 +24,10 @@ namespace mvp {
 
 constexpr int kLeanBid = 512;
 
+// emd_resident.hip
+hipError_t emd_resident_launch(int b, int n, float *dist, int *assignment, float eps, int iters, char *scratch,
+                               hipStream_t stream);
+
 // The kernels' LDS, one object per kernel: the tiers kernel holds the round loop three times (one
 // instance per cluster width), all on the same memory.
 struct LeanShared {
@@ -62,11 +66,15 @@ template <int WB>
 __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, const int wg, int b,
                                               int n, const float *__restrict__ xyz1, float *__restrict__ dist,
                                               int *assignment, float eps, int iters, char *scratch, int fast_ok,
-                                              int it_stop, int which) {
+                                              int it_stop, int which, int u_stop) {
   constexpr int W = WB, WM = WB;
   const int t = threadIdx.x;
   const int lane = t & (kWave - 1);
+#ifdef MVP_LEAN_PLAIN_WAVE   // (A/B: round 3's code)
   const int wave = t >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (tells the compiler that it is wave-uniform)
+#endif
   char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
   if (cloud >= b) return;
   char *cbase = scratch + (size_t)cloud * emd_scratch_per_cloud(n);
@@ -75,6 +83,9 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
   long long *stats = emd_stats(tail, b, cloud);
   const int it0 = resume->next_it;
   if (it0 == 0 || it0 >= it_stop) return;   // finished already / not this launch's rounds (uniform over the cluster)
+  // u_stop > 0: the cloud is left to the resident kernel (emd_resident.hip) as soon as at most u_stop persons
+  // are unassigned -- possibly at once: the record and the lists stay as the previous launch wrote them
+  if (resume->utot <= u_stop && iters - it0 >= kResMinRounds) return;
   xyz1 += (size_t)cloud * n * 3;
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
@@ -280,7 +291,8 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
   // would only add latency: member 0 adopts the others' lists and carries on
   // alone (same code, workgroup barriers), the others leave.
   bool clustered = WB != 1;
-  int stop_cnt = -1;   // >= 0: the loop ended at it_stop with this many entries in this member's next list
+  int stop_cnt = -1;   // >= 0: the loop ended before round stop_it with this many entries in this member's next list
+  int stop_it = it_stop;
 #ifdef MVP_EMD_PROFILE
   long long prof_pg1 = 0, prof_drain = 0, prof_gather = 0, cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0, prof_a1 = 0, prof_an = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0;
 #endif
@@ -783,9 +795,11 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
         Utot += cntw[w];
         if (w != wg) overflow |= chgw[w] > kChgCap;
       }
-      if (__builtin_expect(it + 1 == it_stop && it + 1 < iters && Utot > 0, 0)) {
+      if (__builtin_expect((it + 1 == it_stop && it + 1 < iters && Utot > 0) ||
+                           (Utot <= u_stop && Utot > 0 && iters - (it + 1) >= kResMinRounds), 0)) {
         // ---- this launch's last round: the lists are left for the next launch below the loop
         stop_cnt = cntw[wg];
+        stop_it = it + 1;
         break;
       }
       if (__builtin_expect(Utot > 0 && Utot <= kSoloMax && it + 1 < iters, 0)) {
@@ -920,8 +934,10 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
     } else {
       __syncthreads();
       Utot = s_cnt[nxt];
-      if (__builtin_expect(it + 1 == it_stop && it + 1 < iters && Utot > 0, 0)) {   // (member 0 alone)
+      if (__builtin_expect((it + 1 == it_stop && it + 1 < iters && Utot > 0) ||
+                           (Utot <= u_stop && Utot > 0 && iters - (it + 1) >= kResMinRounds), 0)) {   // (member 0 alone)
         stop_cnt = Utot;
+        stop_it = it + 1;
         break;
       }
       {
@@ -976,13 +992,13 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
       if (s_err) rs->err = 1;
       rs->cnt[wg] = stop_cnt;
 #ifdef MVP_EMD_CLOUDTIME
-      if (wg == 0) sc.chg[(size_t)kMaxCluster * kChgCap - 64 + (it_stop >> 6)] = ((u64)W << 48) | ((u64)Utot << 32) | (u64)(unsigned)(wall_clock64() - ct0);
+      if (wg == 0) sc.chg[(size_t)kMaxCluster * kChgCap - 64 + (min(stop_it, 3900) >> 6)] = ((u64)W << 48) | ((u64)Utot << 32) | (u64)(unsigned)(wall_clock64() - ct0);
 #endif
       if (wg == 0) {
         rs->utot = Utot;
         rs->nlists = clustered ? W : 1;
         rs->epoch = (int)epoch;
-        rs->next_it = it_stop;
+        rs->next_it = stop_it;
         atomicAdd(reinterpret_cast<unsigned long long *>(&st2[0]), (unsigned long long)n_rounds);
       }
     }
@@ -1062,11 +1078,11 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
 template <int WT>
 __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     int b, int bpad, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment,
-    float eps, int iters, char *scratch, int fast_ok, int it_stop, int which) {
+    float eps, int iters, char *scratch, int fast_ok, int it_stop, int which, int u_stop) {
   __shared__ LeanShared sh;
   const int cloud = WT == 1 ? (int)blockIdx.x : (int)blockIdx.x % bpad;
   const int wg = WT == 1 ? 0 : (int)blockIdx.x / bpad;
-  emd_lean_body<WT>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which);
+  emd_lean_body<WT>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which, u_stop);
 }
 
 // TIERED widths (grid 4 * bpad, 40 <= bpad <= 64).  The clouds' rounds differ in cost -- a cloud with
@@ -1167,7 +1183,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_tiers_kernel(
     wg = q - __builtin_amdgcn_readlane(off, sl);
     cloud = __builtin_amdgcn_readlane(my_cloud, sl);
   }
-#define MVP_LEAN_BODY(WB) emd_lean_body<WB>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which)
+#define MVP_LEAN_BODY(WB) emd_lean_body<WB>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which, 0)
   switch (W) {
     case 8: MVP_LEAN_BODY(8); break;
     case 6: MVP_LEAN_BODY(6); break;
@@ -1183,14 +1199,14 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_tiers_kernel(
 template <int WT>
 static hipError_t emd_lean_launch_w(int b, int n, const float *xyz1, float *dist, int *assignment, float eps,
                                     int iters, char *scratch, int fast_ok, int it_stop, int which,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, int u_stop = 0) {
   int bpad = WT == 1 ? b : (b + 7) / 8 * 8;
   if (WT == 1) {
     hipLaunchKernelGGL(emd_lean_kernel<1>, dim3(b), dim3(kEmdThreads), 0, stream, b, bpad, n, xyz1, dist,
-                       assignment, eps, iters, scratch, 0, it_stop, which);
+                       assignment, eps, iters, scratch, 0, it_stop, which, u_stop);
     return hipSuccess;
   }
-  void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &it_stop, &which};
+  void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &it_stop, &which, &u_stop};
   return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_kernel<WT>), dim3(WT * bpad),
                                     dim3(kEmdThreads), args, 0, stream);
 }
@@ -1202,7 +1218,19 @@ static hipError_t emd_lean_launch_w(int b, int n, const float *xyz1, float *dist
 // XCD's 8 cloud slots, heaviest first, 4 bits each).
 hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps,
                            int iters, char *scratch, int fast_ok, int plan_round, int plan_every,
-                           unsigned long long plan_widths, hipStream_t stream) {
+                           unsigned long long plan_widths, int res_cap, hipStream_t stream) {
+  if (res_cap > 0 && n <= kResMaxN) {
+    // Clouds of at most kResMaxN points: the clustered rounds end as soon as at most res_cap persons are
+    // unassigned; the resident kernel (one workgroup per cloud, the auction state in LDS) runs the rest.
+    res_cap = res_cap > kResList ? kResList : res_cap;
+    hipError_t e = hipSuccess;
+    if (w == 8) e = emd_lean_launch_w<8>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, res_cap);
+    else if (w == 4) e = emd_lean_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, res_cap);
+    else if (w == 2) e = emd_lean_launch_w<2>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, res_cap);
+    else e = emd_lean_launch_w<1>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, res_cap);
+    if (e != hipSuccess) return e;
+    return emd_resident_launch(b, n, dist, assignment, eps, iters, scratch, stream);
+  }
   int bpad = (b + 7) / 8 * 8;
   const int c = bpad / 8;
   // widths of an XCD's cloud slots: 0 = from the loads (the kernel), else the caller's, heaviest first, 4 bits each

@@ -30,10 +30,13 @@ def test_library_exports_every_declared_symbol():
     assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 768 + 80 + 16)
     # the knobs are process-wide: restore what is touched
     try:
-        assert lib.mvp_emd_configure(-1, -1, 0) == 0
-        assert lib.mvp_emd_configure(3, -1, -1) == -2               # MVP_EBADARG: cluster width
+        assert lib.mvp_emd_configure(-1, -1, 0, -1) == 0
+        assert lib.mvp_emd_configure(3, -1, -1, -1) == -2           # MVP_EBADARG: cluster width
+        assert lib.mvp_emd_configure(-1, -1, -1, 0) == -2           # MVP_EBADARG: resident cap 1..128
+        assert lib.mvp_emd_configure(-1, -1, -1, 129) == -2
+        assert lib.mvp_emd_configure(-1, -1, -1, 16) == 0
     finally:
-        assert lib.mvp_emd_configure(0, -1, _lib.EMD_DEFAULT_SPLIT) == 0
+        assert lib.mvp_emd_configure(0, -1, _lib.EMD_DEFAULT_SPLIT, 64) == 0
 
 
 def test_argument_guards_need_no_gpu():
