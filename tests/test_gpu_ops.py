@@ -390,14 +390,16 @@ def test_emd_tiered_launch_refused_late_or_repeated_gives_the_same_bits():
     outs = []
     # also: the plan made late (round 1500: clouds that collapsed to one workgroup are stopped and resumed), and made
     # three times (rounds 600, 1300, 2000: the tiered launch itself stops and hands over to the next one)
-    for extra in ({}, {"MVP_EMD_TIERS_FAIL": "1"}, {"MVP_EMD_PLAN_ROUND": "1500"},
-                  {"MVP_EMD_PLAN_ROUND": "600", "MVP_EMD_PLAN_EVERY": "700"}, {"MVP_EMD_SPLIT": "0"}):
+    # (MVP_EMD_SPLIT=2: the tiered launches; the default, 3, finishes clouds of this size LDS-resident -- last variant)
+    for extra in ({"MVP_EMD_SPLIT": "2"}, {"MVP_EMD_SPLIT": "2", "MVP_EMD_TIERS_FAIL": "1"}, {"MVP_EMD_SPLIT": "2", "MVP_EMD_PLAN_ROUND": "1500"},
+                  {"MVP_EMD_SPLIT": "2", "MVP_EMD_PLAN_ROUND": "600", "MVP_EMD_PLAN_EVERY": "700"}, {"MVP_EMD_SPLIT": "0"}, {}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert len(set(o.split()[0] for o in outs)) == 1, outs
     assert "[204]" in outs[1] and "[204]" not in outs[0], outs      # refused: every cloud finished by a 4-wide launch on granule set 2
+    assert "[301]" in outs[5], outs                                  # default: one workgroup per cloud, the resident launch
 
 
 def test_emd_headline_batch_tiered_equals_single_kernel_and_oracle(oracle, emd_split):

@@ -11,7 +11,7 @@ for n in 1024 2048 4096; do
     MVP_EMD_SPLIT=$split MVP_BENCH_REPS=5 timeout 300 python tools/bench_emd_one.py 64 $n 0.004 3000
   done
 done
-for cap in 16 32; do
+for cap in 8 16 32; do
   echo "## cap=$cap"
   for n in 1024 2048 4096; do
     MVP_EMD_RESIDENT_CAP=$cap MVP_BENCH_REPS=5 timeout 300 python tools/bench_emd_one.py 64 $n 0.004 3000
@@ -25,11 +25,3 @@ if [ -f mvp_benchmark_amd/libmvpops_prof.so ]; then
 fi
 } > gpurun_out/${tag}_resident_times.txt 2>&1
 grep -v amdgpu.ids gpurun_out/${tag}_resident_times.txt
-# A/B of the wave-uniformity hint in the lean kernels at the headline shape
-{
-for rep in 1 2; do
-  MVP_BENCH_REPS=4 timeout 300 python tools/bench_emd_one.py 64 16384 0.004 3000
-  MVP_BENCH_REPS=4 timeout 300 python tools/bench_emd_one.py 64 16384 0.004 3000 mvp_benchmark_amd/libmvpops_plainwave.so
-done
-} > gpurun_out/${tag}_lean_wave_ab.txt 2>&1
-grep -v amdgpu.ids gpurun_out/${tag}_lean_wave_ab.txt
