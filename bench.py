@@ -213,25 +213,38 @@ def _timeit(fn):
     return time.perf_counter() - t0
 
 
+def emd_sources_digest():
+    """sha256 over the EMD kernels' sources: what a set of committed counters was taken on (tools/make_traffic.py
+    stamps profiles/traffic.json with it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mvp_benchmark_amd", "csrc", "emd*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def committed_counters(B, n, eps, iters):
-    """Per-call counters of mvp_emd_forward (its two kernels summed) from the committed rocprofv3
-    --pmc passes (profiles/traffic.json), only if they were taken on this shape."""
+    """Per-call counters of mvp_emd_forward (its kernels summed) from the committed rocprofv3
+    --pmc passes (profiles/traffic.json), only if they were taken on this shape.  `counters_current` says
+    whether the EMD sources are still the ones the counters were taken on (the file carries their digest)."""
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["emd_forward"]
         if (tr["batch"], tr["points"], tr["eps"], tr["iters"]) == (B, n, eps, iters):
+            tr = dict(tr)
+            tr["counters_current"] = tr.get("emd_sources_sha256") == emd_sources_digest()
             return tr
     except (OSError, KeyError, ValueError):
         pass
     return None
 
 
-def side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_points, budget_s=7.0):
+def side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_points, reps=3):
     """Untimed side measurements on rank 0, AFTER the timed region: the EMD sweep of BASELINE
     cfg 4 (B = 64, n in {1024, 2048, 4096, 8192}, eval setting), cfg 2's EMD (B = 32 at the headline
-    size), the training setting (eps 0.005, 50 rounds) and FPS at two sizes.  The list is cycled
-    until `budget_s` seconds of GPU time have been spent (at least two passes), so that a 5-second
-    utilisation sampler sees the GPU busy even when the timed region itself is only ~1 s
-    (--steps 20), and every figure is a mean over several repetitions."""
+    size), the training setting (eps 0.005, 50 rounds) and FPS at two sizes.  Every job runs once untimed
+    and then `reps` times; the figure is the mean (about 0.6 s of GPU time in all)."""
     B, n = args.batch, args.points
     jobs = []
     for (jb, jn, jeps, jit, key) in ((B, 1024, args.eps, args.iters, "emd_cfg4_n1024_ms"),
@@ -253,8 +266,8 @@ def side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_point
         fn_()
     torch.cuda.synchronize()
     tot = {k: [0.0, 0] for k, _ in jobs}
-    spent, passes = 0.0, 0
-    while passes < 2 or spent < budget_s * 1e3:
+    passes = 0
+    while passes < reps:
         for k, fn_ in jobs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -264,10 +277,7 @@ def side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_point
             ms = e0.elapsed_time(e1)
             tot[k][0] += ms
             tot[k][1] += 1
-            spent += ms
         passes += 1
-        if passes >= 200:
-            break
     out = {"side_measurement_reps": passes}
     for k, (ms_sum, cnt) in tot.items():
         ms = ms_sum / cnt
@@ -346,7 +356,7 @@ def run_eval(args, rank, world, dev):
 
     # (N > 1: the other ranks are already waiting to leave -- two passes only)
     side = {} if args.no_side else side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_points,
-                                                      budget_s=7.0 if world == 1 else 0.0)
+                                                      reps=3 if world == 1 else 1)
 
     pairs = float(B) * n * n
     value = pairs * world / (elapsed / args.steps)
@@ -364,7 +374,9 @@ def run_eval(args, rank, world, dev):
                  "valu_insts_per_bid": ctr["SQ_INSTS_VALU"] / total_bids,
                  "salu_insts_per_bid": (ctr.get("SQ_INSTS_SALU") or 0) / total_bids,
                  "valu_issue_frac": ctr["SQ_INSTS_VALU"] * 64 / (emd_ms * 1e-3 * VALU_LANE_OPS_PER_S),
-                 "wait_any_frac": ctr.get("wait_any_frac"), "source": ctr.get("source")}
+                 "wait_any_frac": ctr.get("wait_any_frac"), "source": ctr.get("source"),
+                 # False: the kernels changed since the committed passes (figures of an older build, kept for the trend)
+                 "counters_current": ctr.get("counters_current"), "counters_taken_at": ctr.get("taken_at")}
     line = {
         "metric": "point-pairs/sec CD+EMD @2048->16384 pts, batch 64",
         "value": value,

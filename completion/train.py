@@ -86,14 +86,14 @@ def make_loader(dataset, args, rank, world, shuffle, epoch=0, seed=0):
 
 
 def _needs_unused_parameter_walk(net, args):
-    """True when the configuration leaves parameters without a gradient (DDP must then be told).
-    cfgs/vrcnet.yaml has num_fps == num_coarse == num_points, so MSAP_SKN_decoder never runs
-    conv_s1..3 / expansion2 / conv_f1..2; pcn and ecg use every parameter in every step.
-    `ddp_find_unused_parameters: True|False` in the cfg overrides the rule."""
+    """True unless the cfg says `ddp_find_unused_parameters: False`.
+    cfgs/vrcnet.yaml has num_fps == num_coarse == num_points, so MSAP_SKN_decoder never runs conv_s1..3 /
+    expansion2 / conv_f1..2: a plain DDP raises "Expected to have finished reduction" in the second step there.
+    cfgs/pcn.yaml and cfgs/ecg.yaml use every parameter in every step and switch the per-step graph walk off
+    themselves; a cfg variant that does not say so keeps it (the reference's nn.DataParallel, train.py:49,
+    tolerates unused branches)."""
     forced = args.get("ddp_find_unused_parameters") if args is not None else None
-    if forced is not None:
-        return bool(forced)
-    return args is None or str(args.get("model_name") or "") not in ("pcn", "ecg")
+    return True if forced is None else bool(forced)
 
 
 def wrap_ddp(net, device, world, args=None):
@@ -165,13 +165,31 @@ class GraphedStep:
     def _capture(self, inputs, gt, alpha):
         self.inputs, self.gt = inputs.clone(), gt.clone()
         self.alpha = torch.tensor(float(alpha), device=self.device)
+        # The three warm-up steps a capture needs are real optimizer steps.  So that the first batch is
+        # trained on ONCE (by the first replay), as in the eager loop, parameters, buffers (BatchNorm
+        # statistics), optimizer state and the random streams are put back afterwards -- in place: the
+        # graph records the addresses of the tensors the warm-up created.
+        model_snap = {k: v.detach().clone() for k, v in self.net.state_dict().items()}
+        opt_snap = {p: {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
+                    for p, st in self.opt.state.items()}
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(self.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):              # warm-up steps off the capturing stream (they DO train)
+        with torch.cuda.stream(side):              # warm-up steps off the capturing stream
             for _ in range(3):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for k, v in self.net.state_dict().items():
+                v.copy_(model_snap[k])
+            for p, st in self.opt.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):         # state the warm-up created starts from zero (Adam / AdamW: moments, step)
+                        v.copy_(opt_snap[p][k]) if p in opt_snap and k in opt_snap[p] else v.zero_()
+        torch.set_rng_state(rng_cpu)
+        torch.cuda.set_rng_state(rng_dev, self.device)
+        logging.info('hip_graph: three warm-up steps run and rolled back (parameters, buffers, optimizer state, RNG)')
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.fine, self.total = self._step()
@@ -180,7 +198,7 @@ class GraphedStep:
     def __call__(self, inputs, gt, alpha):
         """-> (mean fine loss, total loss) as device scalars of THIS batch's step."""
         if self.graph is None:
-            self._capture(inputs, gt, alpha)       # (three eager warm-up steps on this batch, then the capture)
+            self._capture(inputs, gt, alpha)       # (warm-up steps on this batch, rolled back; then the capture)
         if (tuple(inputs.shape), tuple(gt.shape)) != self.shape:
             self.opt.zero_grad(set_to_none=True)
             out2, loss2, net_loss = self.net(inputs, gt, alpha=torch.tensor(float(alpha), device=self.device))
@@ -244,7 +262,20 @@ def val(net, curr_epoch_num, val_loss_meters, loader, valid, best_epoch_losses, 
                 r = result_dict[k]
                 r = r[keep.to(r.device)] if torch.is_tensor(r) and r.dim() > 0 else r
                 v.update(float(r.mean()) if torch.is_tensor(r) else float(r), n_keep)
-    check_emd_status()      # a failed auction launch is an exception here, not a NaN in the log
+    # a failed auction launch is an exception here, not a NaN in the log -- on EVERY rank: a rank that raised alone
+    # would leave the others waiting in the meters' all-reduce until the collective times out
+    failure = None
+    try:
+        check_emd_status()
+    except Exception as e:   # noqa: BLE001 (re-raised below, on all ranks)
+        failure = e
+    if get_world_size() > 1:
+        flag = torch.tensor([1.0 if failure is not None else 0.0], device=device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if flag.item() > 0 and failure is None:
+            failure = RuntimeError("the EMD status check failed on another rank")
+    if failure is not None:
+        raise failure
     for v in val_loss_meters.values():
         v.all_reduce(device)
 
@@ -296,15 +327,16 @@ def train(args, log_dir, exp_name):
     lr = args.lr
     opt_cls = getattr(optim, args.optimizer)
     params = unwrap(net).parameters()
+    if args.get("hip_graph"):
+        # (checked before the optimizer is chosen: Adagrad keeps its step counter on the host -- captured, it would be
+        # baked into the graph; the graphed step applies no loss scale)
+        if world != 1 or args.optimizer not in ('Adam', 'AdamW') or device.type != "cuda" or scale != 1.0:
+            raise ValueError("hip_graph: True needs one rank on a GPU, the Adam / AdamW optimizer and a loss scale of 1")
     if args.optimizer == 'Adagrad':
         optimizer = opt_cls(params, lr=lr, initial_accumulator_value=args.initial_accum_val)
     else:
         betas = tuple(_floats(args.betas))
-        extra = {}
-        if args.get("hip_graph"):
-            if world != 1 or args.optimizer not in ('Adam', 'AdamW') or device.type != "cuda":
-                raise ValueError("hip_graph: True needs one rank on a GPU and the Adam / AdamW optimizer")
-            extra = {"capturable": True}
+        extra = {"capturable": True} if args.get("hip_graph") else {}
         optimizer = opt_cls(params, lr=lr, weight_decay=args.weight_decay, betas=betas, **extra)
 
     if args.load_model:

@@ -224,7 +224,8 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
       pm = __builtin_fminf(pm, o.w);
     }
     c_lo[c] = make_float4(bx0, by0, bz0, c_start[c + 1] > c_start[c] ? pm : 0.f);
-    c_hi[c] = make_float4(bx1, by1, bz1, c_start[c + 1] - c_start[c] > 16 ? 1.f : 0.f);
+    // .w: the cell's members in chunks of 16, minus one, at most 7 (a search lists a cell once per chunk)
+    c_hi[c] = make_float4(bx1, by1, bz1, (float)min(7, max(0, c_start[c + 1] - c_start[c] - 1) >> 4));
   }
   // this member's unassigned list, as the first kernel left it
   int *my_ulist = sc.ulist + (size_t)wg * 2 * n;
@@ -454,10 +455,10 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
             s[r] = 0;
             s1[r] = 0;
             if (k < nlist) {
-              const int cw = wl[k], cc = cw & 0x7FFF;
-              const int m0 = c_start[cc], m1 = c_start[cc + 1];
-              s[r] = (cw & 0x8000) ? m0 + 16 + sl : m0 + sl;
-              s1[r] = (cw & 0x8000) ? m1 : min(m1, m0 + 16);
+              const int cw = wl[k], cc = cw & 0x7FF, q = cw >> 11;   // cell, chunk of 16 members
+              const int m0 = c_start[cc] + 16 * q, m1 = c_start[cc + 1];
+              s[r] = m0 + sl;
+              s1[r] = q == 7 ? m1 : min(m1, m0 + 16);   // (the eighth chunk stands for everything behind it)
             }
           }
           bool more = true;
@@ -539,7 +540,8 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
         }
         for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
           const int i = cb + lane;
-          bool cpass = false, big_cell = false;
+          bool cpass = false;
+          int extra = 0;
           int c = 0;
           if (i < nsub) {
             // exact small-integer division via float (i < 1728, divisors <= 144)
@@ -554,24 +556,27 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
             const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
             const float tq = st.tm - cl.w;
             cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
-            big_cell = ch.w != 0.f;
+            extra = cpass ? (int)ch.w : 0;
           }
-          // A cell with more than 16 members is listed twice: the second entry (bit 15) stands for
-          // members 16.. -- they travel in the same round trip as everything else of the visit step
-          // instead of in a second, dependent one (12 % of the cells, i.e. two of three bids).
-          const bool big = cpass && big_cell;
-          const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
+          // A cell is listed once per chunk of 16 members (up to 8 entries; round 2 listed cells of 17..32 members
+          // twice): everything of the cell travels in the round trips of the visit steps, 16 chunks per step,
+          // instead of in dependent passes of 16 members each -- on surface-shaped clouds (MVP's: 30-200
+          // objects in an occupied cell) a visit took 3-8 such extra passes (profiles/r4_emd_surfaces.txt).
+          const unsigned long long cmask = __ballot(cpass), e0 = __ballot((extra & 1) != 0), e1 = __ballot((extra & 2) != 0),
+                                   e2 = __ballot((extra & 4) != 0);
+          const int total = __builtin_popcountll(cmask) + __builtin_popcountll(e0) + 2 * __builtin_popcountll(e1) +
+                            4 * __builtin_popcountll(e2);
+          if (nlist + total > 4 * kRowListCap) visit();   // keep room (a batch adds at most 64 x 8 = the whole list)
           if (cpass) {
             const unsigned long long lt = (1ull << lane) - 1ull;
-            const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(bmask & lt);
-            wl[pos] = (unsigned short)c;
-            if (big) wl[pos + 1] = (unsigned short)(c | 0x8000);
+            const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(e0 & lt) +
+                            2 * __builtin_popcountll(e1 & lt) + 4 * __builtin_popcountll(e2 & lt);
+            for (int q = 0; q <= extra; ++q) wl[pos + q] = (unsigned short)(c | (q << 11));
           }
-          nlist += __builtin_popcountll(cmask) + __builtin_popcountll(bmask);
+          nlist += total;
   #ifdef MVP_EMD_PROFILE
           prof_cells += __builtin_popcountll(cmask);
   #endif
-          if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells
         }
       }
       visit();

@@ -453,16 +453,19 @@ __global__ __launch_bounds__(kScThreads) void gather_max_lds_kernel(
       bi[q] = 0;
     }
     for (int j = 0; j < k; ++j) {
-      const int s = id[(size_t)p * k + j];
+      // (an index outside the cloud would be an LDS read outside the strip: clamped, as no valid input has one)
+      const int s = min(max(id[(size_t)p * k + j], 0), n_src - 1);
       if (j == 0) {
 #pragma unroll
-        for (int q = 0; q < kGmChan; ++q) bi[q] = s;   // a row of -inf / NaN keeps the first neighbour
+        for (int q = 0; q < kGmChan; ++q) bi[q] = s;   // a row of -inf keeps the first neighbour
       }
 #pragma unroll
       for (int q = 0; q < kGmChan; ++q) {
         if (q < cn) {
           const float v = rows[q * n_src + s];
-          const bool gt = v > best[q];              // strict: the first maximum wins (torch.max's rule)
+          // strict: the first maximum wins, and the first NaN wins for good (torch.max's rules: a diverging
+          // run shows its NaN at the pooling layer, as on the gather_points + torch.max route)
+          const bool gt = v > best[q] || (v != v && best[q] == best[q]);
           best[q] = gt ? v : best[q];
           bi[q] = gt ? s : bi[q];
         }

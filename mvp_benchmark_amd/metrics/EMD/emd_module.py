@@ -23,6 +23,8 @@ explicit `emd_module.check()` (blocking; the eval loop calls it once at the
 end) -- raises MvpOpsError for any call that failed (`LAZY_STATUS = False`
 switches that off).  `CHECK_STATUS = True` checks synchronously in the same call.
 """
+import threading
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -38,6 +40,7 @@ CHECK_STATUS = False
 LAZY_STATUS = True
 _PENDING = []          # (event, pinned int64 rounds, description) of calls not examined yet
 _PINNED_POOL = []      # recycled pinned buffers
+_LOCK = threading.RLock()   # both lists: forward may run on several threads (nn.DataParallel, one per GPU)
 
 
 def _examine(rounds, what):
@@ -47,44 +50,71 @@ def _examine(rounds, what):
                           % (bad.numel(), what, bad.tolist()))
 
 
+def _capturing(device=None):
+    """True while `device`'s current stream is being captured into a graph: event queries, pinned copies
+    and the rest of this bookkeeping are not graph work (and an event query would invalidate the capture)."""
+    if not torch.cuda.is_available():
+        return False
+    if device is None:
+        return torch.cuda.is_current_stream_capturing()
+    with torch.cuda.device(device):
+        return torch.cuda.is_current_stream_capturing()
+
+
 def check(block=True):
-    """Examine the status words of the EMD calls made so far (block=True: wait for them)."""
-    keep = []
-    try:
-        while _PENDING:
-            ev, host, what = _PENDING.pop(0)
-            if block:
-                ev.synchronize()
-            elif not ev.query():
-                keep.append((ev, host, what))
-                continue
-            try:
-                _examine(host, what)
-            finally:
-                if len(_PINNED_POOL) < 8:
-                    _PINNED_POOL.append(host)
-    finally:
-        _PENDING[:0] = keep
+    """Examine the status words of the EMD calls made so far (block=True: wait for them).
+    A no-op while a stream is being captured (nothing may be queried then)."""
+    if _capturing():
+        return
+    with _LOCK:
+        keep = []
+        try:
+            while _PENDING:
+                ev, host, what = _PENDING.pop(0)
+                if block:
+                    ev.synchronize()
+                elif not ev.query():
+                    keep.append((ev, host, what))
+                    continue
+                try:
+                    _examine(host, what)
+                finally:
+                    if len(_PINNED_POOL) < 8:
+                        _PINNED_POOL.append(host)
+        finally:
+            _PENDING[:0] = keep
 
 
 def _file_status(scratch, nbytes, batchsize, n, eps, iters):
-    if torch.cuda.is_current_stream_capturing():
+    """Copy the call's status words to pinned memory behind its kernels and file an event that says when
+    they have landed.  Copy and event belong to the stream the kernels were launched on: the current stream
+    of the TENSORS' device, which need not be the current device (nn.DataParallel drives several)."""
+    device = scratch.device
+    if _capturing(device):
         return              # (a captured graph replays the launch, not this bookkeeping)
     rounds = scratch[nbytes - batchsize * 16:].view(torch.int64).view(batchsize, 2)[:, 0]
-    host = None
-    for i, h in enumerate(_PINNED_POOL):
-        if h.numel() == batchsize:
-            host = _PINNED_POOL.pop(i)
-            break
+    with _LOCK:
+        host = None
+        for i, h in enumerate(_PINNED_POOL):
+            if h.numel() == batchsize:
+                host = _PINNED_POOL.pop(i)
+                break
     if host is None:
         host = torch.empty(batchsize, dtype=torch.int64, pin_memory=True)
-    host.copy_(rounds, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    _PENDING.append((ev, host, "b=%d n=%d eps=%g iters=%d" % (batchsize, n, eps, iters)))
-    if len(_PENDING) > 64:      # bounded: a loop that never reaches check() still examines the old ones
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device)
+        with torch.cuda.stream(stream):
+            host.copy_(rounds, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+    with _LOCK:
+        _PENDING.append((ev, host, "b=%d n=%d eps=%g iters=%d on %s" % (batchsize, n, eps, iters, device)))
+        overfull = len(_PENDING) > 64
+    if overfull:      # bounded: a loop that never reaches check() still examines the old ones
         check(block=False)
-        if len(_PENDING) > 64:
+        with _LOCK:
+            overfull = len(_PENDING) > 64
+        if overfull:
             check(block=True)
 
 
@@ -104,7 +134,7 @@ class emdFunction(Function):
         xyz1 = xyz1.contiguous().float()
         xyz2 = xyz2.contiguous().float()
         device = xyz1.device
-        if LAZY_STATUS and _PENDING:
+        if LAZY_STATUS and _PENDING and not _capturing(device):
             check(block=False)
         dist = torch.zeros(batchsize, n, device=device)
         assignment = torch.zeros(batchsize, n, device=device,

@@ -570,6 +570,57 @@ def test_emd_backward_and_guards(oracle):
         emd()(dev(x1[:, :1000]), dev(x2[:, :1000]), 0.005, 50)
 
 
+def test_emd_lazy_status_follows_the_tensors_stream():
+    """The status words of a call are copied, and their event recorded, on the stream the kernels ran on -- the
+    current stream of the tensors' device (the event was recorded on the current device's default
+    stream, so on another stream / device it completed at once and check() read the buffer before the copy
+    landed).  A side stream kept busy by a long kernel: the filed event must not be complete yet."""
+    from mvp_benchmark_amd.metrics import emd
+    from mvp_benchmark_amd.metrics.EMD import emd_module
+    emd_module.check(block=True)
+    assert not emd_module._PENDING
+    x1, x2 = dev(rand_clouds(601, 2, 1024, 3)), dev(rand_clouds(602, 2, 1024, 3))
+    side = torch.cuda.Stream()
+    big = torch.rand(8192, 8192, device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big = big @ big * 1e-4          # ~100 ms of work ahead of the auction on this stream
+        dist, ass = emd()(x1, x2, 0.005, 50)
+    assert len(emd_module._PENDING) == 1
+    ev = emd_module._PENDING[0][0]
+    assert not ev.query()                   # still behind the side stream's work (the default stream is idle)
+    emd_module.check(block=False)
+    assert len(emd_module._PENDING) == 1    # not examined early
+    emd_module.check(block=True)            # waits for the side stream, examines, raises nothing
+    assert not emd_module._PENDING
+    side.synchronize()
+    assert float(dist.min()) >= 0 and int(ass.min()) >= 0
+
+
+def test_emd_lazy_status_is_silent_under_graph_capture():
+    """Inside a stream capture nothing may be queried: forward must neither examine earlier calls nor file
+    its own (the replayed graph re-runs the launch, not the bookkeeping)."""
+    from mvp_benchmark_amd.metrics import emd
+    from mvp_benchmark_amd.metrics.EMD import emd_module
+    x1, x2 = dev(rand_clouds(611, 2, 1024, 3)), dev(rand_clouds(612, 2, 1024, 3))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            d0, a0 = emd()(x1, x2, 0.005, 50)            # warm-up on the capture stream: files entries
+    s.synchronize()
+    assert emd_module._PENDING
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        d1, a1 = emd()(x1, x2, 0.005, 50)
+    pending = len(emd_module._PENDING)
+    g.replay()
+    torch.cuda.synchronize()
+    assert len(emd_module._PENDING) == pending             # the capture filed nothing
+    assert torch.equal(d1, d0) and torch.equal(a1, a0)
+    emd_module.check(block=True)
+
+
 def test_emd_full_size_self_consistency():
     """Headline shape (64, 16384), eval settings: the identity the reference's
     test_emd prints (emd_module.py:100-104) plus near-bijection."""
@@ -914,6 +965,31 @@ def test_gather_max_matches_oracle_composition(oracle, b, c, n, p, k, kind):
         with pytest.raises(_lib.MvpOpsError):
             _lib.call("mvp_gather_max", DEV, b, c, n, p, k, dev(f), dev(idx), torch.empty(b, c, p, device=DEV),
                       torch.empty(b, c, p, dtype=torch.int32, device=DEV))
+
+
+def test_gather_max_propagates_nan_like_torch_max():
+    """A NaN among the neighbours gives NaN (and the first NaN as the winner), a row of -inf keeps -inf and the
+    first neighbour -- torch.max's rules, i.e. what the gather_points + torch.max route of the same wrapper
+    (rows longer than the LDS strip, MVP_NO_GATHER_MAX) and the reference (model_utils.py:101-104) give."""
+    from mvp_benchmark_amd import _lib
+    b, c, n, p, k = 2, 5, 300, 64, 8
+    rng = np.random.default_rng(3)
+    f = rand_clouds(21, b, c, n)
+    f[0, 1, ::7] = np.nan
+    f[1, 2, :] = -np.inf
+    f[1, 3, 5] = np.nan
+    idx = rng.integers(0, n, (b, p, k)).astype(np.int32)
+    idx[1, 0, 3] = 5
+    out = torch.empty(b, c, p, device=DEV)
+    arg = torch.empty(b, c, p, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_gather_max", DEV, b, c, n, p, k, dev(f), dev(idx), out, arg)
+    tf = torch.tensor(f)
+    g = torch.gather(tf.unsqueeze(2).expand(b, c, p, n), 3, torch.tensor(idx).long().unsqueeze(1).expand(b, c, p, k))
+    want, j = g.max(-1)
+    np.testing.assert_array_equal(out.cpu().numpy(), want.numpy())            # (NaN == NaN under assert_array_equal)
+    want_arg = torch.gather(torch.tensor(idx).long().unsqueeze(1).expand(b, c, p, k), 3, j.unsqueeze(-1))[..., 0]
+    np.testing.assert_array_equal(arg.cpu().numpy(), want_arg.numpy())
+    assert torch.isnan(out[1, 3, 0]) and int(arg[1, 3, 0]) == 5
 
 
 def test_scatter_gradient_index_cache(oracle):

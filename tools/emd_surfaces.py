@@ -1,0 +1,104 @@
+"""EMD on surface-shaped clouds: MVP clouds are samples of 2-manifolds
+(completion/dataset.py:21-34, completion/README.md:21-32), the bench's are uniform volumes.
+
+  python tools/emd_surfaces.py [B] [N] [split ...]
+
+Per workload: time of mvp_emd_forward (best of 3, eval setting eps 0.004 / 3000 rounds), rounds, bids per cloud,
+the reference-equivalent pair evaluations per second (bids x N / time: what the reference's exhaustive Bid kernel
+would evaluate, emd_cuda.cu:120-160), and whether every `split` setting gives the same bits."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvp_benchmark_amd import _lib  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def sphere(g, b, n):
+    v = torch.randn(b, n, 3, generator=g)
+    return 0.5 + 0.4 * v / v.norm(dim=2, keepdim=True)
+
+
+def torus(g, b, n):
+    u, v = 2 * np.pi * torch.rand(b, n, generator=g), 2 * np.pi * torch.rand(b, n, generator=g)
+    R, r = 0.3, 0.12
+    return torch.stack([0.5 + (R + r * torch.cos(v)) * torch.cos(u), 0.5 + (R + r * torch.cos(v)) * torch.sin(u),
+                        0.5 + r * torch.sin(v)], 2)
+
+
+def box(g, b, n):
+    p = torch.rand(b, n, 3, generator=g)
+    face = torch.randint(0, 6, (b, n), generator=g)
+    axis, side = face % 3, (face // 3).float()
+    p.scatter_(2, axis.unsqueeze(2), side.unsqueeze(2))
+    return 0.15 + 0.7 * p
+
+
+def chair(g, b, n):
+    """A crude MVP-like shape: seat + back (thin slabs' surfaces) + four legs (thin cylinders)."""
+    part = torch.rand(b, n, generator=g)
+    p = torch.rand(b, n, 3, generator=g)
+    seat = torch.stack([0.2 + 0.6 * p[..., 0], 0.2 + 0.6 * p[..., 1], 0.45 + 0.04 * (p[..., 2] > 0.5).float()], 2)
+    back = torch.stack([0.2 + 0.6 * p[..., 0], 0.76 + 0.04 * (p[..., 1] > 0.5).float(), 0.49 + 0.4 * p[..., 2]], 2)
+    ang = 2 * np.pi * p[..., 0]
+    leg = (p[..., 1] * 4).long().clamp(max=3)
+    cx, cy = 0.25 + 0.5 * (leg % 2).float(), 0.25 + 0.5 * (leg // 2).float()
+    legs = torch.stack([cx + 0.02 * torch.cos(ang), cy + 0.02 * torch.sin(ang), 0.05 + 0.4 * p[..., 2]], 2)
+    out = torch.where((part < 0.45).unsqueeze(2), seat, torch.where((part < 0.8).unsqueeze(2), back, legs))
+    return out
+
+
+SHAPES = {"sphere": sphere, "torus": torus, "box": box, "chair": chair}
+
+
+def run(x1, x2, split):
+    _lib.emd_configure(split=split)
+    b, n = x1.shape[:2]
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    dist = torch.zeros(b, n, device=dev)
+    ass = torch.zeros(b, n, dtype=torch.int32, device=dev)
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call("mvp_emd_forward", dev, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    rec = _lib.emd_records(scratch, nbytes, b)
+    return best, dist.clone(), ass.clone(), rec
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+    splits = [int(a) for a in sys.argv[3:]] or [_lib.EMD_DEFAULT_SPLIT]
+    g = torch.Generator().manual_seed(11)
+    cases = {"uniform volume vs uniform volume": (torch.rand(B, n, 3, generator=g), torch.rand(B, n, 3, generator=g))}
+    for name, f in SHAPES.items():
+        gt = f(g, B, n)
+        cases["%s: independent samples" % name] = (f(g, B, n), gt)
+        for sigma in (0.01, 0.03):
+            cases["%s: gt + noise %.2f" % (name, sigma)] = (gt + sigma * torch.randn(B, n, 3, generator=g), gt)
+    cases["sphere shell vs uniform volume"] = (sphere(g, B, n), torch.rand(B, n, 3, generator=g))
+    print("# B = %d, N = %d, eps 0.004, 3000 rounds; splits %s" % (B, n, splits), flush=True)
+    for name, (x1, x2) in cases.items():
+        x1, x2 = x1.float().to(dev).contiguous(), x2.float().to(dev).contiguous()
+        outs = [run(x1, x2, s) for s in splits]
+        same = all(torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2]) for o in outs)
+        rec = outs[0][3]
+        bids = float(rec["bids"].mean())
+        times = " / ".join("%.2f" % o[0] for o in outs)
+        print("%-36s %s ms | rounds max %d mean %.0f | bids/cloud %.0f | ref-equivalent %.2e pair evals/s | identical %s"
+              % (name, times, int(rec["rounds"].max()), float(rec["rounds"].mean()), bids,
+                 bids * B * n / (outs[0][0] * 1e-3), same), flush=True)
+    _lib.emd_configure(split=_lib.EMD_DEFAULT_SPLIT)
+
+
+if __name__ == "__main__":
+    main()
