@@ -382,8 +382,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       bz1 = __builtin_fmaxf(bz1, o.z);
     }
     c_lo[c] = make_float4(bx0, by0, bz0, 0.f);
-    // (.w: the cell holds more than 16 objects -- it is listed twice by the searches, see there)
-    c_hi[c] = make_float4(bx1, by1, bz1, c_start[c + 1] - c_start[c] > 16 ? 1.f : 0.f);
+    // (.w: the cell's members in chunks of 16, minus one, at most 31 -- a search lists a cell once per chunk, see there)
+    c_hi[c] = make_float4(bx1, by1, bz1, (float)min(31, max(0, c_start[c + 1] - c_start[c] - 1) >> 4));
   }
   __syncthreads();
 
@@ -577,10 +577,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               s[r4] = 0;
               s1[r4] = 0;
               if (k < nlist) {
-                const int cw = wl[k], cc = cw & 0x7FFF;
-                const int m0 = c_start[cc], m1 = c_start[cc + 1];
-                s[r4] = (cw & 0x8000) ? m0 + 16 + l16 : m0 + l16;
-                s1[r4] = (cw & 0x8000) ? m1 : min(m1, m0 + 16);
+                const int cw = wl[k], cc = cw & 0x7FF, q = cw >> 11;   // cell, chunk of 16 members
+                const int m0 = c_start[cc] + 16 * q, m1 = c_start[cc + 1];
+                s[r4] = m0 + l16;
+                s1[r4] = q == 7 ? m1 : min(m1, m0 + 16);   // (here the eighth chunk stands for everything behind it)
               }
             }
             bool more = true;
@@ -604,7 +604,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         };
         for (int cb = 0; __any(cb < nsub); cb += 16) {
           const int i = cb + l16;
-          bool cpass = false, big_cell = false;
+          bool cpass = false;
+          int extra = 0;   // further chunks of 16 members (this schedule lists at most 8 per cell)
           int c = 0;
           if (i < nsub) {
             // exact small-integer division via float (i < 1728, divisors <= 144)
@@ -614,25 +615,41 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             const int kx = rem - ky * nx;
             c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
             const float4 cl = c_lo[c], ch = c_hi[c];
-            big_cell = ch.w != 0.f;
+            extra = min(7, (int)ch.w);
             const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
             const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
             const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
             const float tq = tm - cl.w;
             cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
           }
-          // (a cell with more than 16 members is listed twice, see the one-bidder-per-wave path)
-          const bool big = cpass && big_cell;
+          // (a cell is listed once per chunk of 16 members, see the one-bidder-per-wave path; cells of more than 32
+          // members -- surface-shaped clouds -- get their further entries in the rare branch below)
+          extra = cpass ? extra : 0;
+          const bool big = extra >= 1, huge = extra >= 2;
           const unsigned rmask = (unsigned)((__ballot(cpass) >> rsh) & 0xFFFFull);
           const unsigned bmask = (unsigned)((__ballot(big) >> rsh) & 0xFFFFull);
           if (cpass) {
             const unsigned lt = (1u << l16) - 1u;
             const int pos = nlist + __builtin_popcount(rmask & lt) + __builtin_popcount(bmask & lt);
             wl[pos] = (unsigned short)c;
-            if (big) wl[pos + 1] = (unsigned short)(c | 0x8000);
+            if (big) wl[pos + 1] = (unsigned short)(c | (1 << 11));
           }
           nlist += __builtin_popcount(rmask) + __builtin_popcount(bmask);
-          if (__any(nlist > kRowListCap - 32)) visit();  // keep room for the next 16 cells
+          if (__builtin_expect(__any(huge), 0)) {
+            // further chunks 2 .. extra of this row's cells: positions by a prefix sum over the row's 16 lanes
+            const int cntx = huge ? extra - 1 : 0;   // <= 6 each, <= 96 per row
+            int incl = cntx;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+              const int up = __shfl_up(incl, off, 16);
+              if (l16 >= off) incl += up;
+            }
+            const int rowtot = __shfl(incl, 15, 16);
+            if (__any(nlist + rowtot > kRowListCap)) visit();
+            for (int q = 0; q < cntx; ++q) wl[nlist + incl - cntx + q] = (unsigned short)(c | ((q + 2) << 11));
+            nlist += rowtot;
+          }
+          if (__any(nlist > kRowListCap - 32)) visit();  // keep room for the next 16 cells' first two chunks
         }
         visit();
 
@@ -803,10 +820,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             s[r] = 0;
             s1[r] = 0;
             if (k < nlist) {
-              const int cw = wl[k], cc = cw & 0x7FFF;
-              const int m0 = c_start[cc], m1 = c_start[cc + 1];
-              s[r] = (cw & 0x8000) ? m0 + 16 + sl : m0 + sl;
-              s1[r] = (cw & 0x8000) ? m1 : min(m1, m0 + 16);
+              const int cw = wl[k], cc = cw & 0x7FF, q = cw >> 11;   // cell, chunk of 16 members
+              const int m0 = c_start[cc] + 16 * q, m1 = c_start[cc + 1];
+              s[r] = m0 + sl;
+              s1[r] = q == 31 ? m1 : min(m1, m0 + 16);   // (chunk 31 stands for everything behind it: cells of > 512 members)
             }
           }
           bool more = true;
@@ -866,7 +883,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       }
       for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
         const int i = cb + lane;
-        bool cpass = false, big_cell = false;
+        bool cpass = false;
+        int extra = 0;
         int c = 0;
         if (i < nsub) {
           // exact small-integer division via float (i < 1728, divisors <= 144)
@@ -881,24 +899,35 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
           const float tq = st.tm - cl.w;
           cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
-          big_cell = ch.w != 0.f;
+          extra = cpass ? (int)ch.w : 0;
         }
-        // A cell with more than 16 members is listed twice: the second entry (bit 15) stands for
-        // members 16.. -- they travel in the same round trip as everything else of the visit step
-        // instead of in a second, dependent one (12 % of the cells, i.e. two of three bids).
-        const bool big = cpass && big_cell;
+        // A cell is listed once per chunk of 16 members: they all travel in the round trips of the visit
+        // steps, 16 chunks per step, instead of in dependent passes of 16 members each (cells of 17..32
+        // members: 12 % of the cells of a uniform cloud, i.e. two of three bids; surface-shaped clouds hold
+        // 30-200 objects per occupied cell).  The first two chunks are placed by the lanes themselves, cells
+        // of more than 32 members are taken one by one.
+        const bool big = extra >= 1, huge = extra >= 2;
         const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
+        unsigned long long hmask = __ballot(huge);
         if (cpass) {
           const unsigned long long lt = (1ull << lane) - 1ull;
           const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(bmask & lt);
           wl[pos] = (unsigned short)c;
-          if (big) wl[pos + 1] = (unsigned short)(c | 0x8000);
+          if (big) wl[pos + 1] = (unsigned short)(c | (1 << 11));
         }
         nlist += __builtin_popcountll(cmask) + __builtin_popcountll(bmask);
+        while (__builtin_expect(hmask != 0ull, 0)) {
+          const int l = (int)__builtin_ctzll(hmask);
+          hmask &= hmask - 1ull;
+          const int cc = __builtin_amdgcn_readlane(c, l), ne = __builtin_amdgcn_readlane(extra, l) - 1;   // chunks 2 .. extra
+          if (nlist + ne > 4 * kRowListCap) visit();
+          if (lane < ne) wl[nlist + lane] = (unsigned short)(cc | ((lane + 2) << 11));
+          nlist += ne;
+        }
 #ifdef MVP_EMD_PROFILE
         prof_cells += __builtin_popcountll(cmask);
 #endif
-        if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells
+        if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells' first two chunks
       }
       visit();
 #ifdef MVP_EMD_PROFILE

@@ -224,8 +224,8 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
       pm = __builtin_fminf(pm, o.w);
     }
     c_lo[c] = make_float4(bx0, by0, bz0, c_start[c + 1] > c_start[c] ? pm : 0.f);
-    // .w: the cell's members in chunks of 16, minus one, at most 7 (a search lists a cell once per chunk)
-    c_hi[c] = make_float4(bx1, by1, bz1, (float)min(7, max(0, c_start[c + 1] - c_start[c] - 1) >> 4));
+    // .w: the cell's members in chunks of 16, minus one, at most 31 (a search lists a cell once per chunk)
+    c_hi[c] = make_float4(bx1, by1, bz1, (float)min(31, max(0, c_start[c + 1] - c_start[c] - 1) >> 4));
   }
   // this member's unassigned list, as the first kernel left it
   int *my_ulist = sc.ulist + (size_t)wg * 2 * n;
@@ -458,7 +458,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
               const int cw = wl[k], cc = cw & 0x7FF, q = cw >> 11;   // cell, chunk of 16 members
               const int m0 = c_start[cc] + 16 * q, m1 = c_start[cc + 1];
               s[r] = m0 + sl;
-              s1[r] = q == 7 ? m1 : min(m1, m0 + 16);   // (the eighth chunk stands for everything behind it)
+              s1[r] = q == 31 ? m1 : min(m1, m0 + 16);   // (chunk 31 stands for everything behind it: cells of > 512 members)
             }
           }
           bool more = true;
@@ -558,22 +558,31 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
             cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
             extra = cpass ? (int)ch.w : 0;
           }
-          // A cell is listed once per chunk of 16 members (up to 8 entries; round 2 listed cells of 17..32 members
-          // twice): everything of the cell travels in the round trips of the visit steps, 16 chunks per step,
-          // instead of in dependent passes of 16 members each -- on surface-shaped clouds (MVP's: 30-200
-          // objects in an occupied cell) a visit took 3-8 such extra passes (profiles/r4_emd_surfaces.txt).
-          const unsigned long long cmask = __ballot(cpass), e0 = __ballot((extra & 1) != 0), e1 = __ballot((extra & 2) != 0),
-                                   e2 = __ballot((extra & 4) != 0);
-          const int total = __builtin_popcountll(cmask) + __builtin_popcountll(e0) + 2 * __builtin_popcountll(e1) +
-                            4 * __builtin_popcountll(e2);
-          if (nlist + total > 4 * kRowListCap) visit();   // keep room (a batch adds at most 64 x 8 = the whole list)
+          // A cell is listed once per chunk of 16 members (round 2 listed cells of 17..32 members twice):
+          // everything of the cell travels in the round trips of the visit steps, 16 chunks per step, instead
+          // of in dependent passes of 16 members each -- on surface-shaped clouds (MVP's: 30-200 objects in an
+          // occupied cell) a visit took 3-8 such extra passes (profiles/r4_emd_surfaces.txt).  The first two
+          // chunks are placed by the lanes themselves; cells of more than 32 members (none in most searches on
+          // uniform clouds) are taken one by one below.
+          const bool big = extra >= 1, huge = extra >= 2;
+          const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
+          unsigned long long hmask = __ballot(huge);
           if (cpass) {
             const unsigned long long lt = (1ull << lane) - 1ull;
-            const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(e0 & lt) +
-                            2 * __builtin_popcountll(e1 & lt) + 4 * __builtin_popcountll(e2 & lt);
-            for (int q = 0; q <= extra; ++q) wl[pos + q] = (unsigned short)(c | (q << 11));
+            const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(bmask & lt);
+            wl[pos] = (unsigned short)c;
+            if (big) wl[pos + 1] = (unsigned short)(c | (1 << 11));
           }
-          nlist += total;
+          nlist += __builtin_popcountll(cmask) + __builtin_popcountll(bmask);
+          while (__builtin_expect(hmask != 0ull, 0)) {
+            const int l = (int)__builtin_ctzll(hmask);
+            hmask &= hmask - 1ull;
+            const int cc = __builtin_amdgcn_readlane(c, l), ne = __builtin_amdgcn_readlane(extra, l) - 1;   // chunks 2 .. extra
+            if (nlist + ne > 4 * kRowListCap) visit();
+            if (lane < ne) wl[nlist + lane] = (unsigned short)(cc | ((lane + 2) << 11));
+            nlist += ne;
+          }
+          if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells' first two chunks
   #ifdef MVP_EMD_PROFILE
           prof_cells += __builtin_popcountll(cmask);
   #endif
