@@ -8,7 +8,7 @@ on pred, gt = (64, 16384, 3) uniform [0,1) clouds per GPU (BASELINE.json
 metric: "point-pairs/sec CD+EMD @2048->16384 pts, batch 64").  Inputs are
 resident in HBM before the timed region.  value = B*N*M*n_gpus / time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload eval|vrcnet_train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload eval|vrcnet_train|pcn_eval]
 
 N > 1: one rank per GPU over RCCL.  Started by the driver under
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
@@ -25,6 +25,10 @@ cfgs/vrcnet.yaml): DDP training steps of VRCNet, 32 clouds per rank (global
 batch 32*N), CD loss, Adam; its line reports samples/s, steps/s, the gradient
 all-reduce volume per step and the RCCL bus bandwidth of an all-reduce of that
 volume measured beside the timed region.
+
+--workload pcn_eval is BASELINE cfg 2 / SURVEY M6 (completion/test.py:23-64, train.py's val(), models/pcn.py:75-112
+with cfgs/pcn_eval16k.yaml): the eval step of PCN at 2048 -> 16384 points, 32 clouds per rank -- network forward,
+calc_cd with F1 on the network's output, calc_emd at the eval setting -- with per-part milliseconds.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
   roofline     -- for the dominant kernel (the persistent EMD auction kernel)
@@ -58,8 +62,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=("eval", "vrcnet_train"), default="eval")
-    ap.add_argument("--batch", type=int, default=None, help="clouds per GPU (eval: 64, vrcnet_train: 32)")
+    ap.add_argument("--workload", choices=("eval", "vrcnet_train", "pcn_eval"), default="eval")
+    ap.add_argument("--batch", type=int, default=None, help="clouds per GPU (eval: 64, vrcnet_train / pcn_eval: 32)")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--eps", type=float, default=0.004)
     ap.add_argument("--iters", type=int, default=3000)
@@ -71,7 +75,7 @@ def parse():
     args = ap.parse_args()
     if args.steps is None:
         # (~7 s of timed region for the eval step: long enough for a 5-s utilisation sampler to see it)
-        args.steps = 150 if args.workload == "eval" else 10
+        args.steps = 150 if args.workload == "eval" else 50 if args.workload == "pcn_eval" else 10
     if args.warmup is None:
         args.warmup = 3
     if args.batch is None:
@@ -511,11 +515,108 @@ def run_vrcnet_train(args, rank, world, dev):
     }
 
 
+def run_pcn_eval(args, rank, world, dev):
+    """BASELINE cfg 2: the completion eval step of PCN, 2048 -> 16384 points, 32 clouds per rank:
+    net(partial, gt, prefix="val") = forward + calc_cd(out2, gt, calc_f1=True) (models/pcn.py:75-112,
+    model_utils.py:35-49), then calc_emd(pred, gt, eps 0.004, 3000 rounds) (model_utils.py:51-57), as val() /
+    test.py run them per batch.  Weights are random (no checkpoint exists here): a random-init PCN emits one tight
+    blob, and an auction between a blob and a spread cloud is a degenerate input that says nothing about the
+    eval loop of a trained network (orders of magnitude more bids; measured once below, outside the timed
+    region).  The timed EMD therefore matches an independent spread cloud of the batch's shape against gt --
+    the network's forward pass and the CD / F1 of its real output are timed as they are."""
+    sys.path.insert(0, os.path.join(ROOT, "completion"))
+    import importlib
+    import model_utils as mu
+    import train
+
+    cfg = train.load_config(os.path.join(ROOT, "completion", "cfgs", "pcn_eval16k.yaml"))
+    cfg.eval_emd = False              # (EMD is called beside the model below, on the spread stand-in)
+    B, n = args.batch, int(cfg.num_points)
+    torch.manual_seed(1)
+    net = importlib.import_module("models.pcn").Model(cfg).to(dev).eval()
+    g = torch.Generator().manual_seed(1000 + rank)
+    partial = torch.rand(B, 3, 2048, generator=g).to(dev)
+    gt = torch.rand(B, n, 3, generator=g).to(dev)
+    pred_like = torch.rand(B, n, 3, generator=g).to(dev)
+
+    def step():
+        with torch.no_grad():
+            r = net(partial, gt, prefix="val")
+            e = mu.calc_emd(pred_like, gt, eps=args.eps, iterations=args.iters)
+        return r, e
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r, e = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+
+    # per-part milliseconds, outside the timed region (events on the current stream, mean of 5)
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, out
+
+    with torch.no_grad():
+        fwd_ms, out = timed(lambda: net(partial, prefix="test"))
+        out2 = out["result"]
+        cd_ms, _ = timed(lambda: mu.calc_cd(out2, gt, calc_f1=True))
+        emd_ms, _ = timed(lambda: mu.calc_emd(pred_like, gt, eps=args.eps, iterations=args.iters))
+        blob_ms, _ = timed(lambda: mu.calc_emd(out2, gt, eps=args.eps, iterations=args.iters), reps=1)
+    mu.check_emd_status()
+    ms = elapsed / args.steps * 1e3
+    return {
+        "metric": "PCN completion eval clouds/sec (cfgs/pcn_eval16k.yaml: 2048 -> 16384 pts, CD + F1 + EMD, batch 32 per GPU)",
+        "value": B * world / (ms * 1e-3),
+        "unit": "clouds/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms,
+        "steps_per_s": 1e3 / ms,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (random-init PCN weights, uniform clouds; EMD on an independent uniform stand-in for the prediction)",
+        "config": {"workload": "PCN eval step: forward (2048 -> %d pts) + calc_cd(f1) on its output + calc_emd eps=%g iters=%d, "
+                               "%d clouds per GPU" % (n, args.eps, args.iters, B),
+                   "batch_per_gpu": B, "points": n, "parallelism": "batch-sharded x%d" % world},
+        "parts_ms": {"pcn_forward": fwd_ms, "calc_cd_f1_on_network_output": cd_ms, "calc_emd_spread_prediction": emd_ms,
+                     "sum": fwd_ms + cd_ms + emd_ms},
+        "extra": {"calc_emd_on_random_init_output_ms": blob_ms,
+                  "note": "random-init PCN output is one tight blob: the auction against a spread cloud is the degenerate case "
+                          "(every person bids every round); shown for completeness, not part of the timed step",
+                  "metrics": {k: float(r[k].mean()) for k in ("cd_p", "cd_t", "f1")}, "emd_mean": float(e.mean())},
+    }
+
+
 def main():
     args = parse()
     rank, world, local_rank = launch_or_join(args)
     dev = init_ranks(world, local_rank)
-    line = (run_eval if args.workload == "eval" else run_vrcnet_train)(args, rank, world, dev)
+    runner = {"eval": run_eval, "vrcnet_train": run_vrcnet_train, "pcn_eval": run_pcn_eval}[args.workload]
+    line = runner(args, rank, world, dev)
     if line is not None:
         print(json.dumps(line), flush=True)
     if world > 1:

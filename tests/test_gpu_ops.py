@@ -332,6 +332,63 @@ def test_emd_cfg4_full_batch_matches_oracle(oracle, emd_split, b, split):
     assert tiered.sum() == 0
 
 
+@pytest.mark.parametrize("split", [2, 1])
+def test_emd_cfg4_n2048_full_batch_clustered_matches_oracle(oracle, emd_split, split):
+    """BASELINE cfg 4, n = 2048 at its FULL batch on the clustered kernels (four workgroups per cloud; the default
+    path, which finishes these clouds LDS-resident, is in test_gpu_emd_resident.py): every cloud against the oracle
+    (2048 and 8192 points had only been compared at B <= 3, i.e. on eight workgroups per cloud)."""
+    from mvp_benchmark_amd import _lib
+    emd_split(split)
+    b, n = 64, 2048
+    x1, x2 = rand_clouds(191, b, n, 3), rand_clouds(192, b, n, 3)
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    dist = torch.zeros(b, n, device=DEV)
+    ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_emd_forward", DEV, b, n, dev(x1), dev(x2), dist, ass, 0.004, 3000, scratch, nbytes)
+    torch.cuda.synchronize()
+    od, oa, ost = oracle.emd_forward(x1, x2, 0.004, 3000, return_stats=True)
+    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
+    rec = _lib.emd_records(scratch, nbytes, b)
+    np.testing.assert_array_equal(rec["rounds"], ost[:, 0])
+    np.testing.assert_array_equal(rec["bids"], ost[:, 1])
+    assert (rec["next_round"] == 0).all() and (rec["final_launch"] <= 2).all()
+    assert set(rec["final_width"][rec["first_handover"] > 0].tolist()) <= {4}      # below 4096 points nothing is dealt out again
+
+
+def test_emd_cfg4_n8192_full_batch_tiered_equals_single_kernel_and_oracle(oracle, emd_split):
+    """BASELINE cfg 4, n = 8192 at its FULL batch: the tiered launches (four workgroups per cloud to round 300, then
+    8 .. 2 by load) against the first kernel running every round alone -- all 64 clouds, distances, assignments,
+    rounds and bids -- and the heaviest and the lightest cloud against the exhaustive oracle (~10 s of CPU each)."""
+    from mvp_benchmark_amd import _lib
+    b, n = 64, 8192
+    x1n, x2n = rand_clouds(193, b, n, 3), rand_clouds(194, b, n, 3)
+    x1, x2 = dev(x1n), dev(x2n)
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    out = {}
+    for split in (0, 2):
+        emd_split(split)
+        scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        dist = torch.zeros(b, n, device=DEV)
+        ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+        _lib.call("mvp_emd_forward", DEV, b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes)
+        torch.cuda.synchronize()
+        out[split] = (dist.cpu().numpy(), ass.cpu().numpy(), _lib.emd_records(scratch, nbytes, b))
+    np.testing.assert_array_equal(out[0][0], out[2][0])
+    np.testing.assert_array_equal(out[0][1], out[2][1])
+    r0, r2 = out[0][2], out[2][2]
+    np.testing.assert_array_equal(r0["rounds"], r2["rounds"])
+    np.testing.assert_array_equal(r0["bids"], r2["bids"])
+    tiered = r2["final_launch"] == 2
+    assert tiered.sum() >= 56 and len(set(r2["final_width"][tiered].tolist())) >= 3, r2["final_width"]
+    heavy, light = int(np.argmax(r2["bids"])), int(np.argmin(r2["bids"]))
+    od, oa, ost = oracle.emd_forward(x1n[[heavy, light]], x2n[[heavy, light]], 0.004, 3000, return_stats=True)
+    np.testing.assert_array_equal(out[2][1][[heavy, light]], oa)
+    np.testing.assert_array_equal(out[2][0][[heavy, light]], od)
+    np.testing.assert_array_equal(r2["bids"][[heavy, light]], ost[:, 1])
+
+
 @pytest.mark.parametrize("b", [33, 40, 61])
 def test_emd_tiered_widths_ragged_batches_match_oracle(oracle, b):
     """The tiered launch with cloud slots left empty (33, 40, 61 clouds in grids laid out for 40 / 40 /
