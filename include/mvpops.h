@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 10
+#define MVP_ABI_VERSION 11
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -228,6 +228,17 @@ int mvp_ball_query(int b, int n, int m, float min_radius, float max_radius,
  * max-heap + heap-sort (knn_cuda.cu:26-53). */
 int mvp_knn(int b, int n, int m, int nsample, const float *xyz,
             const float *new_xyz, int *idx, float *dist2, void *stream);
+
+/* The same result as mvp_knn for large clouds without the exhaustive scan: both point sets are
+ * Morton-sorted into caller scratch (mvp_knn_scratch_bytes(b, n, m) bytes, 16-byte aligned, contents
+ * irrelevant) and every query searches outwards through boxed tiles, keeping k + 1 candidates; queries
+ * whose k + 1 smallest distances are not pairwise different (lattices, duplicates: there the reference's
+ * result depends on its sequence of heap operations, knn_cuda.cu:26-53,80-90) are recomputed by the
+ * exhaustive kernel.  n < 4096, m < 1024 or nsample > 32: forwards to mvp_knn. */
+long long mvp_knn_scratch_bytes(int b, int n, int m);
+int mvp_knn_sorted(int b, int n, int m, int nsample, const float *xyz,
+                   const float *new_xyz, int *idx, float *dist2, void *scratch,
+                   long long scratch_bytes, void *stream);
 
 /* Feature-space neighbour search of the models (no native counterpart in the
  * reference: completion/model_utils.py:242-247 builds `-xx - inner - xx^T` on a

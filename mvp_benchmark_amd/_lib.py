@@ -29,6 +29,7 @@ SIGNATURES = {
     "mvp_furthest_point_sampling_with_dist": "iiippp",
     "mvp_ball_query": "iiiffippp",
     "mvp_knn": "iiiipppp",
+    "mvp_knn_sorted": "iiiipppppq",
     "mvp_topk_gram": "iiippp",
     "mvp_three_nn": "iiipppp",
     "mvp_three_interpolate": "iiiipppp",
@@ -54,7 +55,7 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 10  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 11  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
 EMD_DEFAULT_SPLIT = 3
@@ -90,6 +91,8 @@ def load():
     lib.mvp_fps_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mvp_chamfer_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_chamfer_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.mvp_knn_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_knn_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.mvp_scatter_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_scatter_scratch_bytes.argtypes = [ctypes.c_int] * 4
     lib.mvp_pointwise_wgrad_scratch_bytes.restype = ctypes.c_longlong
@@ -181,6 +184,11 @@ def fps_scratch_bytes(b, n):
     return int(load().mvp_fps_scratch_bytes(int(b), int(n)))
 
 
+def knn_scratch_bytes(b, n, m):
+    """Scratch of mvp_knn_sorted (n candidates, m queries per cloud)."""
+    return int(load().mvp_knn_scratch_bytes(int(b), int(n), int(m)))
+
+
 def chamfer_scratch_bytes(b, n, m):
     return int(load().mvp_chamfer_scratch_bytes(int(b), int(n), int(m)))
 
@@ -202,6 +210,6 @@ def pointwise_wgrad_mfma_scratch_bytes(b, cin, cout, length, with_bias):
 
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
-    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_fps_scratch_bytes", "mvp_fps_cluster_scratch_bytes",
+    return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_knn_scratch_bytes", "mvp_fps_scratch_bytes", "mvp_fps_cluster_scratch_bytes",
             "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes", "mvp_pointwise_wgrad_mfma_scratch_bytes"] \
         + list(SIGNATURES)

@@ -19,6 +19,7 @@
 //     candidate inside it (lowest index wins) -- chamfer3D.cu:36,46,126.
 //   * arithmetic is the canonical fma chain shared with the CPU oracle.
 #include "common.h"
+#include "cs_sort.h"
 
 namespace mvp {
 
@@ -145,33 +146,6 @@ __global__ __launch_bounds__(kCdThreads) void nm_distance_kernel(
 // the current best is still evaluated.  Ties go to the lowest ORIGINAL index
 // (chamfer3D.cu:36,46,126) by minimising the key {distance bits, original
 // index} -- the visiting order no longer is the index order.
-constexpr int kCsThreads = 1024;
-constexpr int kCsCells = 4096;  // 16^3
-constexpr int kCsTile = 16;
-constexpr int kCsBatch = 1024;
-constexpr int kCsPad = 0x7fffffff;  // original index of a padding entry
-
-__host__ __device__ inline long long cs_round_up(long long c) { return (c + kCsBatch - 1) / kCsBatch * kCsBatch; }
-// bytes of one sorted side holding c points: points + tile boxes + batch boxes
-__host__ __device__ inline long long cs_side_bytes(long long c) {
-  const long long cp = cs_round_up(c);
-  return cp * 16 + cp / kCsTile * 32 + cp / kCsBatch * 32;
-}
-
-struct CsSide {
-  float4 *pts;   // cp sorted points (padding: +inf coordinates, index kCsPad)
-  float4 *tbox;  // 2 per tile: lo, hi
-  float4 *bbox;  // 2 per batch: lo, hi
-};
-__host__ __device__ inline CsSide cs_carve(char *base, long long c) {
-  const long long cp = cs_round_up(c);
-  CsSide s;
-  s.pts = reinterpret_cast<float4 *>(base);
-  s.tbox = reinterpret_cast<float4 *>(base + cp * 16);
-  s.bbox = reinterpret_cast<float4 *>(base + cp * 16 + cp / kCsTile * 32);
-  return s;
-}
-
 __device__ __forceinline__ int cs_spread4(int v) {  // bit i -> bit 3i
   v &= 0xF;
   v = (v | (v << 4)) & 0xC3;
@@ -306,32 +280,6 @@ __global__ __launch_bounds__(kCsThreads) void chamfer_sort_kernel(
     out.bbox[2 * bt + 0] = make_float4(bl[0], bl[1], bl[2], 0.f);
     out.bbox[2 * bt + 1] = make_float4(bh[0], bh[1], bh[2], 0.f);
   }
-}
-
-// squared distance between two axis-aligned boxes (0 if they overlap), with
-// the rounding behaviour described above
-__device__ __forceinline__ float cs_box_dist(const float (&qlo)[3], const float (&qhi)[3],
-                                             const float4 &tlo, const float4 &thi) {
-  const float gx = __builtin_fmaxf(__builtin_fmaxf(tlo.x - qhi[0], qlo[0] - thi.x), 0.f);
-  const float gy = __builtin_fmaxf(__builtin_fmaxf(tlo.y - qhi[1], qlo[1] - thi.y), 0.f);
-  const float gz = __builtin_fmaxf(__builtin_fmaxf(tlo.z - qhi[2], qlo[2] - thi.z), 0.f);
-  return sqdist3(gx, gy, gz);
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float cs_dpp_max(float v) {
-  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-  return __builtin_fmaxf(v, o);
-}
-// wave64 maximum with DPP row operations only; result taken from lane 63
-__device__ __forceinline__ float cs_wave_max(float v) {
-  v = cs_dpp_max<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v = cs_dpp_max<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v = cs_dpp_max<0x141, 0xF>(v);  // row_half_mirror
-  v = cs_dpp_max<0x140, 0xF>(v);  // row_mirror
-  v = cs_dpp_max<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
-  v = cs_dpp_max<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 template <int Q>
@@ -567,6 +515,12 @@ extern "C" int mvp_chamfer_forward(int b, int n, int m, const float *xyz1,
   return check_launch("mvp_chamfer_forward");
 }
 
+namespace mvp {
+void cs_sort_launch(int b, int n1, int n2, const float *xyz1, const float *xyz2, char *scratch, hipStream_t stream) {
+  hipLaunchKernelGGL(chamfer_sort_kernel, dim3(2, b), dim3(kCsThreads), 0, stream, n1, n2, xyz1, xyz2, scratch);
+}
+}  // namespace mvp
+
 extern "C" long long mvp_chamfer_scratch_bytes(int b, int n, int m) {
   if (b < 0 || n < 0 || m < 0) return -1;
   return (long long)b * (cs_side_bytes(n) + cs_side_bytes(m));
@@ -584,8 +538,7 @@ extern "C" int mvp_chamfer_forward_sorted(int b, int n, int m, const float *xyz1
   if (scratch_bytes < mvp_chamfer_scratch_bytes(b, n, m)) return MVP_EBADARG;
   if ((reinterpret_cast<uintptr_t>(scratch) & 15) != 0) return MVP_EBADARG;
   if (b > 65535) return MVP_EBADSHAPE;
-  hipLaunchKernelGGL(chamfer_sort_kernel, dim3(2, b), dim3(kCsThreads), 0, as_stream(stream), n, m,
-                     xyz1, xyz2, reinterpret_cast<char *>(scratch));
+  cs_sort_launch(b, n, m, xyz1, xyz2, reinterpret_cast<char *>(scratch), as_stream(stream));
   // One query per lane: a wave's 64 consecutive sorted queries make the
   // smallest box, so the most tiles are skipped (measured: Q = 1 / 2 / 4 ->
   // 0.88 / 1.02 / 1.35 ms at (64, 16384, 16384); exhaustive 3.95 ms).

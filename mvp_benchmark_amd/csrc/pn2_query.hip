@@ -16,6 +16,7 @@
 // All three keep the reference's exact selection/tie semantics (see each
 // kernel) and the canonical distance chain of the oracle.
 #include "common.h"
+#include "cs_sort.h"
 
 namespace mvp {
 
@@ -174,6 +175,199 @@ __global__ __launch_bounds__(T) void knn_kernel(
     for (int i = 0; i < nsample; ++i) {
       o[i] = hi[i * T + t];
       od[i] = hd[i * T + t];
+    }
+  }
+}
+
+// One WAVE per listed query: the reference's sequence of heap operations (admission in index order by strict
+// `<` against the root, reheap, final heap sort: knn_cuda.cu:26-53,80-90) with the 64 lanes screening 64
+// consecutive candidates at a time against the root the step started with -- the survivors, a superset of
+// what the reference admits there, are replayed in index order against the current root.  The fix-up pass of
+// the sorted variant below: a handful of queries per million on random clouds, every query on a lattice.
+constexpr int kFixWaves = 4;
+__global__ __launch_bounds__(kFixWaves * 64) void knn_fix_kernel(
+    int n, int m, int nsample, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    int *__restrict__ idx, float *__restrict__ dist2, const int *__restrict__ fix_cnt, const int *__restrict__ fix_list) {
+  __shared__ float s_hd[kFixWaves][32];
+  __shared__ int s_hi[kFixWaves][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cloud = blockIdx.y;
+  const int cnt = min(fix_cnt[cloud], m);
+  float *hd = s_hd[wave];
+  int *hi = s_hi[wave];
+  const float *pts = xyz + (size_t)cloud * n * 3;
+  for (int e = blockIdx.x * kFixWaves + wave; e < cnt; e += gridDim.x * kFixWaves) {
+    const int p = fix_list[(size_t)cloud * m + e];
+    const float *c = new_xyz + ((size_t)cloud * m + p) * 3;
+    const float nx = c[0], ny = c[1], nz = c[2];
+    if (lane < nsample) {
+      hd[lane] = 1e10f;
+      hi[lane] = 0;
+    }
+    float rootd = 1e10f;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      float d = __builtin_inff();
+      if (i < n) d = sqdist3(nx - pts[(size_t)i * 3 + 0], ny - pts[(size_t)i * 3 + 1], nz - pts[(size_t)i * 3 + 2]);
+      unsigned long long mask = __ballot(d < rootd);
+      while (mask) {
+        const int l = (int)__builtin_ctzll(mask);
+        mask &= mask - 1ull;
+        const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
+        if (dl < rootd) {   // (wave-uniform: every lane runs the same heap update on the wave's LDS column)
+          hd[0] = dl;
+          hi[0] = base + l;
+          knn_reheap<1>(hd, hi, 0, nsample);
+          rootd = hd[0];
+        }
+      }
+    }
+    for (int i = nsample - 1; i > 0; i--) {   // heap_sort
+      const float tf = hd[0];
+      hd[0] = hd[i];
+      hd[i] = tf;
+      const int ti = hi[0];
+      hi[0] = hi[i];
+      hi[i] = ti;
+      knn_reheap<1>(hd, hi, 0, i);
+    }
+    if (lane < nsample) {
+      idx[((size_t)cloud * m + p) * nsample + lane] = hi[lane];
+      dist2[((size_t)cloud * m + p) * nsample + lane] = hd[lane];
+    }
+  }
+}
+
+// Pruned exact variant for large clouds (n >= 4096, k <= 32): the same result with most of the m*n pairs
+// never evaluated.  Both point sets are Morton-sorted with boxes per 16 and per 1024 points (cs_sort.h,
+// chamfer_sort_kernel); a lane owns a query -- a wave's 64 consecutive sorted queries sit in a small box --
+// and keeps a max-heap of its k+1 best candidates in an LDS column; batches are visited outwards from the
+// query block's own position in the order, a batch / tile is skipped when its box is farther from the
+// wave's query box than the worst heap root of the wave, and a tile is evaluated only if some query's own
+// root still reaches its box (strict `>` on monotone box distances, as in the sorted Chamfer kernel).
+// Exactness.  The reference admits candidates in INDEX order by strict `<` against the heap root and ends
+// with a heap sort (knn_cuda.cu:80-90): when the k+1 smallest distances of a query are pairwise different,
+// the k nearest are a unique set and the heap sort returns them in ascending order whatever the order of
+// admission was -- that is what this kernel computes in its own visiting order.  When two of them are EQUAL
+// (lattices, duplicated points) both which candidates stay and where they end up depend on the reference's
+// sequence of heap operations: such queries are flagged and recomputed by knn_kernel, which replays that
+// sequence (knn_fix_kernel, one wave per listed query).
+// (The k+1 candidates of a query live in REGISTERS as an ascending list -- insertion is a branch-free
+// compare/select chain over KL compile-time slots, KL >= nsample + 1; keeping more than needed only loosens
+// the pruning bound.  The exhaustive kernel's LDS heaps, which the reference's tie behaviour needs, cost a
+// dependent LDS round trip per heap level and admission: most of that kernel's time.)
+template <int T, int KL>
+__global__ __launch_bounds__(T) void knn_sorted_kernel(
+    int n, int m, int nsample, char *__restrict__ scratch, int *__restrict__ idx, float *__restrict__ dist2,
+    int *__restrict__ fix_cnt, int *__restrict__ fix_list) {
+  __shared__ __attribute__((aligned(16))) float4 tile[kCsBatch];                 // one batch of candidates
+  __shared__ __attribute__((aligned(16))) float4 tbx[2 * kCsBatch / kCsTile];    // its tiles' boxes
+  const int K1 = nsample + 1;
+
+  const int t = threadIdx.x;
+  const int cloud = blockIdx.y;
+  const long long per_cloud = cs_side_bytes(m) + cs_side_bytes(n);
+  char *cbase = scratch + (size_t)cloud * per_cloud;
+  const CsSide qs = cs_carve(cbase, m), cs = cs_carve(cbase + cs_side_bytes(m), n);
+  int j = blockIdx.x * T + t;   // consecutive in the sorted order
+  const bool valid = j < m;
+  j = valid ? j : m - 1;
+  const float4 q = qs.pts[j];
+  const int qorig = valid ? __float_as_int(q.w) : -1;
+  const float qx = q.x, qy = q.y, qz = q.z;
+  float qlo[3] = {qx, qy, qz}, qhi[3] = {qx, qy, qz};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {  // the wave's query box
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      qlo[a] = __builtin_fminf(qlo[a], __shfl_xor(qlo[a], off, 64));
+      qhi[a] = __builtin_fmaxf(qhi[a], __shfl_xor(qhi[a], off, 64));
+    }
+  }
+  float dd[KL];
+  int ii[KL];
+#pragma unroll
+  for (int i = 0; i < KL; ++i) {
+    dd[i] = 1e10f;
+    ii[i] = 0;
+  }
+  float wmax = 1e10f;   // worst list tail of this wave
+
+  const int nb = (int)(cs_round_up(n) / kCsBatch);
+  const int nblk = (m + T - 1) / T;
+  const int b0 = (int)((long long)blockIdx.x * nb / nblk);  // same relative position in the order
+  // the tile at the wave's own relative position in the candidates' order
+  const int own_tile = (int)(((long long)blockIdx.x * T + (t & ~63) + 32) * (long long)(cs_round_up(n) / kCsTile) / max(1, m));
+  for (int k = 0; k < 2 * nb; ++k) {
+    const int bi = b0 + ((k & 1) ? (k + 1) / 2 : -(k / 2));  // b0, b0+1, b0-1, b0+2, ...
+    if (bi < 0 || bi >= nb) continue;                        // block-uniform
+    const bool need = !(cs_box_dist(qlo, qhi, cs.bbox[2 * bi], cs.bbox[2 * bi + 1]) > wmax);  // wave-uniform
+    if (!__syncthreads_or(need)) continue;
+    for (int i = t; i < kCsBatch; i += T) tile[i] = cs.pts[(size_t)bi * kCsBatch + i];
+    for (int i = t; i < 2 * kCsBatch / kCsTile; i += T) tbx[i] = cs.tbox[(size_t)bi * (2 * kCsBatch / kCsTile) + i];
+    __syncthreads();
+    if (need) {
+      const float lbl = cs_box_dist(qlo, qhi, tbx[2 * (t & 63)], tbx[2 * (t & 63) + 1]);   // lane l: tile l of the batch
+      unsigned long long todo = __ballot(!(lbl > wmax));
+      // tiles are taken outwards from the wave's own relative position in the order (alternately the next one
+      // above and the next one below it): the lists tighten on the nearest tiles first
+      const int own = min(63, max(0, own_tile - bi * (kCsBatch / kCsTile)));
+      bool up = true;
+      while (todo) {
+        const unsigned long long hi_part = todo & (~0ull << own), lo_part = todo & ~(~0ull << own);
+        int s;
+        if ((up && hi_part) || !lo_part) s = (int)__builtin_ctzll(hi_part);
+        else s = 63 - (int)__builtin_clzll(lo_part);
+        up = !up;
+        todo &= ~(1ull << s);
+        if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbl), s)) > wmax) continue;
+        const float4 tlo = tbx[2 * s], thi = tbx[2 * s + 1];
+        const float gx = __builtin_fmaxf(__builtin_fmaxf(tlo.x - qx, qx - thi.x), 0.f);
+        const float gy = __builtin_fmaxf(__builtin_fmaxf(tlo.y - qy, qy - thi.y), 0.f);
+        const float gz = __builtin_fmaxf(__builtin_fmaxf(tlo.z - qz, qz - thi.z), 0.f);
+        if (!__any(!(sqdist3(gx, gy, gz) > dd[KL - 1]))) continue;   // no query's list reaches this tile
+        // (every candidate that ANY lane admits runs the insertion for the whole wave; letting each lane take its
+        // own next survivor -- max-over-lanes(survivors) insertions per tile -- was slower: 0.93 -> 2.09 ms, the
+        // per-lane LDS gather and the loop around it cost more than the insertions they save)
+        bool changed = false;
+#pragma unroll 4
+        for (int c = 0; c < kCsTile; ++c) {
+          const float4 p = tile[s * kCsTile + c];
+          const float d = sqdist3(qx - p.x, qy - p.y, qz - p.z);
+          if (__any(d < dd[KL - 1])) {
+            const int id = __float_as_int(p.w);
+#pragma unroll
+            for (int i = KL - 1; i >= 1; --i) {
+              const bool sh = d < dd[i - 1];
+              const bool here = !sh && d < dd[i];
+              dd[i] = sh ? dd[i - 1] : (here ? d : dd[i]);
+              ii[i] = sh ? ii[i - 1] : (here ? id : ii[i]);
+            }
+            const bool here0 = d < dd[0];
+            dd[0] = here0 ? d : dd[0];
+            ii[0] = here0 ? id : ii[0];
+            changed = true;
+          }
+        }
+        if (changed) wmax = cs_wave_max(dd[KL - 1]);   // (wave-uniform)
+      }
+    }
+    __syncthreads();
+  }
+  // are the k+1 smallest distances pairwise different?  (the list is ascending)
+  if (valid) {
+    bool tie = false;
+#pragma unroll
+    for (int i = 0; i + 1 < KL; ++i) tie |= i + 1 < K1 && dd[i] == dd[i + 1];
+    if (tie) fix_list[(size_t)cloud * m + atomicAdd(&fix_cnt[cloud], 1)] = qorig;
+    int *o = idx + ((size_t)cloud * m + qorig) * nsample;
+    float *od = dist2 + ((size_t)cloud * m + qorig) * nsample;
+#pragma unroll
+    for (int i = 0; i < KL; ++i) {
+      if (i < nsample) {
+        o[i] = ii[i];
+        od[i] = dd[i];
+      }
     }
   }
 }
@@ -500,6 +694,43 @@ extern "C" int mvp_knn(int b, int n, int m, int nsample, const float *xyz,
                        m, nsample, xyz, new_xyz, idx, dist2);
   }
   return check_launch("mvp_knn");
+}
+
+// scratch of mvp_knn_sorted: the sorted sides of every cloud, then b counters (queries to recompute) padded to
+// 16 bytes, then b x m query ids
+static long long knn_cnt_bytes(int b) { return ((long long)b * 4 + 15) / 16 * 16; }
+extern "C" long long mvp_knn_scratch_bytes(int b, int n, int m) {
+  if (b < 0 || n < 0 || m < 0) return -1;
+  return (long long)b * (cs_side_bytes(m) + cs_side_bytes(n)) + knn_cnt_bytes(b) + ((long long)b * m * 4 + 15) / 16 * 16;
+}
+
+extern "C" int mvp_knn_sorted(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx,
+                              float *dist2, void *scratch, long long scratch_bytes, void *stream) {
+  // small clouds / many neighbours: the exhaustive kernel (break-even near 4096 candidates; the heaps of
+  // k + 1 <= 33 entries per query fit the workgroup's LDS)
+  if (b <= 0 || n < 4096 || m < 1024 || nsample < 1 || nsample > 32 || (n > m ? n : m) > (1 << 30))
+    return mvp_knn(b, n, m, nsample, xyz, new_xyz, idx, dist2, stream);
+  if (!xyz || !new_xyz || !idx || !dist2 || !scratch) return MVP_EBADARG;
+  if (scratch_bytes < mvp_knn_scratch_bytes(b, n, m)) return MVP_EBADARG;
+  if ((reinterpret_cast<uintptr_t>(scratch) & 15) != 0) return MVP_EBADARG;
+  if (b > 65535) return MVP_EBADSHAPE;
+  char *sc = reinterpret_cast<char *>(scratch);
+  int *fix_cnt = reinterpret_cast<int *>(sc + (size_t)b * (cs_side_bytes(m) + cs_side_bytes(n)));
+  int *fix_list = reinterpret_cast<int *>(reinterpret_cast<char *>(fix_cnt) + knn_cnt_bytes(b));
+  if (hipMemsetAsync(fix_cnt, 0, (size_t)knn_cnt_bytes(b), as_stream(stream)) != hipSuccess) return check_launch("mvp_knn_sorted");
+  cs_sort_launch(b, m, n, new_xyz, xyz, sc, as_stream(stream));   // side 0: the queries, side 1: the candidates
+  constexpr int T = 256;
+  const dim3 grid((m + T - 1) / T, b);
+  if (nsample <= 8)
+    hipLaunchKernelGGL((knn_sorted_kernel<T, 9>), grid, dim3(T), 0, as_stream(stream), n, m, nsample, sc, idx, dist2, fix_cnt, fix_list);
+  else if (nsample <= 16)
+    hipLaunchKernelGGL((knn_sorted_kernel<T, 17>), grid, dim3(T), 0, as_stream(stream), n, m, nsample, sc, idx, dist2, fix_cnt, fix_list);
+  else
+    hipLaunchKernelGGL((knn_sorted_kernel<T, 33>), grid, dim3(T), 0, as_stream(stream), n, m, nsample, sc, idx, dist2, fix_cnt, fix_list);
+  // queries with equal distances among their k + 1 nearest: the reference's own sequence of heap operations
+  hipLaunchKernelGGL(knn_fix_kernel, dim3(16, b), dim3(kFixWaves * 64), 0, as_stream(stream), n, m, nsample, xyz, new_xyz, idx,
+                     dist2, fix_cnt, fix_list);
+  return check_launch("mvp_knn_sorted");
 }
 
 extern "C" int mvp_topk_gram(int b, int n, int k, const float *dot, const float *sq, int *idx,

@@ -18,7 +18,7 @@ import threading
 import torch
 from torch.autograd import Function
 
-from .._lib import call, fps_scratch_bytes, scatter_scratch_bytes
+from .._lib import call, fps_scratch_bytes, knn_scratch_bytes, scatter_scratch_bytes
 
 
 def _need_contiguous(*tensors):
@@ -183,7 +183,14 @@ class KNN(Function):
         B, npoint, _ = center_xyz.shape
         idx = _new(xyz, B, npoint, k, dtype=torch.int32, zero=True)
         dist2 = _new(xyz, B, npoint, k, zero=True)
-        call("mvp_knn", xyz.device, B, xyz.shape[1], npoint, k, xyz, center_xyz, idx, dist2)
+        n = xyz.shape[1]
+        if n >= 4096 and npoint >= 1024 and k <= 32:
+            # large clouds: Morton-sorted, pruned, the same bits (csrc/pn2_query.hip: knn_sorted_kernel)
+            nbytes = knn_scratch_bytes(B, n, npoint)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
+            call("mvp_knn_sorted", xyz.device, B, n, npoint, k, xyz, center_xyz, idx, dist2, scratch, nbytes)
+        else:
+            call("mvp_knn", xyz.device, B, n, npoint, k, xyz, center_xyz, idx, dist2)
         idx = idx.transpose(2, 1).contiguous()            # (B, k, npoint)
         ctx.mark_non_differentiable(idx)
         return idx

@@ -880,6 +880,52 @@ def test_knn_matches_oracle(oracle, k, n, m):
     np.testing.assert_array_equal(idx.cpu().numpy(), oracle.knn(k, xyz2, ctr))
 
 
+@pytest.mark.parametrize("k,n,m,kind", [(16, 4096, 4096, "random"), (1, 5000, 1024, "random"), (32, 4100, 1500, "random"),
+                                        (9, 8192, 3000, "duplicates"), (16, 4096, 4096, "lattice"), (16, 6000, 2048, "clustered"),
+                                        (16, 16384, 16384, "self")])
+def test_knn_sorted_variant_is_bit_identical(oracle, k, n, m, kind):
+    """mvp_knn_sorted (clouds of >= 4096 candidates: Morton-sorted, pruned) against the oracle's replay of the
+    reference's heap (knn_cuda.cu:58-95), indices AND distances, through the C ABI: random clouds (the k + 1 nearest
+    pairwise different: the pruned search alone decides), duplicated points and a lattice (equal distances: those
+    queries are recomputed wave by wave with the reference's heap sequence -- the counters say how many), ragged sizes (padding of the sorted
+    sets), clustered queries far from most candidates, and self-kNN at the headline cloud size."""
+    from mvp_benchmark_amd import _lib
+    b = 2 if n <= 8192 else 1
+    xyz = rand_clouds(700 + k, b, n, 3)
+    ctr = rand_clouds(701 + k, b, m, 3)
+    if kind == "duplicates":
+        xyz = np.concatenate([xyz[:, : n // 2], xyz[:, : n // 2]], 1)
+    elif kind == "lattice":
+        g = np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) / 16
+        xyz = np.stack([g[np.random.default_rng(s).permutation(4096)] for s in range(b)])
+        ctr = xyz.copy()
+    elif kind == "clustered":
+        ctr = (0.9 + 0.05 * ctr).astype(np.float32)
+    elif kind == "self":
+        ctr = xyz.copy()
+    want_i, want_d = oracle.knn(k, xyz, ctr, return_dist=True)        # (b, k, m) indices, (b, m, k) squared distances
+    nbytes = _lib.knn_scratch_bytes(b, n, m)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    idx = torch.zeros(b, m, k, dtype=torch.int32, device=DEV)
+    d2 = torch.zeros(b, m, k, device=DEV)
+    _lib.call("mvp_knn_sorted", DEV, b, n, m, k, dev(xyz), dev(ctr), idx, d2, scratch, nbytes)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(idx.cpu().numpy().transpose(0, 2, 1), want_i)
+    np.testing.assert_array_equal(d2.cpu().numpy(), want_d)
+    # the counters of the fix-up pass (queries recomputed by the reference's own heap sequence) sit in front of the id lists
+    cnt_at = nbytes - ((b * m * 4 + 15) // 16 * 16) - ((b * 4 + 15) // 16 * 16)
+    recomputed = scratch[cnt_at: cnt_at + b * 4].view(torch.int32).cpu().numpy()
+    if kind in ("random", "clustered", "self"):
+        assert recomputed.sum() <= 2               # (two equal distances among 17 random ones: ~1e-5 per query)
+    elif kind == "lattice":
+        assert (recomputed == m).all()             # every query of a lattice has equidistant neighbours
+    else:
+        assert recomputed.sum() > 0
+    # the operator takes the same route for these sizes
+    from mvp_benchmark_amd.mm3d_pn2 import knn
+    np.testing.assert_array_equal(knn(k, dev(xyz), dev(ctr), False).cpu().numpy(), want_i)
+
+
 def test_knn_default_centre_and_transposed(oracle):
     from mvp_benchmark_amd.mm3d_pn2 import knn
     xyz = rand_clouds(5, 2, 600, 3)
