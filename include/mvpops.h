@@ -202,7 +202,7 @@ int mvp_furthest_point_sampling_with_dist(int b, int n, int m,
  * through memory once per round (csrc/fps.hip: fps_cluster_kernel).  n a multiple of w * 1024,
  * n <= 16384; scratch of mvp_fps_cluster_scratch_bytes(b) bytes.  MVP_EBADSHAPE when the shape is
  * not covered or the cooperative launch does not fit the device (the caller then uses
- * mvp_furthest_point_sampling).  Opt-in: measured slower or on par, see DESIGN.md section 10. */
+ * mvp_furthest_point_sampling).  Opt-in: measured slower or on par, see profiles/NOTES_r1-r3_design_notebook.md section 10. */
 long long mvp_fps_cluster_scratch_bytes(int b);
 int mvp_furthest_point_sampling_cluster(int b, int n, int m, int w, const float *points,
                                         float *temp, int *idx, void *scratch,

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   for (int it = 0; it < iters; ++it) {
     if (Utot == 0) break;
 #ifdef MVP_EMD_PROFILE
-    if (cloud == 0 && wg == 0 && t == 0 && (it == 25 || it == 50 || it == 100 || it == 150 || it == 250 || it == 500 || it == 750 ||
+    if (cloud == 0 && wg == 0 && t == 0 && (it == 1 || it == 2 || it == 3 || it == 5 || it == 10 || it == 25 || it == 50 || it == 100 || it == 150 || it == 250 || it == 500 || it == 750 ||
                                            it == 1000 || it == 1500 || it == 2000 || it == 2500 || it == iters - 1))
       printf("head cloud 0: round %d starts at %lld cycles, unassigned %d\n", it, __builtin_readcyclecounter() - t_loop0, Utot);
 #endif

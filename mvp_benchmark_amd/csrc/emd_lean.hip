@@ -15,7 +15,7 @@
 //   emd_lean_body<W>        the rounds of one cloud on a cluster of W workgroups (device function)
 //   emd_lean_kernel<W>      every cloud on the cluster width the first kernel ran with
 //   emd_lean_tiers_kernel   from round 300 on: the workgroups dealt out again, 8 .. 2 per cloud by the
-//                           clouds' load (a launch lasts as long as its slowest cloud)
+//                           clouds' load (a launch lasts as long as its slowest cloud; DESIGN.md 5.2, notebook 5e)
 #include <cstdlib>
 
 #include "emd_common.h"

@@ -607,7 +607,7 @@ static int launch_fps(int b, int n, int m, const float *dataset, float *temp,
 //     key = value bits << 32 | (1023 - bitrev(t)) << 14 | (16383 - k)
 // = the reference's winner: largest value, then smallest bit-reversed thread slot, then (inside a
 // thread) the lowest k.  Cooperative launch (the members wait for each other).
-// Measured (profiles/r3_fps_cluster.txt): see DESIGN.md section 10.
+// Measured (profiles/r3_fps_cluster.txt): see profiles/NOTES_r1-r3_design_notebook.md section 10.
 constexpr unsigned kFpsSpinLimit = 1u << 24;
 
 template <int PW, int W>

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(int nelem, 
 // implicit-GEMM kernel for these shapes wraps the same arithmetic in NCHW <-> NHWC transposes -- and
 // one of its variants reads out of bounds (a cold-cache MIOpen picked
 // igemm_bwd_gtcx35_nhwc_fp32_bx0_ex1_bt256x64x4 for ECG's 24-channel edge convolutions and faulted,
-// depending on what the allocator had mapped behind the tensor; rocgdb trace in DESIGN.md section 10).
+// depending on what the allocator had mapped behind the tensor; rocgdb trace in profiles/NOTES_r1-r3_design_notebook.md section 10).
 template <int CI>
 __global__ __launch_bounds__(256) void pointwise_dgrad_kernel(int cin, int cout, int len, const float *__restrict__ w,
                                                                const float *__restrict__ gy, float *__restrict__ gx) {
