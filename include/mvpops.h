@@ -123,8 +123,8 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * loaded clouds keep 4 each)
  * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  With split = 3 (the default)
  * clouds of at most 4096 points leave the clustered kernels as soon as at most
- * `resident_cap` (32) persons are unassigned -- round ~100 of 3000 at 1024
- * points, ~300 at 2048, 500-900 at 4096 -- and a last, plain launch
+ * `resident_cap` (16) persons are unassigned -- round ~300 of 3000 at 1024
+ * points, 500-850 at 2048, 900-1700 at 4096 -- and a last, plain launch
  * (csrc/emd_resident.hip, one workgroup per cloud) runs the remaining rounds
  * with the whole auction state in that workgroup's LDS: no global memory access
  * inside a round.  Which workgroups serve a cloud, and in which launch, never
@@ -150,7 +150,7 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  *               8,5,4,4,3,3,3,2, fixes the widths of an XCD's eight clouds, heaviest first, sum
  *               32, instead of deriving them from the loads; MVP_EMD_PLAN_EVERY rounds between
  *               re-plans, default: never again)
- *   resident_cap  1..64 (default 32): unassigned persons at which a cloud of <= 4096
+ *   resident_cap  1..16 (default 16: one wave of the workgroup per unassigned person): unassigned persons at which a cloud of <= 4096
  *               points moves into LDS (split = 3)
  * This is the library's only process-wide state (kept under a mutex; a call of
  * mvp_emd_forward reads one consistent copy).  Results never depend on it

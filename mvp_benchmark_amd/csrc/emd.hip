@@ -1488,7 +1488,7 @@ struct EmdKnobs {
 static std::mutex g_knob_mutex;
 static EmdKnobs &emd_knobs_locked() {   // (callers hold g_knob_mutex)
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 3, 300, 4096, 0ull, 32};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
+    EmdKnobs v{kMaxCluster, 1, 3, 300, 4096, 0ull, 16};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
     if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 3 ? 3 : atoi(e);

@@ -32,9 +32,10 @@
 namespace mvp {
 
 // (kResList, kResMaxN, kResMinRounds: emd_common.h)
-constexpr int kResBlock = 64;   // slots per block = lanes per wave
+constexpr int kResSub = 16;       // slots per sub-block: a 16-lane row of a visit step
 constexpr int kResBuckets = 256;
 constexpr unsigned short kResFree = 0xFFFFu;
+static_assert(kResList == kEmdWaves, "one list position per wave, for the life of the launch");
 
 template <int NMAX>
 struct ResShared {
@@ -42,24 +43,22 @@ struct ResShared {
   float px[NMAX], py[NMAX], pz[NMAX];    // person -> point
   unsigned short owner[NMAX];            // slot -> person (kResFree: none)
   unsigned short h1[NMAX];               // person -> slot it last bid on (seed hint); at the end: person -> slot
-  float4 b_lo[NMAX / kResBlock], b_hi[NMAX / kResBlock];   // block: box min + price lower bound / box max
+  float4 s_lo[NMAX / kResSub], s_hi[NMAX / kResSub];   // sub-block: box min + price lower bound / box max
+  unsigned short w_list[kEmdWaves][NMAX / kResSub];    // surviving sub-blocks of a wave's search
   int cnt[2][kResBuckets];               // by round parity: bids per bucket of object slots
-  int list[2][kResList];                 // unassigned persons of this / the next round
-  int s_bj[kResList], s_bo[kResList];    // this round's bids: person, slot,
-  float s_binc[kResList];                // increment
-  int s_cnt[2];
+  int s_bj[kEmdWaves], s_bo[kEmdWaves];  // this round's bid of every position (person or -1, slot)
+  float s_binc[kEmdWaves];               // its increment
+  int s_act[3];                          // by round % 3: positions that hold a bidder
   int s_err;
 };
 
-// min over the wave, valid in lane 63
-__device__ __forceinline__ float wave_min_lane63(float v) {
+// min over each 16-lane row, valid in every lane of the row
+__device__ __forceinline__ float row_min(float v) {
   const float inf = __builtin_inff();
   v = __builtin_fminf(v, dpp_f32<0xB1, 0xF>(inf, v));    // quad_perm [1,0,3,2]
   v = __builtin_fminf(v, dpp_f32<0x4E, 0xF>(inf, v));    // quad_perm [2,3,0,1]
   v = __builtin_fminf(v, dpp_f32<0x141, 0xF>(inf, v));   // row_half_mirror
   v = __builtin_fminf(v, dpp_f32<0x140, 0xF>(inf, v));   // row_mirror
-  v = __builtin_fminf(v, dpp_f32<0x142, 0xA>(inf, v));   // row_bcast15 -> rows 1, 3
-  v = __builtin_fminf(v, dpp_f32<0x143, 0xC>(inf, v));   // row_bcast31 -> rows 2, 3
   return v;
 }
 
@@ -72,6 +71,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
   const int t = threadIdx.x;
   const int lane = t & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (tells the compiler that it is wave-uniform)
+  const int row = lane >> 4, sl = lane & 15;
   char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
   EmdHandover *resume = emd_handover(tail, b, cloud);
   long long *stats = emd_stats(tail, b, cloud);
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
   const EmdScratch sc = emd_carve(scratch + (size_t)cloud * emd_scratch_per_cloud(n), n);
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
-  const int nblk = n / kResBlock;   // n % 1024 == 0
+  const int nsub = n / kResSub;          // n % 1024 == 0: a multiple of 64
+  const int npass = nsub / kWave;        // sub-block tests per lane: 1, 2, 3 or 4
 
   // ------------------------------------------------------------ load the auction state
   for (int s = t; s < n; s += kEmdThreads) {
@@ -95,58 +96,74 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
     sh.h1[s] = p1 < 0 ? kResFree : (unsigned short)p1;
   }
   if (t < 2 * kResBuckets) (&sh.cnt[0][0])[t] = 0;
+  // this wave's list position: the wave-th entry of the lists the previous launch left (its cluster width:
+  // nlists), concatenated.  A position keeps its wave for the rest of the auction: a loser stays, an evicted
+  // owner takes the place of the winner that evicted it.
+  int j = -1;
   {
-    // the lists the previous launch left (its cluster width: nlists), concatenated
     const int nl = resume->nlists;
-    int p = t, k = -1, total = 0;
+    int p = wave, total = 0;
 #pragma unroll
     for (int w = 0; w < kMaxCluster; ++w) {
       const int cw = w < nl ? resume->cnt[w] : 0;
-      if (k < 0 && p >= 0 && p < cw) k = sc.ulist[(size_t)w * 2 * n + p];
+      if (j < 0 && p >= 0 && p < cw) j = sc.ulist[(size_t)w * 2 * n + p];
       p -= cw;
       total += cw;
     }
-    if (t < total && t < kResList) sh.list[0][t] = k;
+    j = __builtin_amdgcn_readfirstlane(j);
     if (t == 0) {
-      sh.s_cnt[0] = min(total, kResList);
-      sh.s_cnt[1] = 0;
+      sh.s_act[it0 % 3] = min(total, kResList);
+      sh.s_act[(it0 + 1) % 3] = 0;
+      sh.s_act[(it0 + 2) % 3] = 0;
       sh.s_err = (resume->err != 0 || total > kResList) ? 1 : 0;   // (the launcher never hands over more)
     }
   }
   __syncthreads();
-  // exact bounding box and exact price minimum per block of 64 slots
-  for (int blk = wave; blk < nblk; blk += kEmdWaves) {
-    const float4 o = sh.obj[blk * kResBlock + lane];
-    float lx = o.x, ly = o.y, lz = o.z, lw = o.w, hx = o.x, hy = o.y, hz = o.z;
+  // exact bounding box and exact price minimum per sub-block of 16 slots: a 16-lane row each
+  for (int q = wave; q < nsub / 4; q += kEmdWaves) {
+    const int sub = 4 * q + row;
+    const float4 o = sh.obj[sub * kResSub + sl];
+    float lx = o.x, ly = o.y, lz = o.z, hx = o.x, hy = o.y, hz = o.z;
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      lx = __builtin_fminf(lx, __shfl_xor(lx, off, kWave));
-      ly = __builtin_fminf(ly, __shfl_xor(ly, off, kWave));
-      lz = __builtin_fminf(lz, __shfl_xor(lz, off, kWave));
-      lw = __builtin_fminf(lw, __shfl_xor(lw, off, kWave));
-      hx = __builtin_fmaxf(hx, __shfl_xor(hx, off, kWave));
-      hy = __builtin_fmaxf(hy, __shfl_xor(hy, off, kWave));
-      hz = __builtin_fmaxf(hz, __shfl_xor(hz, off, kWave));
+    for (int off = 1; off < kResSub; off <<= 1) {
+      lx = __builtin_fminf(lx, __shfl_xor(lx, off, kResSub));
+      ly = __builtin_fminf(ly, __shfl_xor(ly, off, kResSub));
+      lz = __builtin_fminf(lz, __shfl_xor(lz, off, kResSub));
+      hx = __builtin_fmaxf(hx, __shfl_xor(hx, off, kResSub));
+      hy = __builtin_fmaxf(hy, __shfl_xor(hy, off, kResSub));
+      hz = __builtin_fmaxf(hz, __shfl_xor(hz, off, kResSub));
     }
-    if (lane == 0) {
-      sh.b_lo[blk] = make_float4(lx, ly, lz, lw);
-      sh.b_hi[blk] = make_float4(hx, hy, hz, 0.f);
+    const float lw = row_min(o.w);
+    if (sl == 0) {
+      sh.s_lo[sub] = make_float4(lx, ly, lz, lw);
+      sh.s_hi[sub] = make_float4(hx, hy, hz, 0.f);
     }
   }
+  // the position's bidder: its point and its hint stay in registers while it keeps bidding
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  int p1 = 0;
+  auto load_person = [&]() {
+    qx = sh.px[j];
+    qy = sh.py[j];
+    qz = sh.pz[j];
+    p1 = __builtin_amdgcn_readfirstlane((int)sh.h1[j]);
+    if (__builtin_expect(p1 == kResFree, 0)) p1 = 0;   // (every person has bid before a hand-over; any block will do)
+  };
   __syncthreads();
+  if (j >= 0) load_person();
 
   // ------------------------------------------------------------ the auction
-  int cur = 0;
   long long n_rounds = 0, n_bids = 0;
-  int U = __builtin_amdgcn_readfirstlane(sh.s_cnt[0]);
-  int last_u = 0;   // bidders of the forced last round (their bids are their assignment)
+  bool last_done = false;   // the forced last round ran: the positions' bids are their assignment
+  unsigned short *wl = sh.w_list[wave];
 #ifdef MVP_EMD_PROFILE
-  long long prof_folds = 0, prof_blocks = 0, prof_bidcyc = 0, prof_nbid = 0, cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, prof_slow = 0,
+  long long prof_folds = 0, prof_subs = 0, prof_bidcyc = 0, prof_nbid = 0, cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, prof_slow = 0,
             prof_seed = 0;
   const long long t_loop0 = __builtin_readcyclecounter();
   const long long w_loop0 = wall_clock64();
 #endif
   for (int it = it0; it < iters; ++it) {
+    const int U = __builtin_amdgcn_readfirstlane(sh.s_act[it % 3]);
     if (U == 0) break;
     n_rounds += 1;
     n_bids += U;
@@ -154,32 +171,34 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
     const int tpu = -U;   // thread_per_unass (emd_cuda.cu:107-109), resolved inside emd_precedes: ties only
     int *cnt = sh.cnt[it & 1];
 
-    // ---------------- Bid (emd_cuda.cu:95-179): wave w bids for the list positions w, w + 16, ...
+    // ---------------- Bid (emd_cuda.cu:95-179): the wave bids for the person at its position
 #ifdef MVP_EMD_PROFILE
     const long long tp0 = __builtin_readcyclecounter();
 #endif
-    for (int u = wave; u < U; u += kEmdWaves) {
-      const int j = __builtin_amdgcn_readfirstlane(sh.list[cur][u]);
-      const float qx = sh.px[j], qy = sh.py[j], qz = sh.pz[j];
-      int p1 = __builtin_amdgcn_readfirstlane((int)sh.h1[j]);
-      if (__builtin_expect(p1 == kResFree, 0)) p1 = 0;   // (every person has bid before a hand-over; any block will do)
-      const int home = p1 >> 6;
+    int bk = -1;
+    float inc = 0.f;
+    if (j >= 0) {
 #ifdef MVP_EMD_PROFILE
       const long long tb0 = __builtin_readcyclecounter();
 #endif
-      // one lane per block: squared distance to the block's box, its price bound
-      float bd2 = __builtin_inff(), bpl = 0.f;
-      if (lane < nblk) {
-        const float4 lo = sh.b_lo[lane], hi = sh.b_hi[lane];
-        const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi.x), 0.f);
-        const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi.y), 0.f);
-        const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi.z), 0.f);
-        bd2 = sqdist3(dx, dy, dz);
-        bpl = lo.w;
+      const int home = p1 >> 6;   // the 64-slot block (four sub-blocks) that holds the previous best object
+      // every sub-block's box and price bound against the bidder's point (independent of the seed: issued first)
+      float bd2[4], bpl[4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        bd2[ps] = __builtin_inff();
+        bpl[ps] = 0.f;
+        if (ps < npass) {
+          const float4 lo = sh.s_lo[ps * kWave + lane], hi = sh.s_hi[ps * kWave + lane];
+          const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi.x), 0.f);
+          const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi.y), 0.f);
+          const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi.z), 0.f);
+          bd2[ps] = sqdist3(dx, dy, dz);
+          bpl[ps] = lo.w;
+        }
       }
-      // The block that holds the bidder's previous best object, evaluated exactly: the lanes that hold its two
-      // best values (more on ties) start the running top two; the second of them is a lower bound of the final
-      // second-best value (64 distinct real objects).
+      // The home block evaluated exactly: the lanes that hold its two best values (more on ties) start the
+      // running top two; the second of them is a lower bound of the final second-best value (64 distinct objects).
       BidState st;
       st.b1 = -1e9f;
       st.b2 = -1e9f;
@@ -187,54 +206,57 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
       st.b2k = -1;
       st.tm = __builtin_inff();
       {
-        const float4 o = sh.obj[home * kResBlock + lane];
+        const float4 o = sh.obj[home * kWave + lane];
         const float v = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
         float t1, t2;
         wave_top2(v, t1, t2);
-        emd_fold(st, __ballot(v >= t2), v, home * kResBlock + lane, n, tpu, sc.perm);
+        emd_fold(st, __ballot(v >= t2), v, home * kWave + lane, n, tpu, sc.perm);
       }
 #ifdef MVP_EMD_PROFILE
       prof_seed += __builtin_readcyclecounter() - tb0;
 #endif
-      auto blocks = [&]() -> unsigned long long {
-        const float tq = st.tm - bpl;
-        return __ballot(tq >= 0.f && bd2 <= tq * tq);   // (lanes >= nblk: inf)
-      };
-      unsigned long long bm = blocks() & ~(1ull << home);
-      while (bm) {
-        // the next four surviving blocks (fewer: the last one again, its candidates masked out)
-        int bi[4];
-        bool ok[4];
+      // surviving sub-blocks (the home block's four excluded) compacted into the wave's list
+      int nl = 0;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        if (ps < npass) {
+          const float tq = st.tm - bpl[ps];
+          const int sub = ps * kWave + lane;
+          const bool pass = tq >= 0.f && bd2[ps] <= tq * tq && (sub >> 2) != home;
+          const unsigned long long m = __ballot(pass);
+          if (pass) wl[nl + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)sub;
+          nl += __builtin_popcountll(m);
+        }
+      }
+#ifdef MVP_EMD_PROFILE
+      prof_subs += nl;
+#endif
+      // visit: a step = four sub-blocks, one per 16-lane row; four steps in flight
+      for (int k0 = 0; k0 < nl; k0 += 16) {
+        int slot[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          ok[r] = bm != 0ull;
-          bi[r] = ok[r] ? (int)__builtin_ctzll(bm) : bi[r > 0 ? r - 1 : 0];
-          bm &= bm - 1ull;
+          const int k = k0 + 4 * r + row;
+          slot[r] = k < nl ? (int)wl[k] * kResSub + sl : -1;
         }
         float4 o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = sh.obj[bi[r] * kResBlock + lane];
+        for (int r = 0; r < 4; ++r) o[r] = sh.obj[slot[r] < 0 ? 0 : slot[r]];
         float sd[4];
         unsigned long long m[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           sd[r] = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
           const float tq = st.tm - o[r].w;
-          m[r] = ok[r] ? __ballot(tq >= 0.f && sd[r] <= tq * tq) : 0ull;
+          m[r] = __ballot(slot[r] >= 0 && tq >= 0.f && sd[r] <= tq * tq);
         }
 #ifdef MVP_EMD_PROFILE
-        prof_blocks += (int)ok[0] + (int)ok[1] + (int)ok[2] + (int)ok[3];
         prof_folds += __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) + __builtin_popcountll(m[2]) + __builtin_popcountll(m[3]);
 #endif
-        if ((m[0] | m[1] | m[2] | m[3]) != 0ull) {
-          float v[4];
+        // (exact values only for the steps that hold a candidate: 1-2 of the four, usually)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = emd_value(sd[r], o[r].w);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (m[r]) emd_fold(st, m[r], v[r], bi[r] * kResBlock + lane, n, tpu, sc.perm);
-          if (bm) bm &= blocks();
-        }
+        for (int r = 0; r < 4; ++r)
+          if (m[r]) emd_fold(st, m[r], emd_value(sd[r], o[r].w), slot[r], n, tpu, sc.perm);
       }
 #ifdef MVP_EMD_PROFILE
       prof_bidcyc += __builtin_readcyclecounter() - tb0;
@@ -244,19 +266,24 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
         if (lane == 0) sh.s_err = 1;
         st.bk = st.bk < 0 ? 0 : st.bk;
       }
+      bk = st.bk;
+      inc = st.b1 - st.b2 + eps;
+      p1 = bk;   // the hint of the next bid of this person (a loser bids again at once)
       if (lane == 0) {
-        sh.s_bj[u] = j;
-        sh.s_bo[u] = st.bk;
-        sh.s_binc[u] = st.b1 - st.b2 + eps;
-        sh.h1[j] = (unsigned short)st.bk;
-        atomicAdd(&cnt[st.bk & (kResBuckets - 1)], 1);
+        sh.s_bj[wave] = j;
+        sh.s_bo[wave] = bk;
+        sh.s_binc[wave] = inc;
+        sh.h1[j] = (unsigned short)bk;
+        atomicAdd(&cnt[bk & (kResBuckets - 1)], 1);
       }
-    }
-    if (wave >= U && !last) {
-      // a wave without a bidder refreshes a block's price bound (prices do not move during Bid: exact)
-      const int blk = (int)(((unsigned)it * (unsigned)kEmdWaves + (unsigned)wave) % (unsigned)nblk);
-      const float pm = wave_min_lane63(sh.obj[blk * kResBlock + lane].w);
-      if (lane == kWave - 1) sh.b_lo[blk].w = pm;
+    } else {
+      if (lane == 0) sh.s_bj[wave] = -1;
+      if (!last) {
+        // a position without a bidder refreshes four sub-blocks' price bounds (prices do not move during Bid: exact)
+        const int sub = 4 * (int)(((unsigned)it * (unsigned)kEmdWaves + (unsigned)wave) % (unsigned)(nsub / 4)) + row;
+        const float pm = row_min(sh.obj[sub * kResSub + sl].w);
+        if (sl == 0) sh.s_lo[sub].w = pm;
+      }
     }
 #ifdef MVP_EMD_PROFILE
     const long long tp1 = __builtin_readcyclecounter();
@@ -269,18 +296,15 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
 #endif
     if (last) {
       // every bidder of the last round takes what it bid on (emd_cuda.cu:201-212): resolved below the loop
-      last_u = U;
+      last_done = true;
       break;
     }
 
-    // ---------------- GetMax + Assign (emd_cuda.cu:181-215): every wave settles the bids it placed
-    const int nxt = cur ^ 1;
-    for (int u = wave; u < U; u += kEmdWaves) {
-      const int j = __builtin_amdgcn_readfirstlane(sh.s_bj[u]), o = __builtin_amdgcn_readfirstlane(sh.s_bo[u]);
-      const float inc = sh.s_binc[u];
-      const int c = __builtin_amdgcn_readfirstlane(cnt[o & (kResBuckets - 1)]);
-      int prev = sh.owner[o];
-      const float price = sh.obj[o].w;
+    // ---------------- GetMax + Assign (emd_cuda.cu:181-215): every wave settles the bid it placed
+    if (j >= 0) {
+      const int c = __builtin_amdgcn_readfirstlane(cnt[bk & (kResBuckets - 1)]);
+      const int prev = __builtin_amdgcn_readfirstlane((int)sh.owner[bk]);
+      const float price = sh.obj[bk].w;
       bool win = true;
       if (__builtin_expect(c != 1, 0)) {
         // another bid in my bucket: compare the round's bids -- the maximal increment bid on my object, then
@@ -289,40 +313,37 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
         prof_slow += 1;
 #endif
         float mi = inc;
-        for (int v = 0; v < U; ++v)
-          if (sh.s_bo[v] == o) mi = __builtin_fmaxf(mi, sh.s_binc[v]);
+        for (int v = 0; v < kEmdWaves; ++v)
+          if (sh.s_bj[v] >= 0 && sh.s_bo[v] == bk) mi = __builtin_fmaxf(mi, sh.s_binc[v]);
         int wj = -1;
-        for (int v = 0; v < U; ++v)
-          if (sh.s_bo[v] == o && emd_in_band(sh.s_binc[v], mi)) wj = max(wj, sh.s_bj[v]);
+        for (int v = 0; v < kEmdWaves; ++v)
+          if (sh.s_bj[v] >= 0 && sh.s_bo[v] == bk && emd_in_band(sh.s_binc[v], mi)) wj = max(wj, sh.s_bj[v]);
         win = wj == j;
       }
-      // next round's list: the evicted owner, or the loser itself (the order of a list changes no result)
-      int again = j;
-      if (win) {   // one winner per object
-        again = prev == kResFree ? -1 : prev;
+      if (win) {   // one winner per object; the evicted owner takes this position
         if (lane == 0) {
-          sh.owner[o] = (unsigned short)j;
-          sh.obj[o].w = price + inc;
+          sh.owner[bk] = (unsigned short)j;
+          sh.obj[bk].w = price + inc;
         }
+        j = prev == kResFree ? -1 : prev;
+        if (j >= 0) load_person();
       }
-      if (again >= 0 && lane == 0) sh.list[nxt][atomicAdd(&sh.s_cnt[nxt], 1)] = again;   // (<= U entries: never grows)
+      if (j >= 0 && lane == 0) atomicAdd(&sh.s_act[(it + 1) % 3], 1);
     }
     if (wave == kEmdWaves - 1) {
-      // the next round's counters (last read in the round before this one), the list size after next
+      // the next round's counters (last read in the round before this one), the count of the round after next
       if (lane < kResBuckets / 4) reinterpret_cast<int4 *>(sh.cnt[(it + 1) & 1])[lane] = make_int4(0, 0, 0, 0);
-      if (lane == 0) sh.s_cnt[cur] = 0;
+      if (lane == 0) sh.s_act[(it + 2) % 3] = 0;
     }
     lds_barrier();
-    cur = nxt;
-    U = __builtin_amdgcn_readfirstlane(sh.s_cnt[cur]);
 #ifdef MVP_EMD_PROFILE
     cyc_assign += __builtin_readcyclecounter() - tp2;
 #endif
   }
 #ifdef MVP_EMD_PROFILE
   if (cloud < 2 && lane == 0 && (wave == 0 || wave == 3))
-    printf("resident cloud %d wave %d: rounds %lld bids(all waves) %lld | this wave: %lld bids, %lld cycles each (home block %lld), blocks %.1f folds %.1f per bid | cycles bid %lld wait %lld assign %lld total %lld | contested buckets %lld\n",
-           cloud, wave, n_rounds, n_bids, prof_nbid, prof_bidcyc / (prof_nbid + 1), prof_seed / (prof_nbid + 1), (double)prof_blocks / (double)(prof_nbid + 1),
+    printf("resident cloud %d wave %d: rounds %lld bids(all waves) %lld | this wave: %lld bids, %lld cycles each (home block %lld), sub-blocks %.1f folds %.1f per bid | cycles bid %lld wait %lld assign %lld total %lld | contested buckets %lld\n",
+           cloud, wave, n_rounds, n_bids, prof_nbid, prof_bidcyc / (prof_nbid + 1), prof_seed / (prof_nbid + 1), (double)prof_subs / (double)(prof_nbid + 1),
            (double)prof_folds / (double)(prof_nbid + 1), cyc_bid, cyc_sync1, cyc_assign, __builtin_readcyclecounter() - t_loop0, prof_slow);
   if (cloud < 2 && lane == 0 && wave == 0)
     printf("resident cloud %d: %lld cycles in %lld ticks of the 100 MHz clock = %.0f MHz\n", cloud, __builtin_readcyclecounter() - t_loop0,
@@ -339,13 +360,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
     if (ow != kResFree) pslot[ow] = (unsigned short)s;
   }
   __syncthreads();
-  if (t < last_u) pslot[sh.s_bj[t]] = (unsigned short)sh.s_bo[t];
+  if (last_done && t < kEmdWaves && sh.s_bj[t] >= 0) pslot[sh.s_bj[t]] = (unsigned short)sh.s_bo[t];
   __syncthreads();
-  for (int j = t; j < n; j += kEmdThreads) {
-    const int s = pslot[j];
+  for (int p = t; p < n; p += kEmdThreads) {
+    const int s = pslot[p];
     const float4 o = sh.obj[s];
-    dist[j] = sqdist3(sh.px[j] - o.x, sh.py[j] - o.y, sh.pz[j] - o.z);
-    ass[j] = sc.perm[s];
+    dist[p] = sqdist3(sh.px[p] - o.x, sh.py[p] - o.y, sh.pz[p] - o.z);
+    ass[p] = sc.perm[s];
   }
   if (t == 0) {
     atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)n_rounds);

@@ -21,7 +21,7 @@ def knobs():
     """mvp_emd_configure for one test; the defaults come back afterwards."""
     from mvp_benchmark_amd import _lib
     yield _lib.emd_configure
-    _lib.emd_configure(cluster=0, split=_lib.EMD_DEFAULT_SPLIT, resident_cap=32)
+    _lib.emd_configure(cluster=0, split=_lib.EMD_DEFAULT_SPLIT, resident_cap=16)
 
 
 def _run(x1, x2, eps, iters):
@@ -57,18 +57,18 @@ def test_resident_tail_matches_oracle(oracle, b, n):
     instantiations: <= 2048 and <= 4096 points)."""
     x1, x2 = rand_clouds(1000 + n, b, n, 3), rand_clouds(2000 + n, b, n, 3)
     rec = _check(oracle, x1, x2, 0.004, 3000, expect_resident=True)
-    assert (rec["unassigned"] <= 32).all() and (rec["unassigned"] > 0).all()
+    assert (rec["unassigned"] <= 16).all() and (rec["unassigned"] > 0).all()
 
 
-@pytest.mark.parametrize("cap", [1, 7, 16, 33, 64])
+@pytest.mark.parametrize("cap", [1, 3, 7, 16])
 def test_resident_cap_changes_no_bit(oracle, knobs, cap):
-    """The hand-over point is a tuning knob: 1 person left (the latest possible), the collapse threshold
-    of the clustered kernels, more bidders than waves (drawn list positions, 2+ bids per wave), the list's capacity."""
+    """The hand-over point is a tuning knob: 1 person left (the latest possible), a few, the capacity (one wave of
+    the resident workgroup per unassigned person)."""
     knobs(resident_cap=cap)
     x1, x2 = rand_clouds(301, 3, 2048, 3), rand_clouds(302, 3, 2048, 3)
     rec = _check(oracle, x1, x2, 0.004, 3000)
     assert (rec["unassigned"][rec["final_launch"] == 3] <= cap).all()
-    if cap >= 16:
+    if cap >= 7:
         assert (rec["final_launch"] == 3).all()
 
 
@@ -100,7 +100,7 @@ def test_resident_edge_cases(oracle, kind):
     elif kind == "few_rounds_left":
         x1, x2 = rand_clouds(35, 2, 2048, 3), rand_clouds(36, 2, 2048, 3)
         trace = oracle.emd_forward_ex(x1, x2, eps, 3000)[3]
-        iters = max(int(np.argmax(row <= 32)) for row in trace) + 40
+        iters = max(int(np.argmax(row <= 16)) for row in trace) + 40
     elif kind == "last_round_forced":
         x1, x2, eps, iters = rand_clouds(37, 2, 2048, 3), rand_clouds(38, 2, 2048, 3), 0.002, 400
         assert oracle.emd_forward_ex(x1, x2, eps, iters)[3][:, -1].min() > 0
