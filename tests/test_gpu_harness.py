@@ -271,14 +271,8 @@ def test_graphed_training_step_matches_eager():
         opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)     # same update arithmetic both ways
         step = train.GraphedStep(net, opt, torch.device(DEV)) if graphed else None
         losses = []
-        # (the captured variant takes three eager warm-up steps on its first batch: do the same here)
-        if not graphed:
-            gt = batches[0]
-            for _ in range(3):
-                opt.zero_grad()
-                _, _, loss = net(gt.transpose(2, 1).contiguous(), gt, alpha=0.5)
-                loss.mean().backward()
-                opt.step()
+        # (the captured variant's three warm-up steps are rolled back -- parameters, optimizer state, random
+        # streams: ADVICE r3 -- so both variants train on every batch exactly once)
         for it in range(6):
             gt = batches[it % 3]
             x = gt.transpose(2, 1).contiguous()
