@@ -150,7 +150,7 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  *               8,5,4,4,3,3,3,2, fixes the widths of an XCD's eight clouds, heaviest first, sum
  *               32, instead of deriving them from the loads; MVP_EMD_PLAN_EVERY rounds between
  *               re-plans, default: never again)
- *   resident_cap  1..16 (default 16: one wave of the workgroup per unassigned person): unassigned persons at which a cloud of <= 4096
+ *   resident_cap  1..64 (default 16: one wave of the workgroup per unassigned person; more: several per wave): unassigned persons at which a cloud of <= 4096
  *               points moves into LDS (split = 3)
  * This is the library's only process-wide state (kept under a mutex; a call of
  * mvp_emd_forward reads one consistent copy).  Results never depend on it

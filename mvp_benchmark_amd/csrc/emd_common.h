@@ -40,7 +40,7 @@ static_assert(kLeanCap <= kRecCap, "the lean kernel keeps every list entry's rec
 // `res_cap` <= kResList persons are unassigned and at least kResMinRounds rounds are left: the whole
 // auction state then lives in one workgroup's LDS.
 constexpr int kResMaxN = 4096;
-constexpr int kResList = 16;
+constexpr int kResList = 64;
 constexpr int kResMinRounds = 32;
 
 // Filter slack.  An object is skipped only if

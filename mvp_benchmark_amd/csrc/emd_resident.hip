@@ -35,7 +35,7 @@ namespace mvp {
 constexpr int kResSub = 16;       // slots per sub-block: a 16-lane row of a visit step
 constexpr int kResBuckets = 256;
 constexpr unsigned short kResFree = 0xFFFFu;
-static_assert(kResList == kEmdWaves, "one list position per wave, for the life of the launch");
+static_assert(kResList % kEmdWaves == 0, "list positions are dealt out to the waves round-robin, for the life of the launch");
 
 template <int NMAX>
 struct ResShared {
@@ -44,13 +44,38 @@ struct ResShared {
   unsigned short owner[NMAX];            // slot -> person (kResFree: none)
   unsigned short h1[NMAX];               // person -> slot it last bid on (seed hint); at the end: person -> slot
   float4 s_lo[NMAX / kResSub], s_hi[NMAX / kResSub];   // sub-block: box min + price lower bound / box max
-  unsigned short w_list[kEmdWaves][NMAX / kResSub];    // surviving sub-blocks of a wave's search
+  unsigned short w_list[kEmdWaves][NMAX / kResSub + 16];   // surviving sub-blocks of a wave's search (+ a step's over-read)
   int cnt[2][kResBuckets];               // by round parity: bids per bucket of object slots
-  int s_bj[kEmdWaves], s_bo[kEmdWaves];  // this round's bid of every position (person or -1, slot)
-  float s_binc[kEmdWaves];               // its increment
+  float4 r_q[kResList];                  // a position's bidder: its point, bits(person) (-1: nobody)
+  int r_p1[kResList];                    // ... and the slot it last bid on (the home block of its next search)
+  int s_bj[kResList], s_bo[kResList];    // this round's bid of every position (person or -1, slot)
+  float s_binc[kResList];                // its increment
   int s_act[3];                          // by round % 3: positions that hold a bidder
   int s_err;
 };
+
+// max over the wave (uniform result): six v_max_f32 with a DPP operand -- lanes a step does not write keep their own
+// value -- spelled in assembly: the compiler expands each step of the intrinsic form into {mov, nop, mov_dpp,
+// canonicalising max, max} (30 instructions per reduction, four dependent ones per step).  The s_nop 1 in front
+// of every step is the VALU-write -> DPP-read hazard the assembler does not handle inside an asm block.
+__device__ __forceinline__ float res_wave_max(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 
 // min over each 16-lane row, valid in every lane of the row
 __device__ __forceinline__ float row_min(float v) {
@@ -80,8 +105,9 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
   const EmdScratch sc = emd_carve(scratch + (size_t)cloud * emd_scratch_per_cloud(n), n);
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
+  constexpr int kPasses = NMAX / kResSub / kWave;   // sub-block tests per lane this instantiation can need: 2 / 4
   const int nsub = n / kResSub;          // n % 1024 == 0: a multiple of 64
-  const int npass = nsub / kWave;        // sub-block tests per lane: 1, 2, 3 or 4
+  const int npass = nsub / kWave;        // ... and this cloud needs: 1, 2, 3 or 4
 
   // ------------------------------------------------------------ load the auction state
   for (int s = t; s < n; s += kEmdThreads) {
@@ -96,23 +122,30 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
     sh.h1[s] = p1 < 0 ? kResFree : (unsigned short)p1;
   }
   if (t < 2 * kResBuckets) (&sh.cnt[0][0])[t] = 0;
-  // this wave's list position: the wave-th entry of the lists the previous launch left (its cluster width:
-  // nlists), concatenated.  A position keeps its wave for the rest of the auction: a loser stays, an evicted
-  // owner takes the place of the winner that evicted it.
-  int j = -1;
+  // List positions: position p holds the p-th entry of the lists the previous launch left (its cluster width:
+  // nlists), concatenated, and belongs to wave p % 16 for the rest of the auction: a loser stays at its
+  // position, an evicted owner takes the place of the winner that evicted it, a winner of a free object leaves
+  // the position empty.
+  int npos = 0;   // positions in use at the hand-over (their number never grows)
   {
     const int nl = resume->nlists;
-    int p = wave, total = 0;
+    int p = t, k = -1, total = 0;
 #pragma unroll
     for (int w = 0; w < kMaxCluster; ++w) {
       const int cw = w < nl ? resume->cnt[w] : 0;
-      if (j < 0 && p >= 0 && p < cw) j = sc.ulist[(size_t)w * 2 * n + p];
+      if (k < 0 && p >= 0 && p < cw) k = sc.ulist[(size_t)w * 2 * n + p];
       p -= cw;
       total += cw;
     }
-    j = __builtin_amdgcn_readfirstlane(j);
+    npos = __builtin_amdgcn_readfirstlane(min(total, kResList));
+    if (t < kResList) {
+      const float4 pa = t < npos ? sc.person[2 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int p1 = t < npos ? __float_as_int(sc.person[2 * k + 1].y) : 0;
+      sh.r_q[t] = make_float4(pa.x, pa.y, pa.z, __int_as_float(t < npos ? k : -1));
+      sh.r_p1[t] = p1 < 0 ? 0 : p1;   // (every person has bid before a hand-over; any block would do)
+    }
     if (t == 0) {
-      sh.s_act[it0 % 3] = min(total, kResList);
+      sh.s_act[it0 % 3] = npos;
       sh.s_act[(it0 + 1) % 3] = 0;
       sh.s_act[(it0 + 2) % 3] = 0;
       sh.s_err = (resume->err != 0 || total > kResList) ? 1 : 0;   // (the launcher never hands over more)
@@ -139,18 +172,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
       sh.s_hi[sub] = make_float4(hx, hy, hz, 0.f);
     }
   }
-  // the position's bidder: its point and its hint stay in registers while it keeps bidding
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  int p1 = 0;
-  auto load_person = [&]() {
-    qx = sh.px[j];
-    qy = sh.py[j];
-    qz = sh.pz[j];
-    p1 = __builtin_amdgcn_readfirstlane((int)sh.h1[j]);
-    if (__builtin_expect(p1 == kResFree, 0)) p1 = 0;   // (every person has bid before a hand-over; any block will do)
-  };
   __syncthreads();
-  if (j >= 0) load_person();
 
   // ------------------------------------------------------------ the auction
   long long n_rounds = 0, n_bids = 0;
@@ -170,32 +192,57 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
     const bool last = it == iters - 1;
     const int tpu = -U;   // thread_per_unass (emd_cuda.cu:107-109), resolved inside emd_precedes: ties only
     int *cnt = sh.cnt[it & 1];
+    if ((U + kEmdWaves - 1) / kEmdWaves < (npos + kEmdWaves - 1) / kEmdWaves) {
+      // Positions empty out at random: once the persons left would fit fewer positions per wave, wave 0 moves
+      // them to the front (at most three times per cloud; the order of the list changes no result).
+      if (wave == 0) {
+        const float4 rq = sh.r_q[lane];
+        const int rp = sh.r_p1[lane];
+        const bool act = lane < npos && __float_as_int(rq.w) >= 0;
+        const unsigned long long m = __ballot(act);
+        const int dst = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (act) {
+          sh.r_q[dst] = rq;
+          sh.r_p1[dst] = rp;
+        }
+        if (lane >= __builtin_popcountll(m) && lane < npos) sh.r_q[lane] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+      }
+      lds_barrier();
+      npos = U;
+    }
 
-    // ---------------- Bid (emd_cuda.cu:95-179): the wave bids for the person at its position
+    // ---------------- Bid (emd_cuda.cu:95-179): the wave bids for the persons at its positions, one after the other
 #ifdef MVP_EMD_PROFILE
     const long long tp0 = __builtin_readcyclecounter();
 #endif
-    int bk = -1;
-    float inc = 0.f;
-    if (j >= 0) {
+    bool idle = true;
+    for (int pos = wave; pos < npos; pos += kEmdWaves) {
+      const float4 rq = sh.r_q[pos];
+      const int j = __builtin_amdgcn_readfirstlane(__float_as_int(rq.w));
+      if (j < 0) {
+        if (lane == 0) sh.s_bj[pos] = -1;
+        continue;
+      }
+      idle = false;
+      const float qx = rq.x, qy = rq.y, qz = rq.z;
+      const int p1 = __builtin_amdgcn_readfirstlane(sh.r_p1[pos]);
 #ifdef MVP_EMD_PROFILE
       const long long tb0 = __builtin_readcyclecounter();
 #endif
       const int home = p1 >> 6;   // the 64-slot block (four sub-blocks) that holds the previous best object
       // every sub-block's box and price bound against the bidder's point (independent of the seed: issued first)
-      float bd2[4], bpl[4];
+      float bd2[kPasses], bpl[kPasses];
+      // (straight-line: every pass the instantiation can need is loaded at once -- indices beyond this cloud's
+      // sub-blocks are clamped and their result discarded -- so the loads share one LDS round trip)
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        bd2[ps] = __builtin_inff();
-        bpl[ps] = 0.f;
-        if (ps < npass) {
-          const float4 lo = sh.s_lo[ps * kWave + lane], hi = sh.s_hi[ps * kWave + lane];
-          const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi.x), 0.f);
-          const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi.y), 0.f);
-          const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi.z), 0.f);
-          bd2[ps] = sqdist3(dx, dy, dz);
-          bpl[ps] = lo.w;
-        }
+      for (int ps = 0; ps < kPasses; ++ps) {
+        const int sub = min(ps * kWave + lane, nsub - 1);
+        const float4 lo = sh.s_lo[sub], hi = sh.s_hi[sub];
+        const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi.x), 0.f);
+        const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi.y), 0.f);
+        const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi.z), 0.f);
+        bd2[ps] = ps < npass ? sqdist3(dx, dy, dz) : __builtin_inff();
+        bpl[ps] = lo.w;
       }
       // The home block evaluated exactly: the lanes that hold its two best values (more on ties) start the
       // running top two; the second of them is a lower bound of the final second-best value (64 distinct objects).
@@ -208,9 +255,22 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
       {
         const float4 o = sh.obj[home * kWave + lane];
         const float v = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
-        float t1, t2;
-        wave_top2(v, t1, t2);
-        emd_fold(st, __ballot(v >= t2), v, home * kWave + lane, n, tpu, sc.perm);
+        // largest value, then the largest of the rest (one holder of the maximum set aside)
+        const float t1 = res_wave_max(v);
+        const unsigned long long m1 = __ballot(v == t1);
+        const int l1 = (int)__builtin_ctzll(m1);
+        const float t2 = res_wave_max(lane == l1 ? -1e9f : v);
+        const unsigned long long m2 = __ballot(v >= t2);
+        if (__builtin_expect(t1 > t2 && __builtin_popcountll(m2) == 2, 1)) {
+          // two different values, one holder each: the state emd_fold would arrive at
+          st.b1 = t1;
+          st.bk = home * kWave + l1;
+          st.b2 = t2;
+          st.b2k = home * kWave + (int)__builtin_ctzll(m2 & ~m1);
+          st.tm = (3.0f - t2) + kMargin;
+        } else {
+          emd_fold(st, m2, v, home * kWave + lane, n, tpu, sc.perm);   // equal values: the reference's tie order
+        }
       }
 #ifdef MVP_EMD_PROFILE
       prof_seed += __builtin_readcyclecounter() - tb0;
@@ -218,30 +278,28 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
       // surviving sub-blocks (the home block's four excluded) compacted into the wave's list
       int nl = 0;
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        if (ps < npass) {
-          const float tq = st.tm - bpl[ps];
-          const int sub = ps * kWave + lane;
-          const bool pass = tq >= 0.f && bd2[ps] <= tq * tq && (sub >> 2) != home;
-          const unsigned long long m = __ballot(pass);
-          if (pass) wl[nl + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)sub;
-          nl += __builtin_popcountll(m);
-        }
+      for (int ps = 0; ps < kPasses; ++ps) {
+        const float tq = st.tm - bpl[ps];
+        const int sub = ps * kWave + lane;
+        const bool pass = tq >= 0.f && bd2[ps] <= tq * tq && (sub >> 2) != home;   // (passes beyond npass: inf)
+        const unsigned long long m = __ballot(pass);
+        if (pass) wl[nl + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)sub;
+        nl += __builtin_popcountll(m);
       }
 #ifdef MVP_EMD_PROFILE
       prof_subs += nl;
 #endif
       // visit: a step = four sub-blocks, one per 16-lane row; four steps in flight
       for (int k0 = 0; k0 < nl; k0 += 16) {
-        int slot[4];
+        // (the list is read past its end -- the row is padded -- and the entry discarded: four independent reads)
+        int ent[4], slot[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = k0 + 4 * r + row;
-          slot[r] = k < nl ? (int)wl[k] * kResSub + sl : -1;
-        }
+        for (int r = 0; r < 4; ++r) ent[r] = wl[k0 + 4 * r + row];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot[r] = k0 + 4 * r + row < nl ? ent[r] * kResSub + sl : -1;
         float4 o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = sh.obj[slot[r] < 0 ? 0 : slot[r]];
+        for (int r = 0; r < 4; ++r) o[r] = sh.obj[slot[r] < 0 ? sl : slot[r]];
         float sd[4];
         unsigned long long m[4];
 #pragma unroll
@@ -266,24 +324,20 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
         if (lane == 0) sh.s_err = 1;
         st.bk = st.bk < 0 ? 0 : st.bk;
       }
-      bk = st.bk;
-      inc = st.b1 - st.b2 + eps;
-      p1 = bk;   // the hint of the next bid of this person (a loser bids again at once)
       if (lane == 0) {
-        sh.s_bj[wave] = j;
-        sh.s_bo[wave] = bk;
-        sh.s_binc[wave] = inc;
-        sh.h1[j] = (unsigned short)bk;
-        atomicAdd(&cnt[bk & (kResBuckets - 1)], 1);
+        sh.s_bj[pos] = j;
+        sh.s_bo[pos] = st.bk;
+        sh.s_binc[pos] = st.b1 - st.b2 + eps;
+        sh.r_p1[pos] = st.bk;   // the hint of this person's next bid (a loser bids again at once)
+        sh.h1[j] = (unsigned short)st.bk;
+        atomicAdd(&cnt[st.bk & (kResBuckets - 1)], 1);
       }
-    } else {
-      if (lane == 0) sh.s_bj[wave] = -1;
-      if (!last) {
-        // a position without a bidder refreshes four sub-blocks' price bounds (prices do not move during Bid: exact)
-        const int sub = 4 * (int)(((unsigned)it * (unsigned)kEmdWaves + (unsigned)wave) % (unsigned)(nsub / 4)) + row;
-        const float pm = row_min(sh.obj[sub * kResSub + sl].w);
-        if (sl == 0) sh.s_lo[sub].w = pm;
-      }
+    }
+    if (idle && !last) {
+      // a wave without a bidder refreshes four sub-blocks' price bounds (prices do not move during Bid: exact)
+      const int sub = 4 * (int)(((unsigned)it * (unsigned)kEmdWaves + (unsigned)wave) % (unsigned)(nsub / 4)) + row;
+      const float pm = row_min(sh.obj[sub * kResSub + sl].w);
+      if (sl == 0) sh.s_lo[sub].w = pm;
     }
 #ifdef MVP_EMD_PROFILE
     const long long tp1 = __builtin_readcyclecounter();
@@ -300,8 +354,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
       break;
     }
 
-    // ---------------- GetMax + Assign (emd_cuda.cu:181-215): every wave settles the bid it placed
-    if (j >= 0) {
+    // ---------------- GetMax + Assign (emd_cuda.cu:181-215): every wave settles the bids it placed
+    for (int pos = wave; pos < npos; pos += kEmdWaves) {
+      int j = __builtin_amdgcn_readfirstlane(sh.s_bj[pos]);
+      if (j < 0) continue;
+      const int me = j;
+      const int bk = __builtin_amdgcn_readfirstlane(sh.s_bo[pos]);
+      const float inc = sh.s_binc[pos];
       const int c = __builtin_amdgcn_readfirstlane(cnt[bk & (kResBuckets - 1)]);
       const int prev = __builtin_amdgcn_readfirstlane((int)sh.owner[bk]);
       const float price = sh.obj[bk].w;
@@ -313,20 +372,24 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
         prof_slow += 1;
 #endif
         float mi = inc;
-        for (int v = 0; v < kEmdWaves; ++v)
+        for (int v = 0; v < npos; ++v)
           if (sh.s_bj[v] >= 0 && sh.s_bo[v] == bk) mi = __builtin_fmaxf(mi, sh.s_binc[v]);
         int wj = -1;
-        for (int v = 0; v < kEmdWaves; ++v)
+        for (int v = 0; v < npos; ++v)
           if (sh.s_bj[v] >= 0 && sh.s_bo[v] == bk && emd_in_band(sh.s_binc[v], mi)) wj = max(wj, sh.s_bj[v]);
         win = wj == j;
       }
       if (win) {   // one winner per object; the evicted owner takes this position
-        if (lane == 0) {
-          sh.owner[bk] = (unsigned short)j;
-          sh.obj[bk].w = price + inc;
-        }
         j = prev == kResFree ? -1 : prev;
-        if (j >= 0) load_person();
+        const int jc = j < 0 ? 0 : j;
+        const float nx = sh.px[jc], ny = sh.py[jc], nz = sh.pz[jc];
+        const int np1 = sh.h1[jc];
+        if (lane == 0) {
+          sh.owner[bk] = (unsigned short)me;
+          sh.obj[bk].w = price + inc;
+          sh.r_q[pos] = make_float4(nx, ny, nz, __int_as_float(j));
+          sh.r_p1[pos] = np1 == kResFree ? 0 : np1;
+        }
       }
       if (j >= 0 && lane == 0) atomicAdd(&sh.s_act[(it + 1) % 3], 1);
     }
@@ -360,7 +423,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_resident_kernel(
     if (ow != kResFree) pslot[ow] = (unsigned short)s;
   }
   __syncthreads();
-  if (last_done && t < kEmdWaves && sh.s_bj[t] >= 0) pslot[sh.s_bj[t]] = (unsigned short)sh.s_bo[t];
+  if (last_done && t < npos && sh.s_bj[t] >= 0) pslot[sh.s_bj[t]] = (unsigned short)sh.s_bo[t];
   __syncthreads();
   for (int p = t; p < n; p += kEmdThreads) {
     const int s = pslot[p];

@@ -60,10 +60,10 @@ def test_resident_tail_matches_oracle(oracle, b, n):
     assert (rec["unassigned"] <= 16).all() and (rec["unassigned"] > 0).all()
 
 
-@pytest.mark.parametrize("cap", [1, 3, 7, 16])
+@pytest.mark.parametrize("cap", [1, 7, 16, 33, 64])
 def test_resident_cap_changes_no_bit(oracle, knobs, cap):
-    """The hand-over point is a tuning knob: 1 person left (the latest possible), a few, the capacity (one wave of
-    the resident workgroup per unassigned person)."""
+    """The hand-over point is a tuning knob: 1 person left (the latest possible), fewer than waves, one per wave,
+    several list positions per wave (33: some waves three, 64: four each -- the capacity)."""
     knobs(resident_cap=cap)
     x1, x2 = rand_clouds(301, 3, 2048, 3), rand_clouds(302, 3, 2048, 3)
     rec = _check(oracle, x1, x2, 0.004, 3000)

@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol():
     try:
         assert lib.mvp_emd_configure(-1, -1, 0, -1) == 0
         assert lib.mvp_emd_configure(3, -1, -1, -1) == -2           # MVP_EBADARG: cluster width
-        assert lib.mvp_emd_configure(-1, -1, -1, 0) == -2           # MVP_EBADARG: resident cap 1..16
-        assert lib.mvp_emd_configure(-1, -1, -1, 17) == -2
+        assert lib.mvp_emd_configure(-1, -1, -1, 0) == -2           # MVP_EBADARG: resident cap 1..64
+        assert lib.mvp_emd_configure(-1, -1, -1, 65) == -2
         assert lib.mvp_emd_configure(-1, -1, -1, 8) == 0
     finally:
         assert lib.mvp_emd_configure(0, -1, _lib.EMD_DEFAULT_SPLIT, 16) == 0
