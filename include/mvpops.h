@@ -121,11 +121,11 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * still unassigned -- the ones whose rounds cost most -- get 8, the lightest 2
  * (64 uniform clouds: 8,5,4,4,3,3,3,2 over the eight clouds of an XCD; equally
  * loaded clouds keep 4 each)
- * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  With split = 3 (the default)
+ * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  With split = 4 (the default; 3: in a launch of its own)
  * clouds of at most 4096 points leave the clustered kernels as soon as at most
  * `resident_cap` (16) persons are unassigned -- round ~300 of 3000 at 1024
- * points, 500-850 at 2048, 900-1700 at 4096 -- and a last, plain launch
- * (csrc/emd_resident.hip, one workgroup per cloud) runs the remaining rounds
+ * points, 500-850 at 2048, 900-1700 at 4096 -- and member 0 of the cloud's cluster
+ * (csrc/emd_resident.h, one workgroup per cloud) runs the remaining rounds
  * with the whole auction state in that workgroup's LDS: no global memory access
  * inside a round.  Which workgroups serve a cloud, and in which launch, never
  * changes a bit of the result.
@@ -142,8 +142,9 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  * negative argument leaves that knob unchanged.
  *   cluster     0 = automatic, or 1|2|4|8: cap of the workgroups per cloud
  *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
- *   split       3 (default): as 2, and clouds of <= 4096 points finish LDS-resident
- *               (csrc/emd_resident.hip); 2: the tail rounds run in the second kernel, from
+ *   split       4 (default): as 2, and clouds of <= 4096 points finish LDS-resident
+ *               (csrc/emd_resident.h) on member 0 of their cluster, inside the second kernel's launch;
+ *               3: the same in a launch of its own (every cloud waits for the last to get there); 2: the tail rounds run in the second kernel, from
  *               round 300 on with cluster widths by load (8 .. 2 workgroups);
  *               1: second kernel, fixed widths; 0: the first kernel runs every round
  *               (environment, read once: MVP_EMD_PLAN_ROUND = 300; MVP_EMD_PLAN_WIDTHS, e.g.

@@ -58,7 +58,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
 ABI_VERSION = 11  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
-EMD_DEFAULT_SPLIT = 3
+EMD_DEFAULT_SPLIT = 4
 
 _lib = None
 
@@ -167,7 +167,7 @@ def emd_records(scratch, nbytes, b):
       next_round            0 once the cloud is finished
       unassigned            persons unassigned at the LAST hand-over
       final_width           cluster width of the launch that finished the cloud (0: the first kernel did)
-      final_launch          1 = the launch after the first kernel, 2 = the tiered one, 3 = the LDS-resident one"""
+      final_launch          1 = the launch after the first kernel, 2 = the tiered one, 3 = LDS-resident (in its own launch or fused into launch 1)"""
     import torch
     rb = EMD_RECORD_INTS * 4
     stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()

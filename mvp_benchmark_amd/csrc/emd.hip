@@ -1476,11 +1476,12 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
 //   MVP_EMD_SAME_XCD=0        keep the write-through stores even when a cluster shares an XCD
 //   MVP_EMD_SPLIT=0|1|2|3     0: one kernel runs every round; 1: the rounds after the last four-bidders-per-wave
 //                             round run in the lean kernel (emd_lean.hip); 2: + cluster widths dealt out by load
-//                             at round 300 (33..64 clouds of >= 4096 points); 3 (default): + clouds of <= 4096
-//                             points finish LDS-resident on one workgroup (emd_resident.hip)
+//                             at round 300 (33..64 clouds of > 4096 points); 3: + clouds of <= 4096 points finish
+//                             LDS-resident on one workgroup, in a launch of their own (emd_resident.hip); 4 (default):
+//                             ... inside the lean launch, on member 0 of the cloud's cluster (no launch boundary)
 // The results do not depend on any of them (bit-identical; tests/test_gpu_ops.py).
 struct EmdKnobs {
-  int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip), 3 + resident tail
+  int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip), 3 + resident tail (own launch), 4 fused into the lean launch
   int plan_round, plan_every;     // split == 2: round of the first plan; rounds per planned launch
   unsigned long long plan_widths; // widths of an XCD's 8 cloud slots, heaviest first, 4 bits each
   int res_cap;                    // split == 3: unassigned persons at which a cloud of <= 4096 points moves into LDS (emd_resident.hip)
@@ -1488,10 +1489,10 @@ struct EmdKnobs {
 static std::mutex g_knob_mutex;
 static EmdKnobs &emd_knobs_locked() {   // (callers hold g_knob_mutex)
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 3, 300, 4096, 0ull, 16};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
+    EmdKnobs v{kMaxCluster, 1, 4, 300, 4096, 0ull, 16};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
-    if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 3 ? 3 : atoi(e);
+    if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 4 ? 4 : atoi(e);
     if (const char *e = getenv("MVP_EMD_RESIDENT_CAP")) v.res_cap = atoi(e) < 1 ? 1 : atoi(e) > kResList ? kResList : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_ROUND")) v.plan_round = atoi(e) < 1 ? 1 : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_EVERY")) v.plan_every = atoi(e) < 64 ? 64 : atoi(e);
@@ -1563,7 +1564,7 @@ extern "C" int mvp_emd_configure(int cluster, int same_xcd, int split, int resid
     k.cluster = cluster == 0 ? kMaxCluster : cluster;
   }
   if (same_xcd >= 0) k.same_xcd = same_xcd != 0;
-  if (split >= 0) k.split = split > 3 ? 3 : split;
+  if (split >= 0) k.split = split > 4 ? 4 : split;
   return MVP_OK;
 }
 
@@ -1604,7 +1605,7 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
   }
   if (lean && emd_lean_launch(b, n, w, xyz1, dist, assignment, eps, iters, sbase, knobs.same_xcd,
                               knobs.plan_round, knobs.split >= 2 ? knobs.plan_every : 0, knobs.plan_widths,
-                              knobs.split >= 3 ? knobs.res_cap : 0, st) != hipSuccess)
+                              knobs.split >= 4 ? knobs.res_cap : knobs.split == 3 ? -knobs.res_cap : 0, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
   return check_launch("mvp_emd_forward");
 }

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "emd_common.h"
+#include "emd_resident.h"
 
 namespace mvp {
 
@@ -62,26 +63,28 @@ struct LeanShared {
 // had another width: entry p of its lists' concatenation goes to member p % WB.  Which workgroups
 // serve a cloud does not change a bit of the result -- the auction state is in the scratch, the
 // bids of a round do not depend on each other or on their order.
+// Returns 1 when this workgroup is to finish the cloud LDS-resident itself (`fused`: no launch in between; the
+// members of the cluster have left their lists in the scratch and all but member 0 are gone), else 0.
 template <int WB>
-__device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, const int wg, int b,
-                                              int n, const float *__restrict__ xyz1, float *__restrict__ dist,
-                                              int *assignment, float eps, int iters, char *scratch, int fast_ok,
-                                              int it_stop, int which, int u_stop) {
+__device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, const int wg, int b,
+                                             int n, const float *__restrict__ xyz1, float *__restrict__ dist,
+                                             int *assignment, float eps, int iters, char *scratch, int fast_ok,
+                                             int it_stop, int which, int u_stop, int fused = 0) {
   constexpr int W = WB, WM = WB;
   const int t = threadIdx.x;
   const int lane = t & (kWave - 1);
   const int wave = t >> 6;   // (marking it wave-uniform with readfirstlane: 3 VGPRs fewer, the same 34.5-34.8 ms at the headline)
   char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
-  if (cloud >= b) return;
+  if (cloud >= b) return 0;
   char *cbase = scratch + (size_t)cloud * emd_scratch_per_cloud(n);
   u64 *slots = emd_granules(tail, b, cloud, which);   // this launch's own granules (zeroed by the host)
   EmdHandover *resume = emd_handover(tail, b, cloud);
   long long *stats = emd_stats(tail, b, cloud);
   const int it0 = resume->next_it;
-  if (it0 == 0 || it0 >= it_stop) return;   // finished already / not this launch's rounds (uniform over the cluster)
+  if (it0 == 0 || it0 >= it_stop) return 0;   // finished already / not this launch's rounds (uniform over the cluster)
   // u_stop > 0: the cloud is left to the resident kernel (emd_resident.hip) as soon as at most u_stop persons
   // are unassigned -- possibly at once: the record and the lists stay as the previous launch wrote them
-  if (resume->utot <= u_stop && iters - it0 >= kResMinRounds) return;
+  if (resume->utot <= u_stop && iters - it0 >= kResMinRounds) return fused && wg == 0 ? 1 : 0;
   xyz1 += (size_t)cloud * n * 3;
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
@@ -272,7 +275,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
         dist[j] = __builtin_nanf("");
         ass[j] = -1;
       }
-      return;
+      return 0;
     }
   } else {
     __syncthreads();
@@ -290,6 +293,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
   bool clustered = WB != 1;
   int stop_cnt = -1;   // >= 0: the loop ended before round stop_it with this many entries in this member's next list
   int stop_it = it_stop;
+  bool stop_for_res = false;   // ... because at most u_stop persons are left (not because round it_stop is next)
 #ifdef MVP_EMD_PROFILE
   long long prof_pg1 = 0, prof_drain = 0, prof_gather = 0, cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0, prof_a1 = 0, prof_an = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0;
 #endif
@@ -810,6 +814,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
         // ---- this launch's last round: the lists are left for the next launch below the loop
         stop_cnt = cntw[wg];
         stop_it = it + 1;
+        stop_for_res = !(it + 1 == it_stop);
         break;
       }
       if (__builtin_expect(Utot > 0 && Utot <= kSoloMax && it + 1 < iters, 0)) {
@@ -822,7 +827,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
         }
         if (wg != 0) {
           if (t == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
-          return;
+          return 0;
         }
         int idx = t;
 #pragma unroll
@@ -948,6 +953,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
                            (Utot <= u_stop && Utot > 0 && iters - (it + 1) >= kResMinRounds), 0)) {   // (member 0 alone)
         stop_cnt = Utot;
         stop_it = it + 1;
+        stop_for_res = !(it + 1 == it_stop);
         break;
       }
       {
@@ -1012,7 +1018,24 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
         atomicAdd(reinterpret_cast<unsigned long long *>(&st2[0]), (unsigned long long)n_rounds);
       }
     }
-    return;
+    if (fused && stop_for_res) {
+      // The cloud goes on LDS-resident on member 0 at once: the members' lists and counts above are plain stores --
+      // released (written back), one more cluster barrier, then member 0 reads them (and the auction state the
+      // rounds wrote through) after dropping its L1; the other members leave.
+      if (clustered) {
+        __syncthreads();
+        if (t == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        u64 *slots2 = emd_granules(tail2, b, cloud2, which);
+        if (!emd_cluster_gather_n<WM>(slots2, W, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) return 0;
+      } else {
+        __syncthreads();
+      }
+      if (wg != 0) return 0;
+      if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+      __syncthreads();
+      return 1;
+    }
+    return 0;
   }
 #ifdef MVP_EMD_CLOUDTIME
   if (wg == 0 && t == 0)   // 100 MHz constant clock
@@ -1026,7 +1049,7 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
       dist[j] = __builtin_nanf("");
       ass[j] = -1;
     }
-    return;
+    return 0;
   }
   if (t == 0) {
     // rounds: added to the first kernel's count; an internal error drives the sum far below zero
@@ -1082,17 +1105,29 @@ __device__ __forceinline__ void emd_lean_body(LeanShared &sh, const int cloud, c
     dist[j] = sqdist3(dx, dy, dz);
     ass[j] = sc.perm[s];
   }
+  return 0;
 }
 
 // Every cloud on a cluster of WT workgroups (grid WT * bpad, laid out as the first kernel's).
-template <int WT>
+// RESN > 0 (2048 / 4096, with u_stop > 0): a cloud of at most RESN points does not wait for a next launch once at
+// most u_stop persons are unassigned -- member 0 of its cluster runs the resident rounds (emd_resident.h) at once,
+// on this workgroup, with the LDS re-used.
+template <int WT, int RESN>
 __global__ __launch_bounds__(kEmdThreads) void emd_lean_kernel(
     int b, int bpad, int n, const float *__restrict__ xyz1, float *__restrict__ dist, int *assignment,
     float eps, int iters, char *scratch, int fast_ok, int it_stop, int which, int u_stop) {
-  __shared__ LeanShared sh;
   const int cloud = WT == 1 ? (int)blockIdx.x : (int)blockIdx.x % bpad;
   const int wg = WT == 1 ? 0 : (int)blockIdx.x / bpad;
-  emd_lean_body<WT>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which, u_stop);
+  if constexpr (RESN == 0) {
+    __shared__ LeanShared sh;
+    emd_lean_body<WT>(sh, cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, it_stop, which, u_stop);
+  } else {
+    constexpr size_t kBytes = sizeof(LeanShared) > sizeof(ResShared<RESN>) ? sizeof(LeanShared) : sizeof(ResShared<RESN>);
+    __shared__ __attribute__((aligned(16))) char raw[kBytes];
+    if (emd_lean_body<WT>(*reinterpret_cast<LeanShared *>(raw), cloud, wg, b, n, xyz1, dist, assignment, eps, iters, scratch,
+                          fast_ok, it_stop, which, u_stop, 1))
+      emd_resident_body<RESN>(*reinterpret_cast<ResShared<RESN> *>(raw), cloud, b, n, dist, assignment, eps, iters, scratch);
+  }
 }
 
 // TIERED widths (grid 4 * bpad, 40 <= bpad <= 64).  The clouds' rounds differ in cost -- a cloud with
@@ -1206,19 +1241,28 @@ __global__ __launch_bounds__(kEmdThreads) void emd_lean_tiers_kernel(
 #undef MVP_LEAN_BODY
 }
 
-template <int WT>
+template <int WT, int RESN = 0>
 static hipError_t emd_lean_launch_w(int b, int n, const float *xyz1, float *dist, int *assignment, float eps,
                                     int iters, char *scratch, int fast_ok, int it_stop, int which,
                                     hipStream_t stream, int u_stop = 0) {
   int bpad = WT == 1 ? b : (b + 7) / 8 * 8;
   if (WT == 1) {
-    hipLaunchKernelGGL(emd_lean_kernel<1>, dim3(b), dim3(kEmdThreads), 0, stream, b, bpad, n, xyz1, dist,
+    hipLaunchKernelGGL((emd_lean_kernel<1, RESN>), dim3(b), dim3(kEmdThreads), 0, stream, b, bpad, n, xyz1, dist,
                        assignment, eps, iters, scratch, 0, it_stop, which, u_stop);
     return hipSuccess;
   }
   void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &it_stop, &which, &u_stop};
-  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_kernel<WT>), dim3(WT * bpad),
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_kernel<WT, RESN>), dim3(WT * bpad),
                                     dim3(kEmdThreads), args, 0, stream);
+}
+
+template <int RESN>
+static hipError_t emd_lean_launch_res(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps,
+                                      int iters, char *scratch, int fast_ok, hipStream_t stream, int u_stop) {
+  if (w == 8) return emd_lean_launch_w<8, RESN>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, u_stop);
+  if (w == 4) return emd_lean_launch_w<4, RESN>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, u_stop);
+  if (w == 2) return emd_lean_launch_w<2, RESN>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, u_stop);
+  return emd_lean_launch_w<1, RESN>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, u_stop);
 }
 
 // Runs the rounds the first kernel handed over.  Clouds that were not handed over exit at once.
@@ -1229,16 +1273,23 @@ static hipError_t emd_lean_launch_w(int b, int n, const float *xyz1, float *dist
 hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, int *assignment, float eps,
                            int iters, char *scratch, int fast_ok, int plan_round, int plan_every,
                            unsigned long long plan_widths, int res_cap, hipStream_t stream) {
-  if (res_cap > 0 && n <= kResMaxN) {
-    // Clouds of at most kResMaxN points: the clustered rounds end as soon as at most res_cap persons are
-    // unassigned; the resident kernel (one workgroup per cloud, the auction state in LDS) runs the rest.
-    res_cap = res_cap > kResList ? kResList : res_cap;
-    hipError_t e = hipSuccess;
-    if (w == 8) e = emd_lean_launch_w<8>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, res_cap);
-    else if (w == 4) e = emd_lean_launch_w<4>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, res_cap);
-    else if (w == 2) e = emd_lean_launch_w<2>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, res_cap);
-    else e = emd_lean_launch_w<1>(b, n, xyz1, dist, assignment, eps, iters, scratch, fast_ok, iters, 1, stream, res_cap);
+  if (res_cap != 0 && n <= kResMaxN) {
+    // Clouds of at most kResMaxN points: the clustered rounds end as soon as at most |res_cap| persons are
+    // unassigned and the rest runs LDS-resident on one workgroup per cloud (emd_resident.h) -- res_cap > 0: on
+    // member 0 of the cloud's cluster at once, inside the same launch; res_cap < 0: in a launch of its own
+    // (every cloud waits for the last one to get there: A/B, and the fallback if the fused kernels do not fit).
+    const bool fused = res_cap > 0;
+    int cap = res_cap > 0 ? res_cap : -res_cap;
+    cap = cap > kResList ? kResList : cap;
+    hipError_t e = hipErrorUnknown;
+    if (fused) {
+      e = n <= 2048 ? emd_lean_launch_res<2048>(b, n, w, xyz1, dist, assignment, eps, iters, scratch, fast_ok, stream, cap)
+                    : emd_lean_launch_res<4096>(b, n, w, xyz1, dist, assignment, eps, iters, scratch, fast_ok, stream, cap);
+      if (e != hipSuccess) (void)hipGetLastError();
+    }
+    if (e != hipSuccess) e = emd_lean_launch_res<0>(b, n, w, xyz1, dist, assignment, eps, iters, scratch, fast_ok, stream, cap);
     if (e != hipSuccess) return e;
+    // (fused: only clouds nobody finished -- none -- are left for it; it exits at once)
     return emd_resident_launch(b, n, dist, assignment, eps, iters, scratch, stream);
   }
   int bpad = (b + 7) / 8 * 8;

@@ -51,10 +51,13 @@ def _check(oracle, x1, x2, eps, iters, expect_resident=None):
     return rec
 
 
+@pytest.mark.parametrize("split", [4, 3])
 @pytest.mark.parametrize("b,n", [(3, 1024), (3, 2048), (2, 3072), (3, 4096)])
-def test_resident_tail_matches_oracle(oracle, b, n):
-    """Eval setting (eps 0.004, 3000 rounds) at every cloud size the resident kernel covers (two
-    instantiations: <= 2048 and <= 4096 points)."""
+def test_resident_tail_matches_oracle(oracle, knobs, b, n, split):
+    """Eval setting (eps 0.004, 3000 rounds) at every cloud size the resident rounds cover (two
+    instantiations: <= 2048 and <= 4096 points), fused into the lean launch (split 4, the default: member 0 of
+    the cloud's cluster goes on at once) and in a launch of their own (split 3)."""
+    knobs(split=split)
     x1, x2 = rand_clouds(1000 + n, b, n, 3), rand_clouds(2000 + n, b, n, 3)
     rec = _check(oracle, x1, x2, 0.004, 3000, expect_resident=True)
     assert (rec["unassigned"] <= 16).all() and (rec["unassigned"] > 0).all()
@@ -72,10 +75,11 @@ def test_resident_cap_changes_no_bit(oracle, knobs, cap):
         assert (rec["final_launch"] == 3).all()
 
 
+@pytest.mark.parametrize("split", [4, 3])
 @pytest.mark.parametrize("width", [1, 2, 4, 8])
-def test_resident_after_every_cluster_width(oracle, knobs, width):
-    """The resident kernel picks up whatever lists the clustered launch left: 1, 2, 4 or 8 of them."""
-    knobs(cluster=width)
+def test_resident_after_every_cluster_width(oracle, knobs, width, split):
+    """The resident rounds pick up whatever lists the clustered rounds left: 1, 2, 4 or 8 of them."""
+    knobs(cluster=width, split=split)
     x1, x2 = rand_clouds(311, 2, 2048, 3), rand_clouds(312, 2, 2048, 3)
     _check(oracle, x1, x2, 0.004, 3000, expect_resident=True)
 
@@ -132,10 +136,16 @@ def test_resident_cfg4_full_batch_matches_oracle(oracle, n):
 
 
 def test_resident_equals_clustered_at_4096_full_batch(oracle, knobs):
-    """64 clouds of 4096 points: the resident path (default) against the tiered clustered launches
-    (split = 2), bit for bit; the heaviest and the lightest cloud also against the oracle."""
+    """64 clouds of 4096 points: the resident path (default: fused) against the tiered clustered launches
+    (split = 2) and against the resident launch of its own (split = 3), bit for bit; the heaviest and the lightest
+    cloud also against the oracle."""
     x1, x2 = rand_clouds(401, 64, 4096, 3), rand_clouds(402, 64, 4096, 3)
     d3, a3, r3 = _run(x1, x2, 0.004, 3000)
+    knobs(split=3)
+    d3b, a3b, r3b = _run(x1, x2, 0.004, 3000)
+    np.testing.assert_array_equal(a3, a3b)
+    np.testing.assert_array_equal(d3, d3b)
+    np.testing.assert_array_equal(r3["bids"], r3b["bids"])
     knobs(split=2)
     d2, a2, r2 = _run(x1, x2, 0.004, 3000)
     np.testing.assert_array_equal(a3, a2)

@@ -456,7 +456,7 @@ def test_emd_tiered_launch_refused_late_or_repeated_gives_the_same_bits():
         outs.append(r.stdout.strip().splitlines()[-1])
     assert len(set(o.split()[0] for o in outs)) == 1, outs
     assert "[204]" in outs[1] and "[204]" not in outs[0], outs      # refused: every cloud finished by a 4-wide launch on granule set 2
-    assert "[301]" in outs[5], outs                                  # default: one workgroup per cloud, the resident launch
+    assert "[301]" in outs[5], outs                                  # default: one workgroup per cloud, LDS-resident
 
 
 def test_emd_headline_batch_tiered_equals_single_kernel_and_oracle(oracle, emd_split):
