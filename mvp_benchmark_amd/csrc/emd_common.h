@@ -280,6 +280,38 @@ __device__ __forceinline__ void wave_top2(float v, float &b1, float &b2) {
   b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 63));
 }
 
+// max over the wave (uniform result): six v_max_f32 with a DPP operand -- lanes a step does not write keep their own
+// value -- spelled in assembly: the compiler expands each step of the intrinsic form into {mov, nop, mov_dpp,
+// canonicalising max, max} (30 instructions per reduction, four dependent ones per step).  The s_nop 1 in front
+// of every step is the VALU-write -> DPP-read hazard the assembler does not handle inside an asm block.
+__device__ __forceinline__ float emd_wave_max(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Second-largest value (with multiplicity) of the wave's per-lane values: the maximum, then the maximum of the
+// rest with one holder of the maximum set aside.  Two DPP reductions of six instructions each instead of
+// wave_second_largest's six identity-filled merge steps (~55 instructions).
+__device__ __forceinline__ float emd_wave_second(float v) {
+  const float t1 = emd_wave_max(v);
+  const int l1 = (int)__builtin_ctzll(__ballot(v == t1));
+  return emd_wave_max((int)(threadIdx.x & 63) == l1 ? -1e9f : v);
+}
+
 struct GridGeom {
   float lox, loy, loz, invh;
   int g;

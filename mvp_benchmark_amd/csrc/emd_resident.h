@@ -56,29 +56,6 @@ struct ResShared {
   int s_err;
 };
 
-// max over the wave (uniform result): six v_max_f32 with a DPP operand -- lanes a step does not write keep their own
-// value -- spelled in assembly: the compiler expands each step of the intrinsic form into {mov, nop, mov_dpp,
-// canonicalising max, max} (30 instructions per reduction, four dependent ones per step).  The s_nop 1 in front
-// of every step is the VALU-write -> DPP-read hazard the assembler does not handle inside an asm block.
-__device__ __forceinline__ float res_wave_max(float v) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1"
-      : "+v"(v));
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
 // min over each 16-lane row, valid in every lane of the row
 __device__ __forceinline__ float row_min(float v) {
   const float inf = __builtin_inff();
@@ -258,10 +235,10 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
         const float4 o = sh.obj[home * kWave + lane];
         const float v = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
         // largest value, then the largest of the rest (one holder of the maximum set aside)
-        const float t1 = res_wave_max(v);
+        const float t1 = emd_wave_max(v);
         const unsigned long long m1 = __ballot(v == t1);
         const int l1 = (int)__builtin_ctzll(m1);
-        const float t2 = res_wave_max(lane == l1 ? -1e9f : v);
+        const float t2 = emd_wave_max(lane == l1 ? -1e9f : v);
         const unsigned long long m2 = __ballot(v >= t2);
         if (__builtin_expect(t1 > t2 && __builtin_popcountll(m2) == 2, 1)) {
           // two different values, one holder each: the state emd_fold would arrive at
