@@ -452,18 +452,25 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         n_visit += (nlist + 15) / 16;
 #endif
         for (int k0 = 0; k0 < nlist; k0 += 16) {
-          int s[4], s1[4];
+          // (straight-line: the four list entries, then the four cells' offsets, are read unconditionally -- entries
+          // behind the list's end are clamped and discarded -- so that each set shares ONE LDS round trip; guarded by
+          // `k < nlist` the compiler put a full wait behind every single read: eight dependent trips per step)
+          int s[4], s1[4], cw[4], m0[4], m1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cw[r] = wl[min(k0 + r * 4 + sub, 4 * kRowListCap - 1)];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int k = k0 + r * 4 + sub;
-            s[r] = 0;
-            s1[r] = 0;
-            if (k < nlist) {
-              const int cw = wl[k], cc = cw & 0x7FF, q = cw >> 11;   // cell, chunk of 16 members
-              const int m0 = c_start[cc] + 16 * q, m1 = c_start[cc + 1];
-              s[r] = m0 + sl;
-              s1[r] = q == 31 ? m1 : min(m1, m0 + 16);   // (chunk 31 stands for everything behind it: cells of > 512 members)
-            }
+            const int cc = min(cw[r] & 0x7FF, kMaxCells - 1);
+            m0[r] = c_start[cc];
+            m1[r] = c_start[cc + 1];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = cw[r] >> 11;   // chunk of 16 members of the cell
+            const bool in = k0 + r * 4 + sub < nlist;
+            const int b0 = m0[r] + 16 * q;
+            s[r] = in ? b0 + sl : 0;
+            s1[r] = in ? (q == 31 ? m1[r] : min(m1[r], b0 + 16)) : 0;   // (chunk 31 stands for everything behind it: cells of > 512 members)
           }
           bool more = true;
           while (more) {  // (a second pass only for cells of more than 32 members)
