@@ -58,7 +58,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
 ABI_VERSION = 11  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
-EMD_DEFAULT_SPLIT = 4
+EMD_DEFAULT_SPLIT = 5
 
 _lib = None
 
@@ -156,7 +156,7 @@ def emd_configure(cluster=-1, same_xcd=-1, split=-1, resident_cap=-1):
         raise MvpOpsError("mvp_emd_configure: %s" % _ERR.get(rc, rc))
 
 
-EMD_RECORD_INTS = 20     # csrc/emd_common.h: struct EmdHandover (80 bytes per cloud, right before the statistics)
+EMD_RECORD_INTS = 24     # csrc/emd_common.h: struct EmdHandover (96 bytes per cloud, right before the statistics)
 
 
 def emd_records(scratch, nbytes, b):

@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
 //                             ... inside the lean launch, on member 0 of the cloud's cluster (no launch boundary)
 // The results do not depend on any of them (bit-identical; tests/test_gpu_ops.py).
 struct EmdKnobs {
-  int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip), 3 + resident tail (own launch), 4 fused into the lean launch
+  int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip), 3 + resident tail (own launch), 4 fused into the lean launch, 5 + gathered-bid rounds
   int plan_round, plan_every;     // split == 2: round of the first plan; rounds per planned launch
   unsigned long long plan_widths; // widths of an XCD's 8 cloud slots, heaviest first, 4 bits each
   int res_cap;                    // split == 3: unassigned persons at which a cloud of <= 4096 points moves into LDS (emd_resident.hip)
@@ -1489,10 +1489,10 @@ struct EmdKnobs {
 static std::mutex g_knob_mutex;
 static EmdKnobs &emd_knobs_locked() {   // (callers hold g_knob_mutex)
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 4, 300, 4096, 0ull, 16};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
+    EmdKnobs v{kMaxCluster, 1, 5, 300, 4096, 0ull, 16};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
-    if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 4 ? 4 : atoi(e);
+    if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 5 ? 5 : atoi(e);
     if (const char *e = getenv("MVP_EMD_RESIDENT_CAP")) v.res_cap = atoi(e) < 1 ? 1 : atoi(e) > kResList ? kResList : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_ROUND")) v.plan_round = atoi(e) < 1 ? 1 : atoi(e);
     if (const char *e = getenv("MVP_EMD_PLAN_EVERY")) v.plan_every = atoi(e) < 64 ? 64 : atoi(e);
@@ -1564,7 +1564,7 @@ extern "C" int mvp_emd_configure(int cluster, int same_xcd, int split, int resid
     k.cluster = cluster == 0 ? kMaxCluster : cluster;
   }
   if (same_xcd >= 0) k.same_xcd = same_xcd != 0;
-  if (split >= 0) k.split = split > 4 ? 4 : split;
+  if (split >= 0) k.split = split > 5 ? 5 : split;
   return MVP_OK;
 }
 
@@ -1603,7 +1603,7 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
     w = 1;
     (void)emd_launch<1>(b, n, xyz1, xyz2, dist, assignment, eps, iters, sbase, lean, 0, st);
   }
-  if (lean && emd_lean_launch(b, n, w, xyz1, dist, assignment, eps, iters, sbase, knobs.same_xcd,
+  if (lean && emd_lean_launch(b, n, w, xyz1, dist, assignment, eps, iters, sbase, knobs.same_xcd | (knobs.split >= 5 ? 2 : 0),
                               knobs.plan_round, knobs.split >= 2 ? knobs.plan_every : 0, knobs.plan_widths,
                               knobs.split >= 4 ? knobs.res_cap : knobs.split == 3 ? -knobs.res_cap : 0, st) != hipSuccess)
     return check_launch("mvp_emd_forward");

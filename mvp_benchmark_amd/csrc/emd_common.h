@@ -39,6 +39,13 @@ static_assert(kLeanCap <= kRecCap, "the lean kernel keeps every list entry's rec
 // The resident kernel (emd_resident.hip) takes a cloud of at most kResMaxN points over once at most
 // `res_cap` <= kResList persons are unassigned and at least kResMinRounds rounds are left: the whole
 // auction state then lives in one workgroup's LDS.
+// Gathered-bid rounds of the lean kernels (emd_lean.hip): once a cloud has at most kGCap unassigned persons its bids
+// travel as tagged 16-byte granules, every member of the cluster settles every bid itself and the round has ONE
+// cluster-wide wait instead of a bid atomic, two all-gathers and Assign's dependent loads.
+constexpr int kGCap = 256;      // bids of a cloud per round
+constexpr int kGMaxN = 16384;   // 14-bit slots / person indices in a granule
+constexpr int kGStride = 2 * kGCap + 8;   // 8-byte words of one parity's bid area: the bids, then a heartbeat per member
+constexpr size_t kEmdBidBytes = 2 * (size_t)kGStride * 8;   // per cloud, both parities
 constexpr int kResMaxN = 4096;
 constexpr int kResList = 64;
 constexpr int kResMinRounds = 32;
@@ -88,6 +95,8 @@ struct EmdHandover {
   int epoch;       // barrier count of the launches so far (launches that share a set of granules go on counting)
   int first_it;    // round of the FIRST hand-over (kept for the statistics; next_it returns to 0 when the cloud is done)
   int last_width;  // cluster width of the launch that finished the cloud + 16 * that launch's granule set (1, 2)
+  int epoch_g;     // gathered-bid rounds run so far (their granules' tags go on counting across launches)
+  int pad_[3];
 };
 static_assert(sizeof(EmdHandover) % 16 == 0, "the scratch tail stays 16-byte granular");
 
@@ -100,15 +109,19 @@ __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
 // kernel, 256 B per cloud for each of the lean kernel's two launches, the hand-over records, then
 // the per-cloud statistics {rounds, bids} (last: read by bench.py).
 constexpr int kEmdGranuleSets = 3;
-constexpr size_t kEmdTailPerCloud = 256 * kEmdGranuleSets + sizeof(EmdHandover) + 16;
+constexpr size_t kEmdTailPerCloud = 256 * kEmdGranuleSets + kEmdBidBytes + sizeof(EmdHandover) + 16;
 __host__ __device__ inline unsigned long long *emd_granules(char *tail, int b, int cloud, int which) {
   return reinterpret_cast<unsigned long long *>(tail + (size_t)which * b * 256 + (size_t)cloud * 256);
 }
+// (after the granule sets: the bid areas of the gathered-bid rounds, kEmdBidBytes per cloud)
+__host__ __device__ inline unsigned long long *emd_bid_area(char *tail, int b, int cloud) {
+  return reinterpret_cast<unsigned long long *>(tail + (size_t)b * 256 * kEmdGranuleSets + (size_t)cloud * kEmdBidBytes);
+}
 __host__ __device__ inline EmdHandover *emd_handover(char *tail, int b, int cloud) {
-  return reinterpret_cast<EmdHandover *>(tail + (size_t)b * 256 * kEmdGranuleSets) + cloud;
+  return reinterpret_cast<EmdHandover *>(tail + (size_t)b * (256 * kEmdGranuleSets + kEmdBidBytes)) + cloud;
 }
 __host__ __device__ inline long long *emd_stats(char *tail, int b, int cloud) {
-  return reinterpret_cast<long long *>(tail + (size_t)b * (256 * kEmdGranuleSets + sizeof(EmdHandover))) + 2 * (size_t)cloud;
+  return reinterpret_cast<long long *>(tail + (size_t)b * (256 * kEmdGranuleSets + kEmdBidBytes + sizeof(EmdHandover))) + 2 * (size_t)cloud;
 }
 
 __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
@@ -196,13 +209,17 @@ struct BidState {
   float b1, b2;  // best / second-best value
   int bk, b2k;   // their slots (b2k is only a seed hint)
   float tm;      // filter threshold: <= fl(fl(3 - b2) + kMargin)
+  float bp;      // (emd_fold<true> only) price of the best object as the search read it
+  int bc;        // (emd_fold<true> only) the list word of the cell it was found in
 };
 
 // Fold the candidates flagged in `mask` (exact value v and slot k per lane)
 // into the uniform state, lowest lane first.
+// PC: the best object's price `pw` and cell word `cw` (per lane, like v and k) are carried along (st.bp, st.bc).
+template <bool PC = false>
 __device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
                                          float v, int k, int n, int tpu,
-                                         const int *__restrict__ perm) {
+                                         const int *__restrict__ perm, float pw = 0.f, int cw = 0) {
   while (mask) {
     const int l = __builtin_ctzll(mask);
     mask &= mask - 1;
@@ -214,11 +231,19 @@ __device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
       st.b2k = st.bk;
       st.b1 = vl;
       st.bk = kl;
+      if constexpr (PC) {
+        st.bp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw), l));
+        st.bc = __builtin_amdgcn_readlane(cw, l);
+      }
     } else if (__builtin_expect(vl == st.b1, 0)) {
       st.b2 = st.b1;
       if (emd_precedes(perm[kl], perm[st.bk], n, tpu)) {
         st.b2k = st.bk;
         st.bk = kl;
+        if constexpr (PC) {
+          st.bp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw), l));
+          st.bc = __builtin_amdgcn_readlane(cw, l);
+        }
       } else {
         st.b2k = kl;
       }

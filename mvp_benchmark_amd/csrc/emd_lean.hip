@@ -17,6 +17,7 @@
 //   emd_lean_tiers_kernel   from round 300 on: the workgroups dealt out again, 8 .. 2 per cloud by the
 //                           clouds' load (a launch lasts as long as its slowest cloud; DESIGN.md 5.2, notebook 5e)
 #include <cstdlib>
+#include <type_traits>
 
 #include "emd_common.h"
 #include "emd_resident.h"
@@ -41,12 +42,28 @@ struct LeanShared {
   int s_alarm[2];
   unsigned s_gout[2 * kMaxCluster];
   int c_start[kMaxCells + 1];
-  int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
-  float s_binc[kLeanBid];
+  union {
+    struct {   // plain rounds: this round's bids by list position
+      int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
+      float s_binc[kLeanBid];
+    };
+    // gathered-bid rounds: bids per (object % 4096), 16-bit counters (a count of one = nobody else bid there); kept at
+    // zero between rounds by their readers
+    unsigned short s_bkt[4096];
+  };
   int s_own_chg[kLeanBid];
   float4 s_rq[2][kRecCap];
   int4 s_ri[2][kRecCap];
   unsigned short w_list[kEmdWaves][4 * kRowListCap];
+  // gathered-bid rounds: every member's view of the cloud -- who owns which object, the round's bids,
+  // every member's list length
+  unsigned short s_owner[kGMaxN];     // object slot -> person (0xFFFF: free)
+  unsigned short s_go[kGCap], s_gj[kGCap];   // the round's bids by position in the cloud-wide order: object, bidder
+  float s_ginc[kGCap];                //   ... increment
+  unsigned short s_won[2][kGCap];     // cells of the objects won this round (their price bound is re-scanned)
+  int s_nwon[2];
+  int s_pub;                          // bids this member has published this round
+  int s_gc[3][kMaxCluster];           // every member's list length: current round / next / (being zeroed)
 #ifdef MVP_EMD_PROFILE
   int s_wbusy[kEmdWaves];
   unsigned long long s_hist2[4];
@@ -193,6 +210,10 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   auto &s_rq = sh.s_rq;
   auto &s_ri = sh.s_ri;
   static_assert(kLeanBid == kRecCap, "one LDS slot per list position");
+  static_assert(sizeof(LeanShared) <= 160 * 1024, "one workgroup per CU: all of its LDS");
+  auto &s_owner = sh.s_owner; auto &s_go = sh.s_go; auto &s_gj = sh.s_gj; auto &s_ginc = sh.s_ginc;
+  auto &s_bkt = sh.s_bkt; auto &s_won = sh.s_won; auto &s_nwon = sh.s_nwon; auto &s_gc = sh.s_gc; auto &s_pub = sh.s_pub;
+  u64 *const bid_area = emd_bid_area(tail, b, cloud);
 
   // ------------------------------------------------------------ resume
   GridGeom gg;
@@ -266,7 +287,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
       s_xcc = (int)(xcc & 0xFu) + 1;
     }
     const bool ok = emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_xcc, &s_xcc, s_gout, &s_abort);
-    same_xcd = fast_ok != 0;
+    same_xcd = (fast_ok & 1) != 0;
 #pragma unroll
     for (int w = 1; w < WM; ++w) same_xcd &= w >= W || s_gout[2 * w] == s_gout[0];
     if (!ok) {
@@ -291,10 +312,17 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   // would only add latency: member 0 adopts the others' lists and carries on
   // alone (same code, workgroup barriers), the others leave.
   bool clustered = WB != 1;
+  // Gathered-bid rounds (entered below once at most kGCap persons are unassigned; their number never grows): `eg`
+  // counts them (tags of the bid granules), `goff` = this member's first position in the cloud-wide order of bids.
+  bool gm_now = false;
+  const bool gm_ok = WB != 1 && n <= kGMaxN && (fast_ok & 2) != 0;   // (fast_ok: bit 0 = same-XCD stores, bit 1 = gathered-bid rounds)
+  unsigned eg = (unsigned)resume->epoch_g;
+  int goff = 0, gi = 0;
   int stop_cnt = -1;   // >= 0: the loop ended before round stop_it with this many entries in this member's next list
   int stop_it = it_stop;
   bool stop_for_res = false;   // ... because at most u_stop persons are left (not because round it_stop is next)
 #ifdef MVP_EMD_PROFILE
+  long long prof_gap = 0, prof_prev4 = 0;
   long long prof_pg1 = 0, prof_drain = 0, prof_gather = 0, cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, cyc_sync2 = 0, n_alarm = 0, n_rebal = 0, prof_u = 0, prof_a1 = 0, prof_an = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0;
 #endif
 #ifdef MVP_EMD_PROFILE
@@ -305,7 +333,17 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   int ct_u[6] = {0, 0, 0, 0, 0, 0};
   long long ct_t[6] = {0, 0, 0, 0, 0, 0}, ct_b[6] = {0, 0, 0, 0, 0, 0};
 #endif
-  for (int it = it0; it < iters; ++it) {
+  // The round loop, instantiated twice -- GM = false: bid atomics + two all-gathers per round; GM = true: gathered-bid
+  // rounds -- so that each mode gets its own register allocation (one loop with a run-time mode: 98 -> 124 VGPRs and
+  // twice the scalar spills in BOTH modes).  Returns 0 when the rounds are over (or the workgroup has nothing left to
+  // do: ret_early), 2 / 3 when the next round is to run in the other mode.
+  int it = it0;
+  bool ret_early = false;
+  auto rounds = [&](auto gm_tag) -> int {
+  constexpr bool GM = decltype(gm_tag)::value;
+  constexpr bool gm = GM;
+  for (; it < iters; ++it) {
+    int sw = 0;   // 2: gathered-bid rounds from the next round on; 3: back to the plain rounds (member 0 alone)
     if (Utot == 0) break;
 #ifdef MVP_EMD_PROFILE
     if (cloud == 0 && wg == 0 && t == 0 && (it == 25 || it == 50 || it == 100 || it == 150 || it == 250 || it == 500 || it == 750 ||
@@ -320,7 +358,32 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         if (it == marks[q]) { ct_u[q] = Utot; ct_t[q] = wall_clock64() - ct0; ct_b[q] = n_bids; }
     }
 #endif
-    const int U = s_cnt[cur];  // this workgroup's bidders
+    // gathered-bid round: every member's list length (scalar registers), this member's first position in the
+    // cloud-wide order, and the heartbeat -- "every store this member issued in earlier rounds is performed" (the
+    // previous settle ended with a drain); the others' settle of THIS round waits for it
+    const int gcur = gi, gnxt = gi == 2 ? 0 : gi + 1, gzero = gi == 0 ? 2 : gi - 1;   // (rotating: this round's lengths, the next round's, the set cleared meanwhile)
+    if constexpr (WB != 1) {
+      if constexpr (GM) {
+        ++eg;
+        goff = 0;
+        {
+          const int cv = s_gc[gcur][lane & (kMaxCluster - 1)];   // (one LDS read; the sum is scalar work)
+#pragma unroll
+          for (int w = 0; w + 1 < WM; ++w)
+            if (w < wg) goff += __builtin_amdgcn_readlane(cv, w);
+        }
+#ifdef MVP_EMD_HBTOP
+        if (t == 0) {
+#else
+        if (t == 0 && s_gc[gcur][wg] == 0) {   // (a member with bidders: its last bid of the round raises the word)
+#endif
+          u64 *hb = bid_area + (size_t)(eg & 1u) * kGStride + 2 * kGCap + wg;
+          if (same_xcd) __hip_atomic_store(hb, (u64)eg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else __hip_atomic_store(hb, (u64)eg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    const int U = gm ? s_gc[gcur][wg] : s_cnt[cur];  // this workgroup's bidders
     n_rounds += 1;
     n_bids += U;
     const bool last = it == iters - 1;
@@ -330,6 +393,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 
 #ifdef MVP_EMD_PROFILE
     const long long tp0 = __builtin_readcyclecounter();
+    if (prof_prev4) prof_gap += tp0 - prof_prev4;
 #endif
     // A bid = one returning 64-bit atomic max on the object's key; the value
     // it returns is examined one bid later (or after the loop), so the wave
@@ -375,6 +439,8 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
       st.b2 = -1e9f;
       st.bk = -1;
       st.b2k = -1;
+      st.bp = 0.f;
+      st.bc = 0x7FF;
       const int s0 = c_start[c0], s1 = c_start[c0 + 1];
       // One pass, one value per lane: lanes 0.. take the home cell's members, lanes 62 / 63 the
       // previous best / second best when they live in another cell (the slots are cell-sorted:
@@ -487,7 +553,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 #ifdef MVP_EMD_PROFILE
               prof_fold += __builtin_popcountll(m);
 #endif
-              if (m) emd_fold(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm);
+              if (m) emd_fold<GM>(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm, o[r].w, cw[r]);
             }
             // cells with more than 16 members (rare): next 16
             bool mine = false;
@@ -513,10 +579,10 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         int ix0, iy0, iz0, nx, ny, nz;
         {
           const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
-          const float gm = (float)(gg.g - 1);
+          const float gmax = (float)(gg.g - 1);
           // the six bounds in six lanes of ONE instruction stream (lane l: axis l % 3, lower bound for
           // l < 3, upper bound otherwise) instead of six wave-uniform chains on the vector unit
-          const int bound = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(lane < 3 ? f_ax - r : f_ax + r), 0.f), gm);
+          const int bound = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(lane < 3 ? f_ax - r : f_ax + r), 0.f), gmax);
           ix0 = __builtin_amdgcn_readlane(bound, 0);
           iy0 = __builtin_amdgcn_readlane(bound, 1);
           iz0 = __builtin_amdgcn_readlane(bound, 2);
@@ -545,7 +611,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
               const float tq = st.tm - o[r].w;
               const bool ps = tq >= 0.f && sd <= tq * tq;
               const unsigned long long m = __ballot(ps);
-              if (m) emd_fold(st, m, emd_value(sd, o[r].w), base + r * kWave + lane, n, tpu, sc.perm);
+              if (m) emd_fold<GM>(st, m, emd_value(sd, o[r].w), base + r * kWave + lane, n, tpu, sc.perm, o[r].w, 0x7FF);
             }
           }
         }
@@ -636,27 +702,64 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
       if (lane == 0) {
         const float inc = st.b1 - st.b2 + eps;
         st_person_hi(j, st.bk, st.bk, st.b2k, inc);
-        s_bj[u] = j;
-        s_bo[u] = st.bk;
-        s_b2k[u] = st.b2k;
-        s_binc[u] = inc;
-        alarm |= emd_band_alarm(pend_old, pend_inc);
-        pend_old = atomicMax(reinterpret_cast<u64 *>(&sc.ostate[st.bk]),
-                             ((u64)emd_f2ord(inc) << 32) | (u64)((unsigned)j + 1u));
-        pend_inc = inc;
+        if constexpr (GM) {
+          // The bid as a granule at this bidder's position of the cloud-wide order: two 8-byte words, each with a
+          // tag of the round -- {increment | object 14 | bidder 14 | tag 4}, {the object's new price | second-best
+          // slot + 1 (next round's hint) 15 | its cell 11 | tag 6} -- so that every member can settle it without
+          // reading anything else.  (A position below the cloud's bidder count is rewritten every round of its
+          // parity: the tags only have to tell a round from the one two before.)
+          const float np = st.bp + inc;
+          const u64 g0 = ((u64)__float_as_uint(inc) << 32) | ((u64)(unsigned)st.bk << 18) | ((u64)(unsigned)j << 4) |
+                         (u64)(eg % 15u + 1u);
+          const u64 g1 = ((u64)__float_as_uint(np) << 32) | ((u64)(unsigned)(st.b2k + 1) << 17) |
+                         ((u64)(unsigned)(st.bc & 0x7FF) << 6) | (u64)(eg % 63u + 1u);
+          u64 *slot = bid_area + (size_t)(eg & 1u) * kGStride + 2 * (size_t)(goff + u);
+          if (same_xcd) {
+            __hip_atomic_store(slot, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(slot + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            __hip_atomic_store(slot, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          // The member's word of the round ("all my bids are out; everything I stored in earlier rounds is performed"
+          // -- the previous settle ended with a drain): raised with the member's last bid.  It is what the others
+          // spin on (W words per poll instead of every bid: polling the bids themselves by every waiting wave of 256
+          // CUs saturated the L2 and doubled the round); only a hint for the bids -- each carries its own tags.
+#ifdef MVP_EMD_HBTOP
+          if (false) {
+#else
+          if (atomicAdd(&s_pub, 1) == U - 1) {
+#endif
+            u64 *hb = bid_area + (size_t)(eg & 1u) * kGStride + 2 * kGCap + wg;
+            if (same_xcd) __hip_atomic_store(hb, (u64)eg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(hb, (u64)eg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else {
+          s_bj[u] = j;
+          s_bo[u] = st.bk;
+          s_b2k[u] = st.b2k;
+          s_binc[u] = inc;
+          alarm |= emd_band_alarm(pend_old, pend_inc);
+          pend_old = atomicMax(reinterpret_cast<u64 *>(&sc.ostate[st.bk]),
+                               ((u64)emd_f2ord(inc) << 32) | (u64)((unsigned)j + 1u));
+          pend_inc = inc;
+        }
         drawn = atomicAdd(&s_next, 1);
       }
       u = __builtin_amdgcn_readlane(drawn, 0);
     }
     }
+    const int nxt = cur ^ 1;
+#ifdef MVP_EMD_PROFILE
+    const long long tp1 = __builtin_readcyclecounter();
+    long long tp2 = tp1, tp3 = tp1;
+    if (lane == 0) s_wbusy[wave] = (int)(tp1 - tp0);
+#endif
+    if constexpr (!GM) {
     alarm |= emd_band_alarm(pend_old, pend_inc);
     int *my_alarm = &s_alarm[it & 1];
     if (alarm) *my_alarm = 1;
     if (t == 0) s_cnt[cur ^ 1] = 0;
-#ifdef MVP_EMD_PROFILE
-    const long long tp1 = __builtin_readcyclecounter();
-    if (lane == 0) s_wbusy[wave] = (int)(tp1 - tp0);
-#endif
     // ---------------- all bids of the round are placed
     bool any_alarm;
     if (clustered) {
@@ -703,11 +806,10 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
       s_next = kEmdWaves;         // list positions 0..15 belong to the waves, the rest are drawn
     }
 #ifdef MVP_EMD_PROFILE
-    const long long tp2 = __builtin_readcyclecounter();
+    tp2 = __builtin_readcyclecounter();
 #endif
 
     // ---------------- Assign (emd_cuda.cu:196-215)
-    const int nxt = cur ^ 1;
     u64 *my_chg = sc.chg + (size_t)wg * kChgCap;
     // Few bidders (the long tail): one or two per WAVE instead of all of them in
     // the lanes of wave 0 -- winners, losers and bound refreshes are divergent
@@ -788,33 +890,250 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 #endif
     }
 #ifdef MVP_EMD_PROFILE
-    const long long tp3 = __builtin_readcyclecounter();
+    tp3 = __builtin_readcyclecounter();
     if (t == 0 && it >= 100) prof_a4 += tp3 - tp2;
 #endif
+    } else {
+      // ---------------- gathered-bid round: wait for the round's bids, then EVERY member settles ALL
+      // of them on its own view of the cloud.  One cluster-wide wait per round: no bid atomic to wait for, no key to
+      // read back, no closing barrier -- a member only ever reads what it wrote itself (prices: every member stores
+      // every winner's new price, the same value) or what a heartbeat vouches for (hint records, written a round or
+      // more before they are read).  emd_cuda.cu:181-215 (GetMax + Assign).
+      if constexpr (WB != 1) {
+        u64 *ba = bid_area + (size_t)(eg & 1u) * kGStride;
+        const unsigned T4 = eg % 15u + 1u, T6 = eg % 63u + 1u;
+        u64 g0 = 0ull, g1 = 0ull;
+        if (wave * kWave < Utot) {   // the waves of threads p < Utot: thread p takes bid p
+          // (1) spin on the members' words of the round, (2) read the bids (normally there at once)
+          for (unsigned spins = 0;; ++spins) {
+            u64 x = (u64)eg;
+            if (lane < W) x = __hip_atomic_load(ba + 2 * kGCap + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(x == (u64)eg)) break;
+            if (spins >= kSpinLimit) {
+              if (lane == 0) s_abort = 1;
+#ifdef MVP_EMD_STUCKDUMP
+              if (wave == 0) {
+                int *dd = ass + wg * 32;
+                if (lane < W) dd[lane] = (int)x;
+                if (lane == 8) dd[8] = (int)eg;
+                if (lane == 9) dd[9] = it;
+                if (lane == 10) dd[10] = Utot;
+                if (lane == 11) dd[11] = U;
+                if (lane == 12) dd[12] = s_pub;
+                if (lane == 13) dd[13] = goff;
+                if (lane == 14) dd[14] = gi;
+                if (lane == 15) dd[15] = 777;
+                if (lane >= 16 && lane < 16 + WM) dd[lane] = s_gc[gcur][lane - 16];
+              }
+#endif
+#if defined(MVP_EMD_PROFILE) || defined(MVP_EMD_STUCK)
+              if (lane < W) printf("cloud %d wg %d wave %d: member word %d stuck at %llu, want %u (it %d Utot %d U %d goff %d gi %d pub %d)\n", cloud, wg, wave, lane, x, eg, it, Utot, U, goff, gi, s_pub);
+#endif
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          const bool isb = t < Utot;
+          bool ok = !isb;
+          for (unsigned spins = 0;; ++spins) {
+            if (isb && !ok) {
+              g0 = __hip_atomic_load(ba + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              g1 = __hip_atomic_load(ba + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = (unsigned)(g0 & 15ull) == T4 && (unsigned)(g1 & 63ull) == T6;
+            }
+            if (__all(ok)) break;
+            if (spins >= kSpinLimit) {
+              if (lane == 0) s_abort = 1;
+#if defined(MVP_EMD_PROFILE) || defined(MVP_EMD_STUCK)
+              if (!ok) printf("cloud %d wg %d: bid %d stuck: %llx %llx, want tags %u %u (it %d Utot %d U %d goff %d)\n", cloud, wg, t, g0, g1, T4, T6, it, Utot, U, goff);
+#endif
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        int go = 0, gj = 0, gb2 = -1, gcell = 0x7FF;
+        float ginc = 0.f, gnp = 0.f;
+        if (t < Utot) {
+          ginc = __uint_as_float((unsigned)(g0 >> 32));
+          go = (int)(g0 >> 18) & 0x3FFF;
+          gj = (int)(g0 >> 4) & 0x3FFF;
+          gnp = __uint_as_float((unsigned)(g1 >> 32));
+          gb2 = ((int)(g1 >> 17) & 0x7FFF) - 1;
+          gcell = (int)(g1 >> 6) & 0x7FF;
+          s_go[t] = (unsigned short)go;
+          s_gj[t] = (unsigned short)gj;
+          s_ginc[t] = ginc;
+          atomicAdd(reinterpret_cast<unsigned *>(s_bkt) + ((go & 4095) >> 1), 1u << ((go & 1) * 16));
+        }
+        lds_barrier();
+        if (s_abort) {
+          aborted = true;
+          break;
+        }
+#ifdef MVP_EMD_PROFILE
+        tp2 = __builtin_readcyclecounter();
+#endif
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+        int rec_pos = -1, rec_j = 0;
+        // Bids whose bucket holds more than one bid (a few per round: ~100 bids in 1024 buckets): the wave looks at
+        // one of them at a time -- does any OTHER bid name the same object? (4 bids per lane) -- and only a real
+        // contest (tens per call) is settled by its lane alone: the maximal increment bid on the object, then the
+        // highest bidder inside its 1e-6 band (emd_cuda.cu:181-194).
+        int contested = 0;   // 1: another bid wins my object
+#ifdef MVP_EMD_PROFILE
+        const long long tq0 = __builtin_readcyclecounter();
+#endif
+        if (wave * kWave < Utot && !last) {
+          bool flagged = false;
+          if (t < Utot) {
+            flagged = s_bkt[go & 4095] != 1;
+            s_bkt[go & 4095] = 0;   // (a bid that shares the bucket and reads after this sees 0: flagged as well)
+          }
+          unsigned long long fm = __ballot(flagged);
+#ifdef MVP_EMD_PROFILE
+          if (lane == 0) atomicAdd(&s_hist2[3], (unsigned long long)__builtin_popcountll(fm) << 32);
+#endif
+          while (fm) {
+            const int l = (int)__builtin_ctzll(fm);
+            fm &= fm - 1ull;
+            const int ol = __builtin_amdgcn_readlane(go, l), pl = (wave << 6) + l;
+            bool same = false;
+            for (int q = lane; q < Utot; q += kWave) same |= q != pl && s_go[q] == ol;
+            if (__builtin_expect(__any(same), 0)) {
+              // a real contest: the maximal increment bid on the object, then the highest bidder inside its 1e-6 band
+              // (emd_cuda.cu:181-194), over all of the round's bids, four per lane
+              float mi = -__builtin_inff();
+              for (int q = lane; q < Utot; q += kWave)
+                if (s_go[q] == ol) mi = __builtin_fmaxf(mi, s_ginc[q]);
+              mi = emd_wave_max(mi);
+              float wjf = -1.f;   // (indices < 2^14: exact in float)
+              for (int q = lane; q < Utot; q += kWave)
+                if (s_go[q] == ol && emd_in_band(s_ginc[q], mi)) wjf = __builtin_fmaxf(wjf, (float)s_gj[q]);
+              wjf = emd_wave_max(wjf);
+              if (lane == l && (int)wjf != gj) contested = 1;   // (1: lost the contest)
+            }
+          }
+        }
+#ifdef MVP_EMD_PROFILE
+        const long long tq1 = __builtin_readcyclecounter();
+        if (contested) atomicAdd(&s_hist2[2], 1ull << 32);
+#endif
+        if (t < Utot) {
+          // the member that placed bid t (it does the stores only one member needs to do)
+          int m = 0, acc = 0;
+#pragma unroll
+          for (int w = 0; w + 1 < WM; ++w) {
+            acc += s_gc[gcur][w];
+            if (w + 1 < W && t >= acc) m = w + 1;
+          }
+          const bool win = !contested;
+          if (win) {
+            if (!last) {
+              const int prev = s_owner[go];
+              s_owner[go] = (unsigned short)gj;
+              st_f32(&sc.obj[go].w, gnp);   // (every member: its own next searches read its own store)
+              if (prev != 0xFFFF) {
+                // the evicted owner bids again next round: in the list of member (position % W) -- the lists stay
+                // even without any exchange
+                const int d = t % W;
+                const int pos = atomicAdd(&s_gc[gnxt][d], 1);
+                if (d == wg) {
+                  pa = ld_person(prev, 0);
+                  pb = ld_person(prev, 1);
+                  rec_pos = pos;
+                  rec_j = prev;
+                }
+                if (m == wg) st_i32(&ass[prev], -1);
+              }
+              if (gcell < ncell) s_won[eg & 1u][atomicAdd(&s_nwon[eg & 1u], 1)] = (unsigned short)gcell;
+            }
+            if (m == wg) {
+              st_ostate(go, gj);
+              st_i32(&ass[gj], go);
+              if (last) st_f32(&sc.obj[go].w, gnp);
+            }
+          } else {
+            // lost: stays in its member's list, record carried over through LDS
+            const int pos = atomicAdd(&s_gc[gnxt][m], 1);
+            if (m == wg) {
+              s_rq[nxt][pos] = s_rq[cur][t - goff];
+              s_ri[nxt][pos] = make_int4(gj, go, gb2, 0);
+            }
+          }
+        }
+        // (what the next round starts from; nobody reads these before the barrier below)
+        if (t < WM) s_gc[gzero][t] = 0;
+        if (t == 0) {
+          s_nwon[(eg + 1u) & 1u] = 0;
+          s_next = kEmdWaves;
+          s_pub = 0;
+        }
+        // drain: this member's stores are performed before its next heartbeat says so (and before its own next
+        // searches read the prices); the evicted persons' records have arrived
+#ifdef MVP_EMD_PROFILE
+        const long long tq2 = __builtin_readcyclecounter();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MVP_EMD_PROFILE
+        const long long tq3 = __builtin_readcyclecounter();
+#endif
+        if (rec_pos >= 0) {
+          s_rq[nxt][rec_pos] = pa;
+          s_ri[nxt][rec_pos] = make_int4(rec_j, __float_as_int(pb.y), __float_as_int(pb.z), 0);
+        }
+        lds_barrier();
+        if (t == 0) s_cnt[nxt] = s_gc[gnxt][wg];
+#ifdef MVP_EMD_PROFILE
+        tp3 = __builtin_readcyclecounter();
+        if (t == 0) { prof_a1 += tq1 - tq0; prof_a2 += tq2 - tq1; prof_a3 += tq3 - tq2; prof_a4 += tp3 - tq3; prof_an += 1; }
+#endif
+      }
+    }
     // ---------------- end of round: next list sizes + refreshed price bounds
     if (clustered) {
 #ifdef MVP_EMD_PROFILE
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const long long tpd = __builtin_readcyclecounter();
-#endif
-      if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort, same_xcd)) {
-        aborted = true;
-        break;
-      }
-#ifdef MVP_EMD_PROFILE
-      const long long tpg2 = __builtin_readcyclecounter();
-      prof_drain += tpd - tp3;
-      prof_gather += tpg2 - tpd;
+      long long tpd = tp3, tpg2 = tp3;
 #endif
       Utot = 0;
       bool overflow = false;
       int cntw[WM], chgw[WM];  // (the same for every lane: kept in scalar registers, the arithmetic on them is SALU work)
+      if constexpr (!GM) {
+#ifdef MVP_EMD_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tpd = __builtin_readcyclecounter();
+#endif
+        if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort, same_xcd)) {
+          aborted = true;
+          break;
+        }
+#ifdef MVP_EMD_PROFILE
+        tpg2 = __builtin_readcyclecounter();
+        prof_drain += tpd - tp3;
+        prof_gather += tpg2 - tpd;
+#endif
 #pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        cntw[w] = w < W ? __builtin_amdgcn_readfirstlane((int)s_gout[2 * w]) : 0;
-        chgw[w] = w < W ? __builtin_amdgcn_readfirstlane((int)s_gout[2 * w + 1]) : 0;
-        Utot += cntw[w];
-        if (w != wg) overflow |= chgw[w] > kChgCap;
+        for (int w = 0; w < WM; ++w) {
+          cntw[w] = w < W ? __builtin_amdgcn_readfirstlane((int)s_gout[2 * w]) : 0;
+          chgw[w] = w < W ? __builtin_amdgcn_readfirstlane((int)s_gout[2 * w + 1]) : 0;
+          Utot += cntw[w];
+          if (w != wg) overflow |= chgw[w] > kChgCap;
+        }
+      } else {
+        // gathered-bid round: every member counted every member's next list itself
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          cntw[w] = w < W ? __builtin_amdgcn_readfirstlane(s_gc[gnxt][w]) : 0;
+          chgw[w] = 0;
+          Utot += cntw[w];
+        }
+        // the rounds end here (last round, or everybody assigned): what follows reads the other members' stores
+        if (it + 1 >= iters || Utot == 0) {
+          if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
+            aborted = true;
+            break;
+          }
+        }
       }
       if (__builtin_expect((it + 1 == it_stop && it + 1 < iters && Utot > 0) ||
                            (Utot <= u_stop && Utot > 0 && iters - (it + 1) >= kResMinRounds), 0)) {
@@ -834,6 +1153,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         }
         if (wg != 0) {
           if (t == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
+          ret_early = true;
           return 0;
         }
         int idx = t;
@@ -851,6 +1171,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
           idx -= cntw[w];
         }
         clustered = false;
+        if constexpr (GM) sw = 3;
         if (t == 0) s_nchg = 0;
         __syncthreads();
       } else {
@@ -865,7 +1186,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         for (int w = 0; w < WM; ++w) maxc = max(maxc, cntw[w]);
         const int even = (Utot + W - 1) / W;
         const int cap = (even + 15) / 16 * 16;
-        if (__builtin_expect(maxc > cap && it + 1 < iters, 0)) {
+        if (__builtin_expect(!gm && maxc > cap && it + 1 < iters, 0)) {
           const int base = Utot / W, rem = Utot % W;
           int exc[WM], dfc[WM], exoff = 0, dfoff = 0, my_exoff = 0, my_dfoff = 0;
 #pragma unroll
@@ -905,6 +1226,8 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
           }
           if (t == 0) s_cnt[nxt] = my_cnt - my_exc + my_dfc;
           __syncthreads();
+#pragma unroll
+          for (int w = 0; w < WM; ++w) cntw[w] = w < W ? base + (w < rem ? 1 : 0) : 0;   // (every list is at its even share now)
 #ifdef MVP_EMD_PROFILE
           n_rebal += 1;
 #endif
@@ -914,7 +1237,24 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
       const long long tpb = __builtin_readcyclecounter();
       prof_pg1 += tpb - tpg2;
 #endif
-      {
+      if constexpr (GM) {
+        // gathered-bid round: the cell of every object won this round is re-scanned (this member stored all of
+        // the round's prices itself and has drained them)
+        const int pw = (int)(eg & 1u);
+        const int nw = min(s_nwon[pw], kGCap);
+        const int idx = kEmdThreads - 1 - t;
+        if (idx < nw) {
+          const int cell = s_won[pw][idx];
+          const int e0 = c_start[cell], e1 = c_start[cell + 1];
+          float pv[16], pm = __builtin_inff();
+#pragma unroll
+          for (int k = 0; k < 16; ++k) pv[k] = e0 + k < e1 ? ld_price(e0 + k) : __builtin_inff();
+#pragma unroll
+          for (int k = 0; k < 16; ++k) pm = __builtin_fminf(pm, pv[k]);
+          for (int s2 = e0 + 16; s2 < e1; ++s2) pm = __builtin_fminf(pm, ld_price(s2));
+          c_lo[cell].w = pm;
+        }
+      } else {
         // Exact price bounds: every cell a winner of the cluster reported is re-scanned by every
         // member, from the prices in memory (all of this round's stores were drained before the
         // barrier opened).  The highest waves take the entries: they start bidding a little later,
@@ -953,6 +1293,31 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         }
       }
       if (t == 0) s_nchg = 0;
+      // ---- at most kGCap persons left (and never more again): the rounds go on with gathered bids.  Every member's
+      // view starts from the memory all of them agree on after the barrier above.
+      if constexpr (WB != 1) {
+        if (!GM && clustered && gm_ok && Utot <= kGCap && it + 1 < iters) {
+          sw = 2;
+          for (int s2 = t; s2 < n; s2 += kEmdThreads)
+            s_owner[s2] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b32(rs, ((unsigned)n + (unsigned)s2) * 16u + 8u, 0, 16);
+#pragma unroll
+          for (int w = 0; w < WM; ++w)
+            if (t == w) {
+              s_gc[0][w] = cntw[w];
+              s_gc[1][w] = 0;
+              s_gc[2][w] = 0;
+            }
+          gi = 0;
+          reinterpret_cast<unsigned *>(s_bkt)[t] = 0u;
+          reinterpret_cast<unsigned *>(s_bkt)[t + kEmdThreads] = 0u;
+          if (t == 0) {
+            s_nwon[0] = 0;
+            s_nwon[1] = 0;
+            s_pub = 0;
+          }
+          __syncthreads();
+        }
+      }
     } else {
       __syncthreads();
       Utot = s_cnt[nxt];
@@ -978,6 +1343,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     }
 #ifdef MVP_EMD_PROFILE
     const long long tp4 = __builtin_readcyclecounter();
+    prof_prev4 = tp4;
     cyc_bid += tp1 - tp0; cyc_sync1 += tp2 - tp1; cyc_assign += tp3 - tp2; cyc_sync2 += tp4 - tp3;
     if (t == 0 && it >= 100) {
       int mx = 0, sm = 0;
@@ -986,7 +1352,23 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     }
 #endif
     cur ^= 1;
+    if constexpr (GM) gi = gnxt;
+    if (sw) {
+      ++it;
+      return sw;
+    }
   }
+  return 0;
+  };
+  for (;;) {
+    int code;
+    if constexpr (WB != 1) code = gm_now ? rounds(std::true_type{}) : rounds(std::false_type{});
+    else code = rounds(std::false_type{});
+    if (code == 2) gm_now = true;
+    else if (code == 3) gm_now = false;
+    else break;
+  }
+  if (ret_early) return 0;
 #ifdef MVP_EMD_PROFILE
   if (clustered && !aborted) {  // cost of the bare all-gather
     const long long tg0 = __builtin_readcyclecounter();
@@ -1021,6 +1403,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         rs->utot = Utot;
         rs->nlists = clustered ? W : 1;
         rs->epoch = (int)epoch;
+        rs->epoch_g = (int)eg;
         rs->next_it = stop_it;
         atomicAdd(reinterpret_cast<unsigned long long *>(&st2[0]), (unsigned long long)n_rounds);
       }
@@ -1052,10 +1435,12 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     // A cluster wait ran into its bound (the members were not co-resident for
     // tens of seconds).  Fail loudly: NaN distances, -1 assignments.
     if (t == 0) stats[0] = -2;
+#ifndef MVP_EMD_STUCKDUMP
     for (int j = t; j < n; j += kEmdThreads) {
       dist[j] = __builtin_nanf("");
       ass[j] = -1;
     }
+#endif
     return 0;
   }
   if (t == 0) {
@@ -1083,6 +1468,9 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
                k ? ">=" : "<", s_slow[k][0], s_slow[k][1] / c, s_slow[k][2] / c, s_slow[k][3] / c, s_slow[k][4] / c, s_slow[k][5] / c, s_slow[k][6] / c, s_slow[k][7] / c);
       }
     if (cloud < 2)
+      printf("cloud %d wg %d gathered rounds (thread 0, %lld): contest check %lld, settle body %lld, drain %lld, to barrier end %lld cycles per round; flagged %.2f contested %.3f per round\n", cloud, wg, prof_an,
+             prof_a1 / (prof_an + 1), prof_a2 / (prof_an + 1), prof_a3 / (prof_an + 1), prof_a4 / (prof_an + 1), (double)(s_hist2[3] >> 32) / (double)(prof_an + 1), (double)(s_hist2[2] >> 32) / (double)(prof_an + 1));
+    if (cloud < 2 && false)
       printf("cloud %d wg %d Assign (thread 0, %lld samples): loads done at %lld cycles, eviction handled at %lld (sum over winning rounds / all), body done at %lld, phase %lld\n", cloud, wg, prof_an, prof_a1 / (prof_an + 1), prof_a2 / (prof_an + 1), prof_a3 / (prof_an + 1), prof_a4 / (prof_an + 1));
     if (cloud < 2)
       printf("cloud %d wg %d tail rounds %llu: bidders/round %.1f, busiest wave %llu cycles/round, mean wave %llu\n", cloud, wg, s_hist[15],
@@ -1092,8 +1480,8 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
              cloud, wg, s_hist[10], s_hist[12] / (s_hist[10] + 1), s_hist[8] / (s_hist[10] + 1), s_hist[9] / (s_hist[10] + 1), s_hist[11],
              s_hist[0], s_hist[1], s_hist[2], s_hist[3], s_hist[4], s_hist[5], s_hist[6], s_hist[7]);
     if (cloud < 2)
-      printf("cloud %d wg %d: rounds %lld bids %lld alarms %lld rebalances %lld | cycles bid %lld sync1 %lld assign %lld sync2 %lld \n",
-             cloud, wg, n_rounds, n_bids, n_alarm, n_rebal, cyc_bid, cyc_sync1, cyc_assign, cyc_sync2);
+      printf("cloud %d wg %d: rounds %lld bids %lld alarms %lld rebalances %lld | cycles bid %lld sync1 %lld assign %lld sync2 %lld gap %lld\n",
+             cloud, wg, n_rounds, n_bids, n_alarm, n_rebal, cyc_bid, cyc_sync1, cyc_assign, cyc_sync2, prof_gap);
     if (cloud < 2)
       printf("cloud %d wg %d: sync2 = store drain %lld + closing gather %lld + list bookkeeping %lld + bound fetch (rest)\n", cloud, wg, prof_drain, prof_gather, prof_pg1);
 #endif

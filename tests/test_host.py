@@ -24,10 +24,10 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.mvp_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MVP_ABI_VERSION (\d+)", header).group(1))
-    # per cloud: state 132 B/pt + bound broadcast buffers + cell offsets + barrier granules (3 x 256 B),
-    # hand-over record (80 B), statistics (16 B)
-    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * 132 + 8 * 2048 * 8 + 1732 * 4 + 768 + 80 + 16)
-    assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 768 + 80 + 16)
+    # per cloud: state 132 B/pt + bound broadcast buffers + cell offsets + barrier granules (3 x 256 B), the bid areas of
+    # the gathered-bid rounds (2 parities x (256 bids x 16 B + 8 member words)), hand-over record (96 B), statistics (16 B)
+    assert lib.mvp_emd_scratch_bytes(64, 16384) == 64 * (16384 * 132 + 8 * 2048 * 8 + 1732 * 4 + 768 + 2 * (2 * 256 + 8) * 8 + 96 + 16)
+    assert lib.mvp_emd_scratch_bytes(2, 32768) == 2 * (32768 * 132 + 8 * 2048 * 8 + 1732 * 4 + 768 + 2 * (2 * 256 + 8) * 8 + 96 + 16)
     # the knobs are process-wide: restore what is touched
     try:
         assert lib.mvp_emd_configure(-1, -1, 0, -1) == 0

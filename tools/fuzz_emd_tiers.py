@@ -1,6 +1,7 @@
 """Randomised consistency campaign of the EMD launch sequences: for random batch sizes, cloud sizes, settings and input
 distributions every `split` (0: the first kernel alone; 2: + lean kernel + widths dealt out by load at round 300;
-3: + LDS-resident tail for clouds of <= 4096 points in a launch of its own; 4, the default: fused into the lean launch) must give the same bits and the same statistics.
+3: + LDS-resident tail for clouds of <= 4096 points in a launch of its own; 4: fused into the lean launch;
+5, the default: + gathered-bid rounds once at most 256 persons of a cloud are unassigned) must give the same bits and the same statistics.
 
   python tools/fuzz_emd_tiers.py [cases] [seed]          (log of the round's campaign: profiles/r4_fuzz_emd.txt)
 
@@ -75,7 +76,7 @@ def run_case(case, dev="cuda:0"):
     try:
         d0, a0, s0, _ = run(x1, x2, eps, iters, 0, dev)
         ok, notes = True, []
-        for split in (2, 3, 4):
+        for split in (2, 3, 4, 5):
             d, a, s, rec = run(x1, x2, eps, iters, split, dev)
             ok = ok and torch.equal(d0, d) and torch.equal(a0, a) and torch.equal(s0, s)
             fl = rec["final_launch"]
