@@ -42,16 +42,11 @@ struct LeanShared {
   int s_alarm[2];
   unsigned s_gout[2 * kMaxCluster];
   int c_start[kMaxCells + 1];
-  union {
-    struct {   // plain rounds: this round's bids by list position
-      int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
-      float s_binc[kLeanBid];
-    };
-    // gathered-bid rounds: bids per (object % 4096), 16-bit counters (a count of one = nobody else bid there); kept at
-    // zero between rounds by their readers
-    unsigned short s_bkt[4096];
-  };
+  int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
+  float s_binc[kLeanBid];
   int s_own_chg[kLeanBid];
+  // (gathered-bid rounds: a list holds <= kGCap = kRecCap / 2 records, and the upper halves of these four 8 KB arrays
+  // hold the round's bids per object -- one 8-bit counter each, 4 x 4 KB for <= 16384 objects; emd_bid_count below)
   float4 s_rq[2][kRecCap];
   int4 s_ri[2][kRecCap];
   unsigned short w_list[kEmdWaves][4 * kRowListCap];
@@ -210,9 +205,16 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   auto &s_rq = sh.s_rq;
   auto &s_ri = sh.s_ri;
   static_assert(kLeanBid == kRecCap, "one LDS slot per list position");
+  // Bids per object of the round (gathered-bid rounds): byte counter of object o.  Exact -- a count of one means nobody
+  // else bid for the object; 256 bids on one object wrap to 0 and a carry into the neighbour: both read "not one" and
+  // take the (rare) path that looks at the bids themselves.  Kept at zero between rounds by their readers.
+  static_assert(2 * kGCap <= kRecCap && kGMaxN <= 4 * 4096 && sizeof(float4) * kRecCap == 8192, "the counters' home");
+  auto bid_count = [&](int o) -> unsigned char * {
+    return reinterpret_cast<unsigned char *>(&s_rq[0][0]) + 4096 + ((o >> 12) << 13) + (o & 4095);
+  };
   static_assert(sizeof(LeanShared) <= 160 * 1024, "one workgroup per CU: all of its LDS");
   auto &s_owner = sh.s_owner; auto &s_go = sh.s_go; auto &s_gj = sh.s_gj; auto &s_ginc = sh.s_ginc;
-  auto &s_bkt = sh.s_bkt; auto &s_won = sh.s_won; auto &s_nwon = sh.s_nwon; auto &s_gc = sh.s_gc; auto &s_pub = sh.s_pub;
+  auto &s_won = sh.s_won; auto &s_nwon = sh.s_nwon; auto &s_gc = sh.s_gc; auto &s_pub = sh.s_pub;
   u64 *const bid_area = emd_bid_area(tail, b, cloud);
 
   // ------------------------------------------------------------ resume
@@ -318,6 +320,14 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   const bool gm_ok = WB != 1 && n <= kGMaxN && (fast_ok & 2) != 0;   // (fast_ok: bit 0 = same-XCD stores, bit 1 = gathered-bid rounds)
   unsigned eg = (unsigned)resume->epoch_g;
   int goff = 0, gi = 0;
+#ifdef MVP_EMD_GMTIME
+  // phase clock of the gathered-bid rounds as wave 0 of member 0 sees them (cycles, summed over the rounds; tools/emd_gm_times.py)
+  long long gmt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long gm_prev = 0;
+#define GMT(i) { const long long now_ = __builtin_readcyclecounter(); gmt[i] += now_ - gm_prev; gm_prev = now_; }
+#else
+#define GMT(i)
+#endif
   int stop_cnt = -1;   // >= 0: the loop ended before round stop_it with this many entries in this member's next list
   int stop_it = it_stop;
   bool stop_for_res = false;   // ... because at most u_stop persons are left (not because round it_stop is next)
@@ -365,6 +375,11 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     if constexpr (WB != 1) {
       if constexpr (GM) {
         ++eg;
+#ifdef MVP_EMD_GMTIME
+        if (gm_prev) GMT(0) else gm_prev = __builtin_readcyclecounter();   // [0] end of the last round's bookkeeping -> this round's start
+        gmt[15] += 1;
+        GMT(14) GMT(14)   // [14] = two stamps back to back (calibration)
+#endif
         goff = 0;
         {
           const int cv = s_gc[gcur][lane & (kMaxCluster - 1)];   // (one LDS read; the sum is scalar work)
@@ -705,14 +720,14 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         if constexpr (GM) {
           // The bid as a granule at this bidder's position of the cloud-wide order: two 8-byte words, each with a
           // tag of the round -- {increment | object 14 | bidder 14 | tag 4}, {the object's new price | second-best
-          // slot + 1 (next round's hint) 15 | its cell 11 | tag 6} -- so that every member can settle it without
+          // slot + 1 (next round's hint) 15 | its cell 11 | the bidder's member 3 | tag 3} -- so that every member can settle it without
           // reading anything else.  (A position below the cloud's bidder count is rewritten every round of its
           // parity: the tags only have to tell a round from the one two before.)
           const float np = st.bp + inc;
           const u64 g0 = ((u64)__float_as_uint(inc) << 32) | ((u64)(unsigned)st.bk << 18) | ((u64)(unsigned)j << 4) |
                          (u64)(eg % 15u + 1u);
           const u64 g1 = ((u64)__float_as_uint(np) << 32) | ((u64)(unsigned)(st.b2k + 1) << 17) |
-                         ((u64)(unsigned)(st.bc & 0x7FF) << 6) | (u64)(eg % 63u + 1u);
+                         ((u64)(unsigned)(st.bc & 0x7FF) << 6) | ((u64)(unsigned)wg << 3) | (u64)(eg % 7u + 1u);
           u64 *slot = bid_area + (size_t)(eg & 1u) * kGStride + 2 * (size_t)(goff + u);
           if (same_xcd) {
             __hip_atomic_store(slot, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -900,8 +915,9 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
       // every winner's new price, the same value) or what a heartbeat vouches for (hint records, written a round or
       // more before they are read).  emd_cuda.cu:181-215 (GetMax + Assign).
       if constexpr (WB != 1) {
+        GMT(1)   // [1] own bids done
         u64 *ba = bid_area + (size_t)(eg & 1u) * kGStride;
-        const unsigned T4 = eg % 15u + 1u, T6 = eg % 63u + 1u;
+        const unsigned T4 = eg % 15u + 1u, T6 = eg % 7u + 1u;
         u64 g0 = 0ull, g1 = 0ull;
         if (wave * kWave < Utot) {   // the waves of threads p < Utot: thread p takes bid p
           // (1) spin on the members' words of the round, (2) read the bids (normally there at once)
@@ -933,13 +949,14 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
             }
             __builtin_amdgcn_s_sleep(1);
           }
+          GMT(2)   // [2] every member's word raised
           const bool isb = t < Utot;
           bool ok = !isb;
           for (unsigned spins = 0;; ++spins) {
             if (isb && !ok) {
               g0 = __hip_atomic_load(ba + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               g1 = __hip_atomic_load(ba + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              ok = (unsigned)(g0 & 15ull) == T4 && (unsigned)(g1 & 63ull) == T6;
+              ok = (unsigned)(g0 & 15ull) == T4 && (unsigned)(g1 & 7ull) == T6;
             }
             if (__all(ok)) break;
             if (spins >= kSpinLimit) {
@@ -952,8 +969,13 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        int go = 0, gj = 0, gb2 = -1, gcell = 0x7FF;
+        GMT(3)   // [3] bids read
+        // Everything of a bid's settlement that does not depend on the other bids is done here, in the shadow of the
+        // wait for the round's last bid: who placed it, who owns the object now (the map only changes after the
+        // barrier), where an evicted owner would go -- and, if to this member, the load of its record.
+        int go = 0, gj = 0, gb2 = -1, gcell = 0x7FF, gm_m = 0, prev = 0xFFFF;
         float ginc = 0.f, gnp = 0.f;
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
         if (t < Utot) {
           ginc = __uint_as_float((unsigned)(g0 >> 32));
           go = (int)(g0 >> 18) & 0x3FFF;
@@ -961,12 +983,25 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
           gnp = __uint_as_float((unsigned)(g1 >> 32));
           gb2 = ((int)(g1 >> 17) & 0x7FFF) - 1;
           gcell = (int)(g1 >> 6) & 0x7FF;
+          gm_m = (int)(g1 >> 3) & 7;
           s_go[t] = (unsigned short)go;
           s_gj[t] = (unsigned short)gj;
           s_ginc[t] = ginc;
-          atomicAdd(reinterpret_cast<unsigned *>(s_bkt) + ((go & 4095) >> 1), 1u << ((go & 1) * 16));
+          {
+            unsigned char *bc = bid_count(go);
+            atomicAdd(reinterpret_cast<unsigned *>(bc - (go & 3)), 1u << ((go & 3) * 8));
+          }
+          if (!last) {
+            prev = s_owner[go];
+            if (prev != 0xFFFF && t % W == wg) {
+              pa = ld_person(prev, 0);
+              pb = ld_person(prev, 1);
+            }
+          }
         }
+        GMT(4)   // [4] decoded, owner looked up
         lds_barrier();
+        GMT(5)   // [5] barrier after the poll
         if (s_abort) {
           aborted = true;
           break;
@@ -974,12 +1009,10 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 #ifdef MVP_EMD_PROFILE
         tp2 = __builtin_readcyclecounter();
 #endif
-        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
-        int rec_pos = -1, rec_j = 0;
-        // Bids whose bucket holds more than one bid (a few per round: ~100 bids in 1024 buckets): the wave looks at
-        // one of them at a time -- does any OTHER bid name the same object? (4 bids per lane) -- and only a real
-        // contest (tens per call) is settled by its lane alone: the maximal increment bid on the object, then the
-        // highest bidder inside its 1e-6 band (emd_cuda.cu:181-194).
+        int rec_pos = -1;
+        // Bids for an object that got more than one bid (~0.3 per round at the headline): the wave settles one of
+        // them at a time -- the maximal increment bid on the object, then the highest bidder inside its 1e-6 band
+        // (emd_cuda.cu:181-194), over all of the round's bids, four per lane.
         int contested = 0;   // 1: another bid wins my object
 #ifdef MVP_EMD_PROFILE
         const long long tq0 = __builtin_readcyclecounter();
@@ -987,8 +1020,9 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         if (wave * kWave < Utot && !last) {
           bool flagged = false;
           if (t < Utot) {
-            flagged = s_bkt[go & 4095] != 1;
-            s_bkt[go & 4095] = 0;   // (a bid that shares the bucket and reads after this sees 0: flagged as well)
+            unsigned char *bc = bid_count(go);
+            flagged = *bc != 1;
+            *bc = 0;   // (a bid for the same object that reads after this sees 0: flagged as well)
           }
           unsigned long long fm = __ballot(flagged);
 #ifdef MVP_EMD_PROFILE
@@ -1019,18 +1053,11 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         const long long tq1 = __builtin_readcyclecounter();
         if (contested) atomicAdd(&s_hist2[2], 1ull << 32);
 #endif
+        GMT(6)   // [6] contest check
         if (t < Utot) {
-          // the member that placed bid t (it does the stores only one member needs to do)
-          int m = 0, acc = 0;
-#pragma unroll
-          for (int w = 0; w + 1 < WM; ++w) {
-            acc += s_gc[gcur][w];
-            if (w + 1 < W && t >= acc) m = w + 1;
-          }
-          const bool win = !contested;
-          if (win) {
+          const int m = gm_m;   // the member that placed bid t (it does the stores only one member needs to do)
+          if (!contested) {
             if (!last) {
-              const int prev = s_owner[go];
               s_owner[go] = (unsigned short)gj;
               st_f32(&sc.obj[go].w, gnp);   // (every member: its own next searches read its own store)
               if (prev != 0xFFFF) {
@@ -1038,12 +1065,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
                 // even without any exchange
                 const int d = t % W;
                 const int pos = atomicAdd(&s_gc[gnxt][d], 1);
-                if (d == wg) {
-                  pa = ld_person(prev, 0);
-                  pb = ld_person(prev, 1);
-                  rec_pos = pos;
-                  rec_j = prev;
-                }
+                if (d == wg) rec_pos = pos;
                 if (m == wg) st_i32(&ass[prev], -1);
               }
               if (gcell < ncell) s_won[eg & 1u][atomicAdd(&s_nwon[eg & 1u], 1)] = (unsigned short)gcell;
@@ -1062,9 +1084,11 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
             }
           }
         }
-        // (what the next round starts from; nobody reads these before the barrier below)
-        if (t < WM) s_gc[gzero][t] = 0;
-        if (t == 0) {
+        GMT(7)   // [7] outcome applied (owner map, list positions, stores issued)
+        // (what the next round starts from; nobody reads these before the barrier below.  By the last wave: it has
+        // no bid to settle)
+        if (t >= kEmdThreads - WM) s_gc[gzero][t - (kEmdThreads - WM)] = 0;
+        if (t == kEmdThreads - 1) {
           s_nwon[(eg + 1u) & 1u] = 0;
           s_next = kEmdWaves;
           s_pub = 0;
@@ -1078,11 +1102,13 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 #ifdef MVP_EMD_PROFILE
         const long long tq3 = __builtin_readcyclecounter();
 #endif
+        GMT(8)   // [8] drained
         if (rec_pos >= 0) {
           s_rq[nxt][rec_pos] = pa;
-          s_ri[nxt][rec_pos] = make_int4(rec_j, __float_as_int(pb.y), __float_as_int(pb.z), 0);
+          s_ri[nxt][rec_pos] = make_int4(prev, __float_as_int(pb.y), __float_as_int(pb.z), 0);
         }
         lds_barrier();
+        GMT(9)   // [9] closing barrier
         if (t == 0) s_cnt[nxt] = s_gc[gnxt][wg];
 #ifdef MVP_EMD_PROFILE
         tp3 = __builtin_readcyclecounter();
@@ -1121,11 +1147,14 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
         }
       } else {
         // gathered-bid round: every member counted every member's next list itself
+        {
+          const int cv = s_gc[gnxt][lane & (kMaxCluster - 1)];   // (one LDS read; the rest is scalar work)
 #pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          cntw[w] = w < W ? __builtin_amdgcn_readfirstlane(s_gc[gnxt][w]) : 0;
-          chgw[w] = 0;
-          Utot += cntw[w];
+          for (int w = 0; w < WM; ++w) {
+            cntw[w] = w < W ? __builtin_amdgcn_readlane(cv, w) : 0;
+            chgw[w] = 0;
+            Utot += cntw[w];
+          }
         }
         // the rounds end here (last round, or everybody assigned): what follows reads the other members' stores
         if (it + 1 >= iters || Utot == 0) {
@@ -1308,8 +1337,9 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
               s_gc[2][w] = 0;
             }
           gi = 0;
-          reinterpret_cast<unsigned *>(s_bkt)[t] = 0u;
-          reinterpret_cast<unsigned *>(s_bkt)[t + kEmdThreads] = 0u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)   // (the four counter areas: 1024 words each)
+            reinterpret_cast<unsigned *>(&s_rq[0][0])[1024 + 2048 * q + t] = 0u;
           if (t == 0) {
             s_nwon[0] = 0;
             s_nwon[1] = 0;
@@ -1351,6 +1381,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
       s_hist[13] += mx; s_hist[14] += sm / kEmdWaves; s_hist[15] += 1; prof_u += U;
     }
 #endif
+    if constexpr (GM) { GMT(10) }   // [10] counts, stop checks, price bounds
     cur ^= 1;
     if constexpr (GM) gi = gnxt;
     if (sw) {
@@ -1443,6 +1474,12 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 #endif
     return 0;
   }
+#ifdef MVP_EMD_GMTIME
+  if (t == 0 && wg == 0) {
+    for (int k = 0; k < 16; ++k) sc.chg[(size_t)kMaxCluster * kChgCap - 128 + k] = (u64)gmt[k];
+    sc.chg[(size_t)kMaxCluster * kChgCap - 128 + 16] = (u64)W;
+  }
+#endif
   if (t == 0) {
     // rounds: added to the first kernel's count; an internal error drives the sum far below zero
     if (wg == 0) {
