@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 11
+#define MVP_ABI_VERSION 12
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -115,20 +115,25 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * kernel of the same shape (csrc/emd_lean.hip) that takes a cloud over for the
  * rounds in which every workgroup has fewer bidders than four per wave (from
  * round ~100 on at 16384 points); it exits at once for clouds the first kernel
- * finished.  With split = 2 (the default), 33..64 clouds of at least 4096 points on
+ * finished.  With split >= 2, 33..64 clouds of at least 4096 points on
  * four workgroups each, that second kernel stops before round 300 and a third launch runs the
  * rest with the workgroups dealt out again: the clouds with the most persons
  * still unassigned -- the ones whose rounds cost most -- get 8, the lightest 2
  * (64 uniform clouds: 8,5,4,4,3,3,3,2 over the eight clouds of an XCD; equally
  * loaded clouds keep 4 each)
- * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  With split = 4 (the default; 3: in a launch of its own)
+ * (csrc/emd_lean.hip, emd_lean_tiers_kernel).  With split >= 4 (3: in a launch of its own)
  * clouds of at most 4096 points leave the clustered kernels as soon as at most
  * `resident_cap` (16) persons are unassigned -- round ~300 of 3000 at 1024
  * points, 500-850 at 2048, 900-1700 at 4096 -- and member 0 of the cloud's cluster
  * (csrc/emd_resident.h, one workgroup per cloud) runs the remaining rounds
  * with the whole auction state in that workgroup's LDS: no global memory access
- * inside a round.  Which workgroups serve a cloud, and in which launch, never
- * changes a bit of the result.
+ * inside a round.  With split = 5 (the default) the clustered kernels switch to
+ * gathered-bid rounds once at most 256 persons of a cloud (of <= 16384 points)
+ * are unassigned: a bid is published as a tagged 16-byte record, every workgroup
+ * of the cluster settles every bid on its own view of the cloud (owner map in
+ * LDS) and a round has one cluster-wide wait instead of a bid atomic and two
+ * all-gathers (csrc/emd_lean.hip).  Which workgroups serve a cloud, in which
+ * launch and in which kind of round, never changes a bit of the result.
  * If a cluster wait is abandoned (members not co-resident for tens of seconds;
  * never seen) dist is filled with NaN, assignment with -1 and the statistics
  * word `rounds` is negative: the host wrapper checks for NaN lazily, and
@@ -142,7 +147,8 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  * negative argument leaves that knob unchanged.
  *   cluster     0 = automatic, or 1|2|4|8: cap of the workgroups per cloud
  *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
- *   split       4 (default): as 2, and clouds of <= 4096 points finish LDS-resident
+ *   split       5 (default): as 4, with gathered-bid rounds once <= 256 persons are unassigned;
+ *               4: as 2, and clouds of <= 4096 points finish LDS-resident
  *               (csrc/emd_resident.h) on member 0 of their cluster, inside the second kernel's launch;
  *               3: the same in a launch of its own (every cloud waits for the last to get there); 2: the tail rounds run in the second kernel, from
  *               round 300 on with cluster widths by load (8 .. 2 workgroups);

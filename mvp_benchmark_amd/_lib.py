@@ -55,7 +55,7 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 11  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 12  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
 EMD_DEFAULT_SPLIT = 5
@@ -167,13 +167,15 @@ def emd_records(scratch, nbytes, b):
       next_round            0 once the cloud is finished
       unassigned            persons unassigned at the LAST hand-over
       final_width           cluster width of the launch that finished the cloud (0: the first kernel did)
-      final_launch          1 = the launch after the first kernel, 2 = the tiered one, 3 = LDS-resident (in its own launch or fused into launch 1)"""
+      final_launch          1 = the launch after the first kernel, 2 = the tiered one, 3 = LDS-resident (in its own launch or fused into launch 1)
+      gathered_rounds       rounds that ran with gathered bids (csrc/emd_lean.hip; as of the last hand-over / the end of the clustered rounds)"""
     import torch
     rb = EMD_RECORD_INTS * 4
     stats = scratch[nbytes - b * 16:].view(torch.int64).view(b, 2).cpu().numpy()
     rec = scratch[nbytes - b * 16 - b * rb: nbytes - b * 16].view(torch.int32).view(b, EMD_RECORD_INTS).cpu().numpy()
     return {"rounds": stats[:, 0], "bids": stats[:, 1], "next_round": rec[:, 0], "unassigned": rec[:, 1],
-            "first_handover": rec[:, 18], "final_width": rec[:, 19] & 15, "final_launch": rec[:, 19] >> 4}
+            "first_handover": rec[:, 18], "final_width": rec[:, 19] & 15, "final_launch": rec[:, 19] >> 4,
+            "gathered_rounds": rec[:, 20]}
 
 
 def fps_cluster_scratch_bytes(b):

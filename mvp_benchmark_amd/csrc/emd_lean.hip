@@ -328,8 +328,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 #else
 #define GMT(i)
 #endif
-  int stop_cnt = -1;   // >= 0: the loop ended before round stop_it with this many entries in this member's next list
-  int stop_it = it_stop;
+  int stop_cnt = -1;   // >= 0: the loop ended before round it + 1 with this many entries in this member's next list
   bool stop_for_res = false;   // ... because at most u_stop persons are left (not because round it_stop is next)
 #ifdef MVP_EMD_PROFILE
   long long prof_gap = 0, prof_prev4 = 0;
@@ -1168,7 +1167,6 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
                            (Utot <= u_stop && Utot > 0 && iters - (it + 1) >= kResMinRounds), 0)) {
         // ---- this launch's last round: the lists are left for the next launch below the loop
         stop_cnt = cntw[wg];
-        stop_it = it + 1;
         stop_for_res = !(it + 1 == it_stop);
         break;
       }
@@ -1354,7 +1352,6 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
       if (__builtin_expect((it + 1 == it_stop && it + 1 < iters && Utot > 0) ||
                            (Utot <= u_stop && Utot > 0 && iters - (it + 1) >= kResMinRounds), 0)) {   // (member 0 alone)
         stop_cnt = Utot;
-        stop_it = it + 1;
         stop_for_res = !(it + 1 == it_stop);
         break;
       }
@@ -1423,6 +1420,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     int *ul2 = emd_carve(scratch + (size_t)cloud2 * emd_scratch_per_cloud(n), n).ulist + (size_t)wg * 2 * n;
     const int nx = cur ^ 1;
     if (t < stop_cnt) ul2[t] = s_ri[nx][t].x;
+    const int stop_it = it + 1;   // (the loop was left by `break`: `it` is the last round that ran)
     if (t == 0) {
       atomicAdd(reinterpret_cast<unsigned long long *>(&st2[1]), (unsigned long long)n_bids);
       if (s_err) rs->err = 1;
@@ -1485,6 +1483,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     if (wg == 0) {
       atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)n_rounds);
       resume->next_it = 0;   // finished: nothing for a later launch
+      resume->epoch_g = (int)eg;   // (statistics: gathered-bid rounds of the call)
       resume->last_width = W + 16 * which;   // (which: 1 = the launch after the first kernel, 2 = the tiered launch)
     }
     if (s_err) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)(-(1ll << 40)));

@@ -79,7 +79,8 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
   char *tail = scratch + (size_t)b * emd_scratch_per_cloud(n);
   EmdHandover *resume = emd_handover(tail, b, cloud);
   long long *stats = emd_stats(tail, b, cloud);
-  const int it0 = resume->next_it;
+  // (an L1-bypassing load: fused into the lean launch, the record was written a moment ago by this very workgroup)
+  const int it0 = __hip_atomic_load(&resume->next_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (it0 == 0) return;   // finished in an earlier launch (uniform over the workgroup)
   const EmdScratch sc = emd_carve(scratch + (size_t)cloud * emd_scratch_per_cloud(n), n);
   dist += (size_t)cloud * n;

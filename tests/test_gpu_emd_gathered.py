@@ -1,0 +1,111 @@
+"""GPU parity tests of the gathered-bid rounds of the EMD auction (csrc/emd_lean.hip, mvp_emd_configure(split = 5),
+the default): once at most 256 persons of a cloud are unassigned the bids of a round travel as tagged records, every
+workgroup of the cloud's cluster settles every bid itself and the round has one cluster-wide wait.  Everything is
+compared with the exhaustive CPU oracle bit for bit (assignment, distances, rounds, bids) through the C ABI, and with
+the plain rounds (split = 2) on full batches (utils/metrics/EMD/emd_cuda.cu:95-226)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rand_clouds
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.tensor(a, device=DEV)
+
+
+@pytest.fixture
+def knobs():
+    """mvp_emd_configure for one test; the defaults come back afterwards."""
+    from mvp_benchmark_amd import _lib
+    yield _lib.emd_configure
+    _lib.emd_configure(cluster=0, same_xcd=1, split=_lib.EMD_DEFAULT_SPLIT, resident_cap=16)
+
+
+def _run(x1, x2, eps, iters):
+    from mvp_benchmark_amd import _lib
+    b, n = x1.shape[:2]
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    dist = torch.zeros(b, n, device=DEV)
+    ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_emd_forward", DEV, b, n, x1 if torch.is_tensor(x1) else dev(x1), x2 if torch.is_tensor(x2) else dev(x2),
+              dist, ass, eps, iters, scratch, nbytes)
+    torch.cuda.synchronize()
+    return dist.cpu().numpy(), ass.cpu().numpy(), _lib.emd_records(scratch, nbytes, b)
+
+
+def _check(oracle, x1, x2, eps, iters):
+    d, a, rec = _run(x1, x2, eps, iters)
+    od, oa, ost = oracle.emd_forward(x1, x2, eps, iters, return_stats=True)
+    np.testing.assert_array_equal(a, oa)
+    np.testing.assert_array_equal(d, od)
+    np.testing.assert_array_equal(rec["rounds"], ost[:, 0])
+    np.testing.assert_array_equal(rec["bids"], ost[:, 1])
+    assert (rec["next_round"] == 0).all()
+    return rec
+
+
+@pytest.mark.parametrize("b,n,width", [(2, 8192, 8), (3, 4096, 4), (2, 2048, 2), (1, 16384, 8), (5, 3072, 0)])
+def test_gathered_rounds_match_oracle(oracle, knobs, b, n, width):
+    """Eval setting (eps 0.004, 3000 rounds) on clusters of 8 / 4 / 2 workgroups: the rounds between the hand-over
+    from the first kernel and the end (or the LDS-resident tail of the small clouds) run with gathered bids."""
+    knobs(cluster=width, split=5)
+    x1, x2 = rand_clouds(100 + n // 1024 + width, b, n, 3), rand_clouds(200 + n // 1024 + width, b, n, 3)
+    rec = _check(oracle, x1, x2, 0.004, 3000)
+    assert (rec["gathered_rounds"] > 0).all(), rec["gathered_rounds"]
+
+
+def test_gathered_rounds_agent_scope_stores(oracle, knobs):
+    """same_xcd = 0: the bid records, member words and state stores of the gathered-bid rounds are written through
+    (the path clusters that span XCDs take)."""
+    knobs(cluster=8, same_xcd=0, split=5)
+    x1, x2 = rand_clouds(77, 2, 4096, 3), rand_clouds(78, 2, 4096, 3)
+    rec = _check(oracle, x1, x2, 0.004, 3000)
+    assert (rec["gathered_rounds"] > 0).all()
+
+
+@pytest.mark.parametrize("iters", [130, 260, 401])
+def test_gathered_forced_last_round(oracle, knobs, iters):
+    """The auction's last round (every bidder takes its object, emd_cuda.cu:196-215) falls into the gathered-bid
+    rounds: short auctions on 8192 points."""
+    knobs(split=5)
+    x1, x2 = rand_clouds(5 + iters, 2, 8192, 3), rand_clouds(6 + iters, 2, 8192, 3)
+    rec = _check(oracle, x1, x2, 0.004, iters)
+    if iters > 200:
+        assert (rec["gathered_rounds"] > 0).all(), rec["gathered_rounds"]
+
+
+def test_gathered_rounds_contested_objects(oracle, knobs):
+    """Duplicated points: many bidders hold equal values, bid for the same object with equal increments (the 1e-6
+    band of GetMax, emd_cuda.cu:181-194) -- the contests the gathered-bid rounds settle from the round's records."""
+    knobs(split=5)
+    rng = np.random.default_rng(11)
+    b, n = 3, 2048
+    x1 = np.repeat(rng.random((b, n // 4, 3), dtype=np.float32), 4, axis=1)
+    x2 = np.repeat(rng.random((b, n // 2, 3), dtype=np.float32), 2, axis=1)
+    for eps, iters in ((0.002, 3000), (0.008, 700)):
+        rec = _check(oracle, x1, x2, eps, iters)
+        assert (rec["gathered_rounds"] > 0).all()
+
+
+@pytest.mark.parametrize("n", [16384, 4096])
+def test_gathered_full_batch_equals_plain_rounds(knobs, n):
+    """64 clouds (the headline batch at 16384 points; 4096 points: lean launch, tiered launch and LDS-resident tail
+    all take part): the default equals split = 2 -- bid atomics and two all-gathers per round -- in every bit,
+    round and bid, and every cloud ran gathered-bid rounds."""
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.rand(64, n, 3, generator=g).to(DEV)
+    x2 = torch.rand(64, n, 3, generator=g).to(DEV)
+    out = {}
+    for split in (2, 5):
+        knobs(split=split)
+        out[split] = _run(x1, x2, 0.004, 3000)
+    np.testing.assert_array_equal(out[2][0], out[5][0])
+    np.testing.assert_array_equal(out[2][1], out[5][1])
+    np.testing.assert_array_equal(out[2][2]["rounds"], out[5][2]["rounds"])
+    np.testing.assert_array_equal(out[2][2]["bids"], out[5][2]["bids"])
+    assert (out[5][2]["gathered_rounds"] > 0).all() and (out[2][2]["gathered_rounds"] == 0).all()

@@ -51,11 +51,11 @@ def _check(oracle, x1, x2, eps, iters, expect_resident=None):
     return rec
 
 
-@pytest.mark.parametrize("split", [4, 3])
+@pytest.mark.parametrize("split", [5, 4, 3])
 @pytest.mark.parametrize("b,n", [(3, 1024), (3, 2048), (2, 3072), (3, 4096)])
 def test_resident_tail_matches_oracle(oracle, knobs, b, n, split):
     """Eval setting (eps 0.004, 3000 rounds) at every cloud size the resident rounds cover (two
-    instantiations: <= 2048 and <= 4096 points), fused into the lean launch (split 4, the default: member 0 of
+    instantiations: <= 2048 and <= 4096 points), fused into the lean launch (split 4; 5, the default: with gathered-bid rounds before; member 0 of
     the cloud's cluster goes on at once) and in a launch of their own (split 3)."""
     knobs(split=split)
     x1, x2 = rand_clouds(1000 + n, b, n, 3), rand_clouds(2000 + n, b, n, 3)
@@ -75,7 +75,7 @@ def test_resident_cap_changes_no_bit(oracle, knobs, cap):
         assert (rec["final_launch"] == 3).all()
 
 
-@pytest.mark.parametrize("split", [4, 3])
+@pytest.mark.parametrize("split", [5, 4, 3])
 @pytest.mark.parametrize("width", [1, 2, 4, 8])
 def test_resident_after_every_cluster_width(oracle, knobs, width, split):
     """The resident rounds pick up whatever lists the clustered rounds left: 1, 2, 4 or 8 of them."""
