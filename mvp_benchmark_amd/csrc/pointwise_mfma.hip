@@ -1,4 +1,5 @@
-// Per-point / per-edge linear maps (1x1 convolutions) on the matrix cores.
+// Per-point / per-edge linear maps (1x1 convolutions) on the matrix cores: forward,
+// data gradient and weight gradient.
 //
 // the grouped-feature MLPs of the completion networks
 // (completion/model_utils.py:26-55 EF_expansion, completion/models/vrcnet.py:21-57
@@ -6,51 +7,198 @@
 // 1x1 convolutions, i.e. per cloud  Y (Cout x L) = W (Cout x Cin) X (Cin x L) with L
 // = points (x neighbours) contiguous.  The reference runs them as cuDNN
 // convolutions followed by separate bias / ReLU / residual / max-over-neighbours
-// kernels.  Here: one LDS-tiled GEMM on v_mfma_f32_32x32x2_f32 -- float32 in,
-// float32 accumulate, bit-for-bit a k-ordered fmaf chain (MI355X_MICROARCH.md:
-// gfx950 has no xf32/TF32; the f32 MFMA peak is 157 TFLOP/s, the same as the
-// packed vector peak, but reachable from one wave per SIMD) -- with the epilogue
-// fused: + bias, ReLU, + residual, and max over groups of `group` consecutive
-// columns (the neighbours of one point), so that the (B, C, P, S) tensor of a
-// set-abstraction stage is never written.
+// kernels.  Here: LDS-tiled GEMMs on v_mfma_f32_32x32x2_f32 -- float32 in, float32
+// accumulate, a k-ordered fmaf chain, no reduced precision (MI355X_MICROARCH.md:
+// gfx950 has no xf32 / TF32; the f32 MFMA peak is 157 TFLOP/s) -- with the
+// epilogue fused (+ bias, ReLU, + residual, max over groups of consecutive columns)
+// and ReLU' applied to the incoming gradient on load in both backward passes.
 //
-// Tiling (256 threads = 4 waves in a 2 x 2 grid): block tile BM x 128 columns,
-// BM = 128 (wave: 2 x 2 MFMA blocks of 32 x 32, 64 accumulator VGPRs) or 64
-// (wave: 1 x 2), K in slabs of 16 through double-buffered LDS (33 KiB: four
-// workgroups per CU hide the global latency; the slab for step i+1 is fetched
-// into registers while step i computes).  A fragments are read from an
-// [k][m]-major image (lanes = consecutive rows), B fragments from [k][n]
-// (lanes = consecutive columns): conflict-free ds_read_b32, one per MFMA operand
-// -- the f32 MFMA issues every 64 cycles, LDS bandwidth is not a concern.
-// The weight may be given (Cout, Cin) row-major (forward) or as its transpose
-// (the data gradient multiplies by W^T: pass the forward weight and w_kmajor = 1).
+// One compute core, three passes.  An operand tile is staged through LDS in one of
+// two images, chosen by how the operand lies in memory, so that every global read
+// and every LDS write is a 16-byte access whatever the pass:
+//   * "x-contiguous" ([k][x] in memory: the activations X / gY per cloud, and the
+//     forward weight read as W^T by the data gradient): LDS image [k][x], an MFMA
+//     fragment is one ds_read_b32 per instruction (lanes = 32 consecutive x);
+//   * "k-contiguous" ([x][k] in memory: the forward weight, and both operands of the
+//     weight gradient, whose reduction dimension is the position): LDS image
+//     [x][k + 4], a fragment is one ds_read_b128 per FOUR instructions.
+// The k-order inside a group of 8 is permuted the same way for both operands
+// (instruction j of a group takes k = j from lanes 0..31 and k = 4 + j from lanes
+// 32..63), which is what lets the 16-byte LDS read feed four MFMAs.
+// Block = 256 threads = 2 x 2 waves, wave tile 32 TM x 32 TN (TM, TN in {1, 2}), K in
+// slabs of BK through double-buffered LDS; the next slab travels global -> registers
+// while the current one computes; all fragments of a k-group are read before its
+// MFMAs.  Workgroups are numbered so that the ones that share an activation tile run
+// back to back on ONE XCD (its L2 serves the re-reads).
 #include "common.h"
 
 namespace mvp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef MVP_MM_BK
-#define MVP_MM_BK 16
-#endif
-constexpr int kMmBN = 128, kMmBK = MVP_MM_BK, kMmThreads = 256;
+constexpr int kMmThreads = 256;
+constexpr int kXC = 0, kKC = 1;    // operand images (above)
+constexpr int kImgPad = 4;         // floats; keeps rows 16-byte aligned and shifts their banks
 
-template <int BM, bool KMAJOR>
+template <int BX, int BK, int MODE>
+struct PwImg {
+  static constexpr int ld = (MODE == kXC ? BX : BK) + kImgPad;
+  static constexpr int floats = (MODE == kXC ? BK : BX) * ld;
+  static constexpr int vecs = BX * BK / 4 / kMmThreads;     // float4 per thread and slab
+  static_assert(BX * BK / 4 % kMmThreads == 0, "slab must divide over the block");
+};
+template <int V>
+struct PwRegs {
+  float4 v[V];
+};
+
+// One slab of an operand: global -> registers.  g: the operand's matrix (row stride ld floats);
+//   kXC: element (k, x) at g[(k0 + k) ld + x0 + x], inside if k0 + k < K and x0 + x < X  (X, ld % 4 == 0)
+//   kKC: element (x, k) at g[(x0 + x) ld + k0 + k], inside if x0 + x < X and k0 + k < K
+// vec: 16-byte loads are legal (alignment of base and row stride); a float4 along k may straddle K.
+// MASK: the mask's values travel in registers of their own and are applied by pw_stash -- a select
+// here would make the wave wait for both loads before it starts computing the current slab.
+template <int BX, int BK, int MODE, bool MASK>
+__device__ __forceinline__ void pw_fetch(PwRegs<BX * BK / 4 / kMmThreads> &r,
+                                         PwRegs<MASK ? BX * BK / 4 / kMmThreads : 1> &rm,
+                                         const float *__restrict__ g, const float *__restrict__ mask, size_t ld, int x0,
+                                         int X, int k0, int K, bool vec, int t) {
+  constexpr int V = PwImg<BX, BK, MODE>::vecs;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int q = t + i * kMmThreads;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (MODE == kXC) {
+      const int k = q / (BX / 4), x = (q % (BX / 4)) * 4;
+      if (k0 + k < K && x0 + x < X) {
+        const size_t o = (size_t)(k0 + k) * ld + x0 + x;
+        v = *reinterpret_cast<const float4 *>(g + o);
+        if constexpr (MASK)
+          if (mask) mk = *reinterpret_cast<const float4 *>(mask + o);
+      }
+    } else {
+      const int x = q / (BK / 4), k = (q % (BK / 4)) * 4;
+      if (x0 + x < X && k0 + k < K) {
+        const size_t o = (size_t)(x0 + x) * ld + k0 + k;
+        if (vec && k0 + k + 3 < K) {
+          v = *reinterpret_cast<const float4 *>(g + o);
+          if constexpr (MASK)
+            if (mask) mk = *reinterpret_cast<const float4 *>(mask + o);
+        } else {                               // unaligned rows (cin % 4 != 0) or the last, partial group of k
+          const float *p = g + o;
+          v.x = p[0];
+          if (k0 + k + 1 < K) v.y = p[1];
+          if (k0 + k + 2 < K) v.z = p[2];
+          if (k0 + k + 3 < K) v.w = p[3];
+          if constexpr (MASK) {
+            if (mask) {
+              const float *m = mask + o;
+              mk.x = m[0];
+              if (k0 + k + 1 < K) mk.y = m[1];
+              if (k0 + k + 2 < K) mk.z = m[2];
+              if (k0 + k + 3 < K) mk.w = m[3];
+            }
+          }
+        }
+      }
+    }
+    r.v[i] = v;
+    if constexpr (MASK) rm.v[i] = mk;
+  }
+}
+
+// registers -> LDS image (16-byte stores); with MASK, a value counts as 0 where its mask is <= 0
+template <int BX, int BK, int MODE, bool MASK>
+__device__ __forceinline__ void pw_stash(float *img, const PwRegs<BX * BK / 4 / kMmThreads> &r,
+                                         const PwRegs<MASK ? BX * BK / 4 / kMmThreads : 1> &rm, int t) {
+  constexpr int V = PwImg<BX, BK, MODE>::vecs, LD = PwImg<BX, BK, MODE>::ld;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int q = t + i * kMmThreads;
+    float4 v = r.v[i];
+    if constexpr (MASK) {
+      v.x = rm.v[i].x > 0.f ? v.x : 0.f;
+      v.y = rm.v[i].y > 0.f ? v.y : 0.f;
+      v.z = rm.v[i].z > 0.f ? v.z : 0.f;
+      v.w = rm.v[i].w > 0.f ? v.w : 0.f;
+    }
+    if constexpr (MODE == kXC) {
+      const int k = q / (BX / 4), x = (q % (BX / 4)) * 4;
+      *reinterpret_cast<float4 *>(img + k * LD + x) = v;
+    } else {
+      const int x = q / (BK / 4), k = (q % (BK / 4)) * 4;
+      *reinterpret_cast<float4 *>(img + x * LD + k) = v;
+    }
+  }
+}
+
+// Fragments of k-group kg (8 values of k) for T MFMA blocks of 32 rows starting at xw:
+// v[i][j] is the operand of instruction j: k = 8 kg + j (lanes 0..31) / 8 kg + 4 + j (lanes 32..63).
+template <int T, int BX, int BK, int MODE>
+__device__ __forceinline__ void pw_frag(float (&v)[T][4], const float *img, int xw, int kg, int lrow, int lk) {
+  constexpr int LD = PwImg<BX, BK, MODE>::ld;
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    if constexpr (MODE == kXC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = img[(kg * 8 + j + 4 * lk) * LD + xw + i * 32 + lrow];
+    } else {
+      const float4 q = *reinterpret_cast<const float4 *>(img + (xw + i * 32 + lrow) * LD + kg * 8 + 4 * lk);
+      v[i][0] = q.x;
+      v[i][1] = q.y;
+      v[i][2] = q.z;
+      v[i][3] = q.w;
+    }
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void pw_mma(f32x16 (&acc)[TM][TN], const float (&a)[TM][4], const float (&b)[TN][4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
+}
+
+// Workgroup number -> work item so that consecutive items run on ONE XCD (workgroups are dealt to the 8 XCDs
+// round-robin by their linear id): XCD x takes items [x per, (x + 1) per).
+__device__ __forceinline__ long long pw_work_item(long long total) {
+  const long long per = (total + 7) / 8;
+  return (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
+// ------------------------------------------------------------------- forward / data gradient
+// Per cloud  Y (M x N) = A (M x K) X (K x N): A = the weight, (M, K) row-major [AMODE kKC: forward] or (K, M)
+// row-major [kXC: the data gradient multiplies by W^T]; X, xmask (K x N), Y per cloud.
+template <int TM, int TN, int BK, int AMODE, bool MASKED>
 __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
-    int cin, int cout, int len, const float *__restrict__ x, const float *__restrict__ xmask,
-    const float *__restrict__ w, const float *__restrict__ bias, const float *__restrict__ residual, int relu,
+    int M, int N, int K, int nb, const float *__restrict__ a, int a_vec, const float *__restrict__ x,
+    const float *__restrict__ xmask, const float *__restrict__ bias, const float *__restrict__ residual, int relu,
     int group, float *__restrict__ y) {
-  constexpr int TM = BM / 64;        // MFMA blocks per wave along M
-  constexpr int TN = 2;              // ... along N (wave tile: 32 TM x 64)
-  constexpr int LDA = BM + 2;        // [k][m] image, padded: rows k and k + 1 (lanes 32..63) land on shifted banks
-  __shared__ __attribute__((aligned(16))) float As[2][kMmBK][LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kMmBK][kMmBN];
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  using IA = PwImg<BM, BK, AMODE>;
+  using IB = PwImg<BN, BK, kXC>;
+  __shared__ __attribute__((aligned(16))) float As[2][IA::floats];
+  __shared__ __attribute__((aligned(16))) float Bs[2][IB::floats];
+  __shared__ float sbias[BM];
+
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const long long total = (long long)tiles_m * tiles_n * nb;
+  const long long work = pw_work_item(total);
+  if (work >= total) return;
+  const int m0 = (int)(work % tiles_m) * BM;               // the M tiles of one activation tile are neighbours
+  const int n0 = (int)((work / tiles_m) % tiles_n) * BN;
+  const int cloud = (int)(work / ((long long)tiles_m * tiles_n));
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * kMmBN, m0 = blockIdx.y * BM, cloud = blockIdx.z;
-  const float *xb = x + (size_t)cloud * cin * len;
-  const float *mb = xmask ? xmask + (size_t)cloud * cin * len : nullptr;   // x is used where mask > 0 (ReLU'(.))
+  const int wm = wave >> 1, wn = wave & 1, lrow = lane & 31, lk = lane >> 5;
+  const float *xb = x + (size_t)cloud * K * N;
+  const float *mb = xmask ? xmask + (size_t)cloud * K * N : nullptr;
+  const size_t lda = AMODE == kKC ? K : M;
+
+  if (t < BM) sbias[t] = (bias && m0 + t < M) ? bias[m0 + t] : 0.f;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -60,171 +208,118 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- global -> registers (one K slab): A BM x 16, B 16 x 128
-  constexpr int A4 = BM * kMmBK / 4 / kMmThreads;   // float4 per thread: 2 (BM 128) or 1 (BM 64)
-  constexpr int B4f = kMmBK * kMmBN / 4 / kMmThreads;  // float4 of the B slab per thread
-  float4 ra[A4], rb[B4f];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < A4; ++i) {
-      const int q = t + i * kMmThreads;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (KMAJOR) {            // w is (cin, cout): 4 consecutive m of one k
-        const int k = q / (BM / 4), m = (q % (BM / 4)) * 4;
-        if (k0 + k < cin) {
-          const float *p = w + (size_t)(k0 + k) * cout + m0 + m;
-          if (m0 + m + 3 < cout) {
-            v = *reinterpret_cast<const float4 *>(p);
-          } else {
-            if (m0 + m < cout) v.x = p[0];
-            if (m0 + m + 1 < cout) v.y = p[1];
-            if (m0 + m + 2 < cout) v.z = p[2];
-          }
-        }
-      } else {                            // w is (cout, cin): 4 consecutive k of one m
-        const int m = q / (kMmBK / 4), k = (q % (kMmBK / 4)) * 4;
-        if (m0 + m < cout) {
-          const float *p = w + (size_t)(m0 + m) * cin + k0 + k;
-          if (k0 + k + 3 < cin && (cin & 3) == 0) {
-            v = *reinterpret_cast<const float4 *>(p);
-          } else {
-            if (k0 + k < cin) v.x = p[0];
-            if (k0 + k + 1 < cin) v.y = p[1];
-            if (k0 + k + 2 < cin) v.z = p[2];
-            if (k0 + k + 3 < cin) v.w = p[3];
-          }
-        }
-      }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B4f; ++i) {
-      const int q = t + i * kMmThreads;
-      const int k = q / 32, n = (q % 32) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + k < cin && n0 + n < len) {   // len % 4 == 0: a float4 is inside or outside
-        v = *reinterpret_cast<const float4 *>(xb + (size_t)(k0 + k) * len + n0 + n);
-        if (mb) {
-          const float4 mk = *reinterpret_cast<const float4 *>(mb + (size_t)(k0 + k) * len + n0 + n);
-          v.x = mk.x > 0.f ? v.x : 0.f;
-          v.y = mk.y > 0.f ? v.y : 0.f;
-          v.z = mk.z > 0.f ? v.z : 0.f;
-          v.w = mk.w > 0.f ? v.w : 0.f;
-        }
-      }
-      rb[i] = v;
-    }
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A4; ++i) {
-      const int q = t + i * kMmThreads;
-      if constexpr (KMAJOR) {
-        const int k = q / (BM / 4), m = (q % (BM / 4)) * 4;
-        As[buf][k][m] = ra[i].x;
-        As[buf][k][m + 1] = ra[i].y;
-        As[buf][k][m + 2] = ra[i].z;
-        As[buf][k][m + 3] = ra[i].w;
-      } else {
-        const int m = q / (kMmBK / 4), k = (q % (kMmBK / 4)) * 4;
-        As[buf][k][m] = ra[i].x;
-        As[buf][k + 1][m] = ra[i].y;
-        As[buf][k + 2][m] = ra[i].z;
-        As[buf][k + 3][m] = ra[i].w;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B4f; ++i) {
-      const int q = t + i * kMmThreads;
-      *reinterpret_cast<float4 *>(&Bs[buf][q / 32][(q % 32) * 4]) = rb[i];
-    }
-  };
-
-  const int nk = (cin + kMmBK - 1) / kMmBK;
-  fetch(0);
-  stash(0);
+  PwRegs<IA::vecs> ra;
+  PwRegs<IB::vecs> rb;
+  PwRegs<1> rnone;
+  PwRegs<MASKED ? IB::vecs : 1> rbm;
+  const int nk = (K + BK - 1) / BK;
+  pw_fetch<BM, BK, AMODE, false>(ra, rnone, a, nullptr, lda, m0, M, 0, K, a_vec != 0, t);
+  pw_fetch<BN, BK, kXC, MASKED>(rb, rbm, xb, mb, N, n0, N, 0, K, true, t);
+  pw_stash<BM, BK, AMODE, false>(As[0], ra, rnone, t);
+  pw_stash<BN, BK, kXC, MASKED>(Bs[0], rb, rbm, t);
   __syncthreads();
-  const int lrow = lane & 31, lk = lane >> 5;
   for (int s = 0; s < nk; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nk) fetch((s + 1) * kMmBK);      // in flight while this slab computes
+    if (s + 1 < nk) {                                   // in flight while this slab computes
+      pw_fetch<BM, BK, AMODE, false>(ra, rnone, a, nullptr, lda, m0, M, (s + 1) * BK, K, a_vec != 0, t);
+      pw_fetch<BN, BK, kXC, MASKED>(rb, rbm, xb, mb, N, n0, N, (s + 1) * BK, K, true, t);
+    }
 #pragma unroll
-    for (int kk = 0; kk < kMmBK; kk += 2) {
-      float a[TM], bq[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + lk][wm * 32 * TM + i * 32 + lrow];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bq[j] = Bs[buf][kk + lk][wn * 64 + j * 32 + lrow];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float av[TM][4], bv[TN][4];
+      pw_frag<TM, BM, BK, AMODE>(av, As[buf], wm * 32 * TM, kg, lrow, lk);
+      pw_frag<TN, BN, BK, kXC>(bv, Bs[buf], wn * 32 * TN, kg, lrow, lk);
+      pw_mma<TM, TN>(acc, av, bv);
     }
     if (s + 1 < nk) {
-      stash(buf ^ 1);                              // the other buffer: nobody reads it in this step
+      pw_stash<BM, BK, AMODE, false>(As[buf ^ 1], ra, rnone, t);      // the other buffer: nobody reads it in this step
+      pw_stash<BN, BK, kXC, MASKED>(Bs[buf ^ 1], rb, rbm, t);
       __syncthreads();
     }
   }
 
-  // ---- epilogue: C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  const int len_out = len / group;
-  float *yb = y + (size_t)cloud * cout * len_out;
-  const float *rbse = residual ? residual + (size_t)cloud * cout * len_out : nullptr;
+  // ---- epilogue.  C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int len_out = N / group;
+  float *yb = y + (size_t)cloud * M * len_out;
+  const float *rbse = residual ? residual + (size_t)cloud * M * len_out : nullptr;
+  if (group == 1 && !rbse) {                             // the common case: straight-line
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
+      float bv[16];                                      // the rows' biases first: independent LDS reads, one wait
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[r] = sbias[wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + j * 32 + lrow;
+        float *yc = yb + (size_t)(m0 + wm * 32 * TM + i * 32 + 4 * lk) * N + col;
+        const int rows_left = M - (m0 + wm * 32 * TM + i * 32 + 4 * lk);   // rows of this lane that exist
+        if (col < N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            float v = acc[i][j][r] + bv[r];
+            v = relu ? __builtin_fmaxf(v, 0.f) : v;
+            if (dr < rows_left) yc[(size_t)dr * N] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + lrow;
+      const int col = n0 + wn * 32 * TN + j * 32 + lrow;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        float v = acc[i][j][r];
-        if (bias && row < cout) v += bias[row];
+        const int lr = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int row = m0 + lr;
+        float v = acc[i][j][r] + sbias[lr];
         if (relu) v = __builtin_fmaxf(v, 0.f);
         if (group > 1) {
-          if (col >= len) v = -__builtin_inff();     // (len % group == 0: a group is inside or outside)
+          if (col >= N) v = -__builtin_inff();            // (N % group == 0: a group is inside or outside)
           for (int off = 1; off < group; off <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
         }
-        if (row < cout && col < len && (lrow & (group - 1)) == 0) {
+        if (row < M && col < N && (lrow & (group - 1)) == 0) {
           const size_t o = (size_t)row * len_out + col / group;
           if (rbse) v += rbse[o];
           yb[o] = v;
         }
       }
     }
-  }
 }
 
-
 // ---------------------------------------------------------------- weight gradient
-// gw[co][ci] = sum_b sum_l g[b][co][l] x[b][ci][l]   (g = grad_out, optionally masked by ReLU'),
-// gb[co] = sum_b sum_l g[b][co][l]: the same GEMM with one more "input channel" that is all ones.
-// M = cout, N = cin (+1), K = the b * len positions -- a huge reduction with a small output:
-// the positions are split over `splits` workgroups per output tile, each writes its partial tile,
-// a second kernel adds the partials in a fixed order (no float atomics: reproducible).
-// Both operands are K-contiguous in memory, so both LDS images are [row][k] (padded to an odd
-// stride: a fragment read takes 32 rows at one k).
-constexpr int kWgBK = 32;
-
-template <int BM>
+// gw[co][ci] = sum_b sum_l g[b][co][l] x[b][ci][l]  (g = grad_out, optionally masked by ReLU'),
+// gb[co] = sum_b sum_l g[b][co][l].  M = cout, N = cin, K = the b * len positions: a huge reduction with a
+// small output.  The positions -- slabs of BK per cloud, numbered across the clouds -- are dealt out in
+// contiguous runs to `splits` workgroups per output tile, as many as fit the chip at once (one wave of
+// workgroups, equal work, no tail); each writes its partial tile, a second kernel adds the partials in a fixed
+// order (no float atomics: reproducible).  The bias gradient is the row sum of the staged g tile, taken from
+// LDS by the workgroups of the first column of tiles.  Both operands are k-contiguous.
+template <int TM, int TN, int BK, bool MASKED>
 __global__ __launch_bounds__(kMmThreads) void pointwise_wgrad_mfma_kernel(
-    int b, int cin, int cout, int len, int chunk, int chunks_per_cloud, const float *__restrict__ x,
-    const float *__restrict__ g, const float *__restrict__ gmask, int with_bias, float *__restrict__ partial) {
-  constexpr int TM = BM / 64, TN = 2;
-  constexpr int LD = kWgBK + 1;
-  __shared__ float As[2][BM][LD];
-  __shared__ float Bs[2][kMmBN][LD];
+    int nb, int cin, int cout, int len, int slabs_per_cloud, int slabs_per_split, int splits,
+    const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ gmask, int with_bias,
+    float *__restrict__ partial, float *__restrict__ pbias) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  using IA = PwImg<BM, BK, kKC>;
+  using IB = PwImg<BN, BK, kKC>;
+  __shared__ __attribute__((aligned(16))) float As[2][IA::floats];
+  __shared__ __attribute__((aligned(16))) float Bs[2][IB::floats];
+
+  const int tiles_m = (cout + BM - 1) / BM, tiles_n = (cin + BN - 1) / BN, tiles = tiles_m * tiles_n;
+  const long long total = (long long)tiles * splits;
+  const long long work = pw_work_item(total);
+  if (work >= total) return;
+  const int tile = (int)(work % tiles), split = (int)(work / tiles);   // the tiles of one run of positions are neighbours
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int s_begin = split * slabs_per_split;
+  const int s_end = min(s_begin + slabs_per_split, nb * slabs_per_cloud);
+
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ncols = cin + (with_bias ? 1 : 0);
-  const int tiles_n = (ncols + kMmBN - 1) / kMmBN;
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * kMmBN;
-  const int split = blockIdx.y;                     // one (cloud, chunk of positions) per split
-  const int cloud = split / chunks_per_cloud, l0 = (split % chunks_per_cloud) * chunk;
-  const int l1 = min(len, l0 + chunk);
-  const float *gb_ = g + (size_t)cloud * cout * len;
-  const float *mb = gmask ? gmask + (size_t)cloud * cout * len : nullptr;
-  const float *xb = x + (size_t)cloud * cin * len;
+  const int wm = wave >> 1, wn = wave & 1, lrow = lane & 31, lk = lane >> 5;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -233,137 +328,119 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_wgrad_mfma_kernel(
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const bool do_bias = with_bias && n0 == 0;
+  constexpr int kParts = kMmThreads / BM;                   // threads per row of the g tile
+  float bsum = 0.f;
 
-  constexpr int A4 = BM * kWgBK / 4 / kMmThreads;    // float4 per thread: 4 (BM 128) or 2 (BM 64)
-  constexpr int B4 = kMmBN * kWgBK / 4 / kMmThreads; // 4
-  float4 ra[A4], rb[B4];
-  auto fetch = [&](int k0) {                         // k0: first position of the slab
-#pragma unroll
-    for (int i = 0; i < A4; ++i) {
-      const int q = t + i * kMmThreads;
-      const int m = q / (kWgBK / 4), k = (q % (kWgBK / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + m < cout && k0 + k < l1) {            // len % 4 == 0 and chunk % 4 == 0
-        v = *reinterpret_cast<const float4 *>(gb_ + (size_t)(m0 + m) * len + k0 + k);
-        if (mb) {
-          const float4 mk = *reinterpret_cast<const float4 *>(mb + (size_t)(m0 + m) * len + k0 + k);
-          v.x = mk.x > 0.f ? v.x : 0.f;
-          v.y = mk.y > 0.f ? v.y : 0.f;
-          v.z = mk.z > 0.f ? v.z : 0.f;
-          v.w = mk.w > 0.f ? v.w : 0.f;
-        }
-      }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B4; ++i) {
-      const int q = t + i * kMmThreads;
-      const int j = q / (kWgBK / 4), k = (q % (kWgBK / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + k < l1) {
-        if (n0 + j < cin) v = *reinterpret_cast<const float4 *>(xb + (size_t)(n0 + j) * len + k0 + k);
-        else if (n0 + j == cin && with_bias) v = make_float4(1.f, 1.f, 1.f, 1.f);   // the bias column
-      }
-      rb[i] = v;
-    }
+  PwRegs<IA::vecs> ra;
+  PwRegs<IB::vecs> rb;
+  PwRegs<1> rnone;
+  PwRegs<MASKED ? IA::vecs : 1> ram;
+  auto fetch = [&](int gs) {
+    const int cloud = gs / slabs_per_cloud, l0 = (gs - cloud * slabs_per_cloud) * BK;
+    const size_t og = (size_t)cloud * cout * len, ox = (size_t)cloud * cin * len;
+    pw_fetch<BM, BK, kKC, MASKED>(ra, ram, g + og, MASKED ? gmask + og : nullptr, len, m0, cout, l0, len, true, t);
+    pw_fetch<BN, BK, kKC, false>(rb, rnone, x + ox, nullptr, len, n0, cin, l0, len, true, t);
   };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A4; ++i) {
-      const int q = t + i * kMmThreads;
-      const int m = q / (kWgBK / 4), k = (q % (kWgBK / 4)) * 4;
-      As[buf][m][k] = ra[i].x;
-      As[buf][m][k + 1] = ra[i].y;
-      As[buf][m][k + 2] = ra[i].z;
-      As[buf][m][k + 3] = ra[i].w;
-    }
-#pragma unroll
-    for (int i = 0; i < B4; ++i) {
-      const int q = t + i * kMmThreads;
-      const int j = q / (kWgBK / 4), k = (q % (kWgBK / 4)) * 4;
-      Bs[buf][j][k] = rb[i].x;
-      Bs[buf][j][k + 1] = rb[i].y;
-      Bs[buf][j][k + 2] = rb[i].z;
-      Bs[buf][j][k + 3] = rb[i].w;
-    }
-  };
-  const int nk = (l1 - l0 + kWgBK - 1) / kWgBK;
-  const int lrow = lane & 31, lk = lane >> 5;
-  if (nk > 0) {
-    fetch(l0);
-    stash(0);
+  if (s_begin < s_end) {
+    fetch(s_begin);
+    pw_stash<BM, BK, kKC, MASKED>(As[0], ra, ram, t);
+    pw_stash<BN, BK, kKC, false>(Bs[0], rb, rnone, t);
   }
   __syncthreads();
-  for (int s = 0; s < nk; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nk) fetch(l0 + (s + 1) * kWgBK);
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    if (s + 1 < s_end) fetch(s + 1);
 #pragma unroll
-    for (int kk = 0; kk < kWgBK; kk += 2) {
-      float a[TM], bq[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[buf][wm * 32 * TM + i * 32 + lrow][kk + lk];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bq[j] = Bs[buf][wn * 64 + j * 32 + lrow][kk + lk];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float av[TM][4], bv[TN][4];
+      pw_frag<TM, BM, BK, kKC>(av, As[buf], wm * 32 * TM, kg, lrow, lk);
+      pw_frag<TN, BN, BK, kKC>(bv, Bs[buf], wn * 32 * TN, kg, lrow, lk);
+      pw_mma<TM, TN>(acc, av, bv);
     }
-    if (s + 1 < nk) {
-      stash(buf ^ 1);
+    if (do_bias) {
+      const float *row = As[buf] + (t / kParts) * IA::ld + (t % kParts) * (BK / kParts);
+#pragma unroll
+      for (int k = 0; k < BK / kParts; k += 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(row + k);
+        bsum += (q.x + q.y) + (q.z + q.w);
+      }
+    }
+    if (s + 1 < s_end) {
+      pw_stash<BM, BK, kKC, MASKED>(As[buf ^ 1], ra, ram, t);
+      pw_stash<BN, BK, kKC, false>(Bs[buf ^ 1], rb, rnone, t);
       __syncthreads();
     }
   }
-  // partial[split][co][col], col < ncols
-  float *pp = partial + (size_t)split * cout * ncols;
+  // partial[split][co][ci]
+  float *pp = partial + (size_t)split * cout * cin;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + lrow;
+      const int col = n0 + wn * 32 * TN + j * 32 + lrow;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row < cout && col < ncols) pp[(size_t)row * ncols + col] = acc[i][j][r];
+        if (row < cout && col < cin) pp[(size_t)row * cin + col] = acc[i][j][r];
       }
     }
+  if (do_bias) {
+#pragma unroll
+    for (int off = 1; off < kParts; off <<= 1) bsum += __shfl_xor(bsum, off, 64);
+    const int row = m0 + t / kParts;
+    if (t % kParts == 0 && row < cout) pbias[(size_t)split * cout + row] = bsum;
+  }
 }
 
 // gw[co][ci] (and gb[co]) = sum over the splits, in split order
-__global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(int cin, int cout, int with_bias, int splits,
+__global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(int cin, int cout, int splits,
                                                                      const float *__restrict__ partial,
+                                                                     const float *__restrict__ pbias,
                                                                      float *__restrict__ gw, float *__restrict__ gb) {
-  const int ncols = cin + (with_bias ? 1 : 0);
-  const long long total = (long long)cout * ncols;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
+  const long long nw = (long long)cout * cin;
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float *src = partial;
+  long long stride = nw;
+  float *dst = gw;
+  if (e >= nw) {
+    e -= nw;
+    if (!gb || e >= cout) return;
+    src = pbias;
+    stride = cout;
+    dst = gb;
+  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int sp = 0;
   for (; sp + 3 < splits; sp += 4) {
-    s0 += partial[(size_t)sp * total + e];
-    s1 += partial[(size_t)(sp + 1) * total + e];
-    s2 += partial[(size_t)(sp + 2) * total + e];
-    s3 += partial[(size_t)(sp + 3) * total + e];
+    s0 += src[(size_t)sp * stride + e];
+    s1 += src[(size_t)(sp + 1) * stride + e];
+    s2 += src[(size_t)(sp + 2) * stride + e];
+    s3 += src[(size_t)(sp + 3) * stride + e];
   }
-  for (; sp < splits; ++sp) s0 += partial[(size_t)sp * total + e];
-  const float v = (s0 + s1) + (s2 + s3);
-  const int row = (int)(e / ncols), col = (int)(e % ncols);
-  if (col < cin) gw[(size_t)row * cin + col] = v;
-  else if (gb) gb[row] = v;
+  for (; sp < splits; ++sp) s0 += src[(size_t)sp * stride + e];
+  dst[e] = (s0 + s1) + (s2 + s3);
 }
 
-// positions per split: whole clouds are cut into chunks so that ~2048 workgroups exist
-static void wgrad_plan(int b, int cin, int cout, int len, int with_bias, int &chunk, int &chunks_per_cloud, int &tiles) {
-  const int bm = cout > 64 ? 128 : 64;
-  const int ncols = cin + (with_bias ? 1 : 0);
-  tiles = ((cout + bm - 1) / bm) * ((ncols + kMmBN - 1) / kMmBN);
-  int want = (2048 + tiles - 1) / tiles;             // splits wanted
-  chunks_per_cloud = (want + b - 1) / b;
-  if (chunks_per_cloud < 1) chunks_per_cloud = 1;
-  chunk = (len + chunks_per_cloud - 1) / chunks_per_cloud;
-  chunk = (chunk + kWgBK - 1) / kWgBK * kWgBK;       // whole slabs
-  if (chunk < 4 * kWgBK) chunk = 4 * kWgBK;
-  chunks_per_cloud = (len + chunk - 1) / chunk;
+#ifndef MVP_WG_BK
+#define MVP_WG_BK 32
+#endif
+constexpr int kWgBK = MVP_WG_BK;
+// workgroups of the weight-gradient kernel resident at once: BK 32 -> 74 KB of LDS, 240 VGPRs: 2 per CU; BK 16: 3 per CU
+constexpr int kWgSlots = kWgBK == 32 ? 512 : 768;
+
+// runs of position slabs: splits x tiles ~ one wave of workgroups
+static void wgrad_plan(int b, int cin, int cout, int len, int &slabs_per_cloud, int &slabs_per_split, int &splits) {
+  const int bm = cout > 64 ? 128 : 64, bn = cin > 64 ? 128 : 64;
+  const long long tiles = (long long)((cout + bm - 1) / bm) * ((cin + bn - 1) / bn);
+  slabs_per_cloud = (len + kWgBK - 1) / kWgBK;
+  const long long slabs = (long long)b * slabs_per_cloud;
+  long long want = kWgSlots / tiles;
+  if (want < 1) want = 1;
+  if (want > slabs) want = slabs;
+  slabs_per_split = (int)((slabs + want - 1) / want);
+  if (slabs_per_split < 4 && slabs >= 4) slabs_per_split = 4;     // a workgroup's prologue wants a few slabs behind it
+  splits = (int)((slabs + slabs_per_split - 1) / slabs_per_split);
 }
 
 }  // namespace mvp
@@ -372,11 +449,10 @@ using namespace mvp;
 
 extern "C" long long mvp_pointwise_wgrad_mfma_scratch_bytes(int b, int cin, int cout, int len, int with_bias) {
   if (b <= 0 || cin <= 0 || cout <= 0 || len <= 0 || (len & 3) != 0) return 0;
-  int chunk, cpc, tiles;
-  wgrad_plan(b, cin, cout, len, with_bias, chunk, cpc, tiles);
-  const long long splits = (long long)b * cpc;
-  if (splits > 65535 || tiles > 2147483647) return 0;
-  return splits * cout * (cin + (with_bias ? 1 : 0)) * 4;
+  if ((long long)b * ((len + kWgBK - 1) / kWgBK) > 2147483647LL) return 0;
+  int spc, sps, splits;
+  wgrad_plan(b, cin, cout, len, spc, sps, splits);
+  return (long long)splits * cout * (cin + (with_bias ? 1 : 0)) * 4;
 }
 
 extern "C" int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const float *x, const float *gy,
@@ -388,20 +464,35 @@ extern "C" int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const
   if (!x || !gy || !gw || !scratch || scratch_bytes < need) return MVP_EBADARG;
   if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gymask)) & 15) != 0)
     return MVP_EBADARG;
-  int chunk, cpc, tiles;
-  wgrad_plan(b, cin, cout, len, with_bias, chunk, cpc, tiles);
-  const int splits = b * cpc;
+  int spc, sps, splits;
+  wgrad_plan(b, cin, cout, len, spc, sps, splits);
   hipStream_t st = as_stream(stream);
   float *partial = static_cast<float *>(scratch);
-  if (cout > 64)
-    hipLaunchKernelGGL(pointwise_wgrad_mfma_kernel<128>, dim3(tiles, splits), dim3(kMmThreads), 0, st, b, cin, cout, len,
-                       chunk, cpc, x, gy, gymask, with_bias, partial);
-  else
-    hipLaunchKernelGGL(pointwise_wgrad_mfma_kernel<64>, dim3(tiles, splits), dim3(kMmThreads), 0, st, b, cin, cout, len,
-                       chunk, cpc, x, gy, gymask, with_bias, partial);
-  const long long total = (long long)cout * (cin + with_bias);
-  hipLaunchKernelGGL(pointwise_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cin, cout,
-                     with_bias, splits, partial, gw, gb);
+  float *pbias = partial + (size_t)splits * cout * cin;
+  const int bm = cout > 64 ? 128 : 64, bn = cin > 64 ? 128 : 64;
+  const long long total = (long long)((cout + bm - 1) / bm) * ((cin + bn - 1) / bn) * splits;
+  const long long nwg = (total + 7) / 8 * 8;
+  if (nwg > 2147483647LL) return MVP_EBADSHAPE;
+#define MVP_WG_(TM, TN, MK)                                                                                             \
+  hipLaunchKernelGGL((pointwise_wgrad_mfma_kernel<TM, TN, kWgBK, MK>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, b, \
+                     cin, cout, len, spc, sps, splits, x, gy, gymask, with_bias, partial, pbias)
+#define MVP_WG(TM, TN)              \
+  do {                              \
+    if (gymask) MVP_WG_(TM, TN, true); \
+    else MVP_WG_(TM, TN, false);    \
+  } while (0)
+  if (bm == 128) {
+    if (bn == 128) MVP_WG(2, 2);
+    else MVP_WG(2, 1);
+  } else {
+    if (bn == 128) MVP_WG(1, 2);
+    else MVP_WG(1, 1);
+  }
+#undef MVP_WG
+#undef MVP_WG_
+  const long long elems = (long long)cout * cin + (with_bias ? cout : 0);
+  hipLaunchKernelGGL(pointwise_wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, cin, cout,
+                     splits, partial, pbias, gw, gb);
   return check_launch("mvp_pointwise_wgrad_mfma");
 }
 
@@ -418,18 +509,27 @@ extern "C" int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float
   if (!w_kmajor && (cin & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) != 0) return MVP_EBADARG;
   hipStream_t st = as_stream(stream);
   const bool big = cout > 64;
-  dim3 grid((len + kMmBN - 1) / kMmBN, (cout + (big ? 128 : 64) - 1) / (big ? 128 : 64), b);
-  if (grid.y > 65535) return MVP_EBADSHAPE;
-#define MVP_MM(BM, KM)                                                                                       \
-  hipLaunchKernelGGL((pointwise_mfma_kernel<BM, KM>), grid, dim3(kMmThreads), 0, st, cin, cout, len, x, xmask, w, \
-                     bias, residual, relu, group, y)
+  const int bm = big ? 128 : 64;
+  const long long total = (long long)((cout + bm - 1) / bm) * ((len + 127) / 128) * b;
+  const long long nwg = (total + 7) / 8 * 8;
+  if (nwg > 2147483647LL) return MVP_EBADSHAPE;
+  const int a_vec = w_kmajor ? 1 : ((cin & 3) == 0);
+#define MVP_MM_(TM, MODE, MK)                                                                                       \
+  hipLaunchKernelGGL((pointwise_mfma_kernel<TM, 2, 16, MODE, MK>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, cout, \
+                     len, cin, b, w, a_vec, x, xmask, bias, residual, relu, group, y)
+#define MVP_MM(TM, MODE)              \
+  do {                                \
+    if (xmask) MVP_MM_(TM, MODE, true); \
+    else MVP_MM_(TM, MODE, false);    \
+  } while (0)
   if (big) {
-    if (w_kmajor) MVP_MM(128, true);
-    else MVP_MM(128, false);
+    if (w_kmajor) MVP_MM(2, kXC);
+    else MVP_MM(2, kKC);
   } else {
-    if (w_kmajor) MVP_MM(64, true);
-    else MVP_MM(64, false);
+    if (w_kmajor) MVP_MM(1, kXC);
+    else MVP_MM(1, kKC);
   }
 #undef MVP_MM
+#undef MVP_MM_
   return check_launch("mvp_pointwise_mfma");
 }

@@ -3,13 +3,15 @@ networks.  Same parameters and state_dict layout as nn.Conv1d /
 nn.Conv2d(kernel_size=1); the reference builds these layers with nn.Conv1d /
 nn.Conv2d directly (completion/models/pcn.py, ecg.py, vrcnet.py).
 
-Routing on float32 CUDA tensors (include/mvpops.h):
-  * forward and data gradient of layers with >= 32 input and output channels:
-    `mvp_pointwise_mfma`, an LDS-tiled GEMM on the float32 MFMA instruction with
-    bias / ReLU / residual / max-over-neighbours fused into its epilogue;
-  * weight gradient of layers with <= 64 x 64 channels -- a GEMM with a tiny
-    output and everything else as its reduction dimension, which the library
-    runs at 0.4-1.0 TB/s of its operands -- `mvp_pointwise_wgrad`;
+Routing on float32 CUDA tensors (include/mvpops.h), training and inference alike:
+  * layers with >= 32 input and output channels: all three passes on the float32
+    MFMA GEMMs of csrc/pointwise_mfma.hip -- forward `mvp_pointwise_mfma` with bias /
+    ReLU / residual / max-over-neighbours fused into its epilogue, data gradient
+    the same kernel on the transposed weight with ReLU' applied to grad_out on
+    load, weight + bias gradient `mvp_pointwise_wgrad_mfma` (ReLU' on load, the
+    NCHW operands read as they lie: no layout transposes);
+  * layers with <= 64 x 64 channels: weight gradient `mvp_pointwise_wgrad`, data
+    gradient `mvp_pointwise_dgrad` (one pass over gy, weights from LDS);
   * everything else (and every non-CUDA / non-float32 tensor): the library
     convolution.
 """
@@ -21,27 +23,18 @@ from torch.autograd import Function
 from ._lib import call, pointwise_wgrad_mfma_scratch_bytes, pointwise_wgrad_scratch_bytes
 
 MAX_COUT = 64   # mvp_pointwise_wgrad's limit
-MAX_CIN = 64    # beyond this MIOpen's weight gradient is as fast or faster (tools/bench_conv_parts.py)
+MAX_CIN = 64
 MFMA_MIN_CH = 32  # mvp_pointwise_mfma: below this many channels a 32-wide MFMA block is mostly padding
 USE_MFMA = True   # A-B switch (tools/bench_models.py)
-# Measured on the 1x1-convolution shapes of PCN / VRCNet (tools/bench_pointwise_mfma.py,
-# profiles/r2_bench_pointwise_mfma.txt): the forward GEMM with its fused epilogue beats the library
-# convolution + separate ReLU by 1.0-1.7x everywhere; the library's data gradient (115-124 TFLOP/s) beats
-# this kernel's (80-117); the weight gradients tie except for wide inputs (Cin > 512: 1.5x).
-MFMA_DGRAD = False
-MFMA_WGRAD_MIN_CIN = 513
-MFMA_FWD_MAX_CIN = 256    # wider inputs: a tie with the library (1.0-1.1x), which then keeps its own algorithm choice
-# Under autograd the routed layers go through a Python autograd.Function (saved tensors, mask, scratch):
-# at VRCNet's 37 such layers per step that host-side cost (the step is close to CPU-bound: 32 ms of
-# host time for 34 ms of GPU time) outweighs the kernels' gains -- 34.6-35.6 ms per step routed against
-# 33.1 ms with the library (profiles/r2_bench_models.txt).  So training keeps the library unless this is
-# set; inference (no autograd) uses the MFMA forward.
-MFMA_TRAIN = False
-# Round 3: the library's weight gradient of the >64-channel 1x1 convolutions is an NHWC implicit-GEMM kernel wrapped in
-# layout transposes (VRCNet step: igemm_wrw 3.4 ms x18 + batched_transpose_32x32_dword 1.8 ms x64,
-# tools/profile_kernels.py); mvp_pointwise_wgrad_mfma reads the NCHW operands as they are.  With this flag the layers
-# with at least MFMA_WGRAD_TRAIN_MIN_CIN input channels go through the autograd.Function under training too -- forward
-# and data gradient stay library calls, only the weight (+ bias) gradient changes hands.
+# Round 4 (tools/bench_conv_passes.py, profiles/r4_conv_passes_*.txt): on the 20 routed shapes of a VRCNet step the
+# three passes cost 3.99 / 3.93 / 5.38 ms on these kernels against 5.34 / 5.54 / 6.29 ms on the library (whose
+# weight gradient is an NHWC implicit GEMM wrapped in layout transposes), every shape at least a tie.  Rounds 2-3 had
+# kept training on the library (MFMA_TRAIN off): the round-2 kernels won the forward only.  The switches stay for A/B:
+MFMA_TRAIN = True          # under autograd the routed layers go through _PointwiseConv
+MFMA_DGRAD = True          # data gradient on mvp_pointwise_mfma (W^T, ReLU' on load)
+MFMA_WGRAD_MIN_CIN = 32    # weight gradient on mvp_pointwise_wgrad_mfma from this many input channels
+MFMA_FWD_MAX_CIN = 1 << 30
+# Only the weight gradients leave the library (forward and data gradient stay library calls); superseded by MFMA_TRAIN
 MFMA_WGRAD_TRAIN = False
 MFMA_WGRAD_TRAIN_MIN_CIN = 65
 

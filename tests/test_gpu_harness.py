@@ -489,13 +489,16 @@ def test_pointwise_conv_weight_gradient(shape, cout, bias):
     assert torch.equal(gw, gw2)                                          # fixed summation order: reproducible
     # the autograd route
     import mvp_benchmark_amd.pointwise as pw
-    pw.MFMA_TRAIN = True
+    assert pw.MFMA_TRAIN                                                 # the default since round 4
     y = pointwise_conv(x, w, b)
-    pw.MFMA_TRAIN = False
-    mfma = cin >= MFMA_MIN_CH and cout >= MFMA_MIN_CH and length % 4 == 0     # (forward: only for cin <= MFMA_FWD_MAX_CIN)
+    mfma = cin >= MFMA_MIN_CH and cout >= MFMA_MIN_CH and length % 4 == 0
     small = cin <= MAX_CIN and cout <= MAX_COUT and length % 4 == 0
     assert isinstance(y.grad_fn, _PointwiseConv._backward_cls) == (mfma or small)
-    y_lib = pointwise_conv(x, w, b)                                      # default: training keeps the library unless small
+    pw.MFMA_TRAIN = False
+    try:
+        y_lib = pointwise_conv(x, w, b)                                  # switched off: the library unless small
+    finally:
+        pw.MFMA_TRAIN = True
     assert isinstance(y_lib.grad_fn, _PointwiseConv._backward_cls) == small
     got = torch.autograd.grad(y, params, go)
     if mfma:
@@ -635,4 +638,4 @@ def test_pointwise_conv_autograd_through_mfma():
             for a, r, name in ((y, yr, "y"), (gx, rx, "gx"), (gw, rw, "gw"), (gb, rb, "gb")):
                 scale = r.abs().max().item() + 1e-6
                 assert (a - r).abs().max().item() < 2e-5 * scale * math.sqrt(max(cin, L)), (cin, cout, relu, name)
-    pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN = False, 513, False
+    pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN = True, 32, True               # the defaults
