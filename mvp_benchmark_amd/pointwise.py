@@ -50,9 +50,27 @@ def _wgrad_scratch(device, nbytes):
     return buf
 
 
+MFMA_WGRAD_MIN_POSITIONS = 16384   # B * L below this: too few slabs of positions to deal out (ECG's 64- and 256-point levels)
+
+
+def _gemm_fits(batch, m, k, length):
+    """Per-cloud GEMM (m x k) (k x length) worth running on mvp_pointwise_mfma?  Not with a long
+    reduction and fewer workgroups (128 x 128 tiles of the output) than the chip holds at once, or a
+    column tile that is half empty: the library splits K there (ECG's bottleneck layers: 1864 -> 768 at
+    256 points 0.28 against 0.21 ms, 2824 -> 1024 at 64 points 0.25 against 0.10;
+    profiles/r4_conv_passes_ecg.txt)."""
+    if k < 512:
+        return True
+    if length < 128:
+        return False
+    bm = 128 if m > 64 else 64
+    return -(-m // bm) * -(-length // 128) * batch >= 512
+
+
 def _mfma_fwd(x, cin, cout, weight=None):
     """Forward GEMM through mvp_pointwise_mfma?"""
-    return cin <= MFMA_FWD_MAX_CIN and _mfma_ok(x, cin, cout, weight)
+    return cin <= MFMA_FWD_MAX_CIN and _mfma_ok(x, cin, cout, weight) \
+        and _gemm_fits(x.size(0), cout, cin, x[0, 0].numel())
 
 
 def _mfma_ok(x, cin, cout, weight=None):
@@ -138,9 +156,11 @@ class _PointwiseConv(Function):
         need_x = ctx.needs_input_grad[0]
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        gx_mfma = MFMA_DGRAD and need_x and _mfma_ok(gy, cout, cin, weight) and cin % 4 == 0
+        gx_mfma = MFMA_DGRAD and need_x and _mfma_ok(gy, cout, cin, weight) and cin % 4 == 0 \
+            and _gemm_fits(x.size(0), cin, cout, x[0, 0].numel())
         wgrad_min = min(MFMA_WGRAD_MIN_CIN, MFMA_WGRAD_TRAIN_MIN_CIN) if MFMA_WGRAD_TRAIN else MFMA_WGRAD_MIN_CIN
         gw_mfma = (need_w or need_b) and cin >= wgrad_min and _mfma_ok(x, cin, cout, weight) and not _covered(x, weight) \
+            and x.size(0) * x[0, 0].numel() >= MFMA_WGRAD_MIN_POSITIONS \
             and pointwise_wgrad_mfma_scratch_bytes(x.size(0), cin, cout, x[0, 0].numel(), ctx.has_bias) > 0
         # ReLU'(.): the MFMA kernels mask grad_out by the saved output on load; the other routes get
         # the masked tensor

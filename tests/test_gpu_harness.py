@@ -622,6 +622,7 @@ def test_pointwise_conv_autograd_through_mfma():
     from mvp_benchmark_amd import pointwise as pw
     from mvp_benchmark_amd.pointwise import PointwiseConv1d, pointwise_conv
     torch.manual_seed(0)
+    min_positions, pw.MFMA_WGRAD_MIN_POSITIONS = pw.MFMA_WGRAD_MIN_POSITIONS, 0       # small batches through the MFMA weight gradient too
     for cin, cout, L, dgrad, wmin in ((128, 256, 768, False, 513), (128, 256, 768, True, 32), (64, 64, 512, True, 32),
                                       (256, 3, 300, False, 513), (24, 24, 256, False, 513), (515, 128, 384, True, 32),
                                       (1090, 256, 256, False, 513), (96, 160, 1000, True, 32)):
@@ -639,3 +640,4 @@ def test_pointwise_conv_autograd_through_mfma():
                 scale = r.abs().max().item() + 1e-6
                 assert (a - r).abs().max().item() < 2e-5 * scale * math.sqrt(max(cin, L)), (cin, cout, relu, name)
     pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN = True, 32, True               # the defaults
+    pw.MFMA_WGRAD_MIN_POSITIONS = min_positions
