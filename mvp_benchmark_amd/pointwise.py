@@ -24,7 +24,12 @@ from ._lib import call, pointwise_wgrad_mfma_scratch_bytes, pointwise_wgrad_scra
 
 MAX_COUT = 64   # mvp_pointwise_wgrad's limit
 MAX_CIN = 64
-MFMA_MIN_CH = 32  # mvp_pointwise_mfma: below this many channels a 32-wide MFMA block is mostly padding
+# Channel minimum of the MFMA route.  Rounds 2-3: 32 (below it a 32-wide MFMA block is mostly padding).  Round 4: 1 -- the
+# skinny layers (attention-weight MLPs 544 / 272 / 136 / 68 -> 16 / 8 / 4 / 2, the 3- and 8-channel inputs) move bytes, not
+# flops, and the library needs 25-200 us per pass for them where one read of the activations takes 7-25
+# (profiles/r4_conv_passes_vrcnet_skinny.txt: 3.60 -> 1.97 ms per step over the 16 shapes).
+MFMA_MIN_CH = 1
+MFMA_SKINNY_FWD_MAX_CIN = 136   # forward with < 32 output channels: the library's GEMV-like kernel wins from ~256 input channels
 USE_MFMA = True   # A-B switch (tools/bench_models.py)
 # Round 4 (tools/bench_conv_passes.py, profiles/r4_conv_passes_*.txt): on the 20 routed shapes of a VRCNet step the
 # three passes cost 3.99 / 3.93 / 5.38 ms on these kernels against 5.34 / 5.54 / 6.29 ms on the library (whose
@@ -32,7 +37,7 @@ USE_MFMA = True   # A-B switch (tools/bench_models.py)
 # kept training on the library (MFMA_TRAIN off): the round-2 kernels won the forward only.  The switches stay for A/B:
 MFMA_TRAIN = True          # under autograd the routed layers go through _PointwiseConv
 MFMA_DGRAD = True          # data gradient on mvp_pointwise_mfma (W^T, ReLU' on load)
-MFMA_WGRAD_MIN_CIN = 32    # weight gradient on mvp_pointwise_wgrad_mfma from this many input channels
+MFMA_WGRAD_MIN_CIN = 1     # weight gradient on mvp_pointwise_wgrad_mfma from this many input channels
 MFMA_FWD_MAX_CIN = 1 << 30
 # Only the weight gradients leave the library (forward and data gradient stay library calls); superseded by MFMA_TRAIN
 MFMA_WGRAD_TRAIN = False
@@ -70,7 +75,7 @@ def _gemm_fits(batch, m, k, length):
 def _mfma_fwd(x, cin, cout, weight=None):
     """Forward GEMM through mvp_pointwise_mfma?"""
     return cin <= MFMA_FWD_MAX_CIN and _mfma_ok(x, cin, cout, weight) \
-        and _gemm_fits(x.size(0), cout, cin, x[0, 0].numel())
+        and _gemm_fits(x.size(0), cout, cin, x[0, 0].numel()) and (cout >= 32 or cin <= MFMA_SKINNY_FWD_MAX_CIN)
 
 
 def _mfma_ok(x, cin, cout, weight=None):
@@ -156,7 +161,8 @@ class _PointwiseConv(Function):
         need_x = ctx.needs_input_grad[0]
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        gx_mfma = MFMA_DGRAD and need_x and _mfma_ok(gy, cout, cin, weight) and cin % 4 == 0 \
+        gx_small = need_x and _covered(x, weight)          # <= 64 x 64 channels: mvp_pointwise_dgrad (11-26 us, at or below the MFMA kernel)
+        gx_mfma = MFMA_DGRAD and need_x and not gx_small and _mfma_ok(gy, cout, cin, weight) and cin % 4 == 0 \
             and _gemm_fits(x.size(0), cin, cout, x[0, 0].numel())
         wgrad_min = min(MFMA_WGRAD_MIN_CIN, MFMA_WGRAD_TRAIN_MIN_CIN) if MFMA_WGRAD_TRAIN else MFMA_WGRAD_MIN_CIN
         gw_mfma = (need_w or need_b) and cin >= wgrad_min and _mfma_ok(x, cin, cout, weight) and not _covered(x, weight) \

@@ -545,7 +545,8 @@ def test_ef_expansion_on_the_op_layer():
 
 
 @pytest.mark.parametrize("B,cin,cout,L", [(2, 128, 256, 2048), (3, 256, 64, 384), (2, 515, 128, 1536), (1, 1090, 256, 2048),
-                                          (2, 64, 64, 3072), (2, 32, 48, 260), (2, 200, 300, 124), (1, 40, 33, 8)])
+                                          (2, 64, 64, 3072), (2, 32, 48, 260), (2, 200, 300, 124), (1, 40, 33, 8),
+                                          (2, 3, 128, 2048), (2, 68, 2, 3072), (2, 544, 16, 384), (2, 8, 128, 768), (3, 2, 1, 64)])
 def test_pointwise_mfma_matches_torch(B, cin, cout, L):
     """mvp_pointwise_mfma (float32 MFMA, k-ordered fmaf chain) against the plain
     PyTorch fp32 convolution: y = W x (+ bias, ReLU, residual), and the data
@@ -574,7 +575,9 @@ def test_pointwise_mfma_matches_torch(B, cin, cout, L):
 
 
 @pytest.mark.parametrize("B,cin,cout,L,bias", [(4, 128, 256, 768, True), (64, 64, 128, 3072, False), (3, 515, 130, 388, True),
-                                               (2, 1090, 256, 2048, True), (5, 40, 33, 16, True), (1, 256, 64, 20, False)])
+                                               (2, 1090, 256, 2048, True), (5, 40, 33, 16, True), (1, 256, 64, 20, False),
+                                               (4, 3, 128, 2048, True), (4, 68, 2, 3072, True), (4, 272, 8, 768, True),
+                                               (64, 512, 1024, 512, True), (2, 1, 1, 4, True)])
 def test_pointwise_wgrad_mfma_matches_torch(B, cin, cout, L, bias):
     """mvp_pointwise_wgrad_mfma (weight + bias gradient as one MFMA GEMM over all positions, partial
     tiles summed in a fixed order) against float64; with the ReLU mask; bit-reproducible."""
@@ -622,10 +625,12 @@ def test_pointwise_conv_autograd_through_mfma():
     from mvp_benchmark_amd import pointwise as pw
     from mvp_benchmark_amd.pointwise import PointwiseConv1d, pointwise_conv
     torch.manual_seed(0)
-    min_positions, pw.MFMA_WGRAD_MIN_POSITIONS = pw.MFMA_WGRAD_MIN_POSITIONS, 0       # small batches through the MFMA weight gradient too
+    defaults = (pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN, pw.MFMA_WGRAD_MIN_POSITIONS)
+    pw.MFMA_WGRAD_MIN_POSITIONS = 0                                                    # small batches through the MFMA weight gradient too
     for cin, cout, L, dgrad, wmin in ((128, 256, 768, False, 513), (128, 256, 768, True, 32), (64, 64, 512, True, 32),
                                       (256, 3, 300, False, 513), (24, 24, 256, False, 513), (515, 128, 384, True, 32),
-                                      (1090, 256, 256, False, 513), (96, 160, 1000, True, 32)):
+                                      (1090, 256, 256, False, 513), (96, 160, 1000, True, 32), (272, 8, 768, True, 1),
+                                      (3, 128, 512, True, 1), (8, 128, 768, True, 1), (68, 2, 1024, True, 1)):
         pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN = dgrad, wmin, True          # every route of the backward pass
         layer = PointwiseConv1d(cin, cout).to(DEV)
         x = torch.randn(4, cin, L, device=DEV, requires_grad=True)
@@ -639,5 +644,4 @@ def test_pointwise_conv_autograd_through_mfma():
             for a, r, name in ((y, yr, "y"), (gx, rx, "gx"), (gw, rw, "gw"), (gb, rb, "gb")):
                 scale = r.abs().max().item() + 1e-6
                 assert (a - r).abs().max().item() < 2e-5 * scale * math.sqrt(max(cin, L)), (cin, cout, relu, name)
-    pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN = True, 32, True               # the defaults
-    pw.MFMA_WGRAD_MIN_POSITIONS = min_positions
+    pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN, pw.MFMA_WGRAD_MIN_POSITIONS = defaults

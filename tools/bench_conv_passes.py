@@ -13,6 +13,7 @@ from mvp_benchmark_amd.pointwise import mfma_linear, mfma_wgrad
 dev = "cuda:0"
 
 name = sys.argv[1] if len(sys.argv) > 1 else "vrcnet"
+MINCH = int(sys.argv[2]) if len(sys.argv) > 2 else 32      # 1: also the layers with fewer than 32 input or output channels
 
 
 def record_shapes(name):
@@ -39,7 +40,7 @@ def record_shapes(name):
     finally:
         F.conv1d, F.conv2d = o1, o2
     torch.cuda.synchronize()
-    return sorted(((k + (n,)) for k, n in shapes.items() if k[1] >= 32 and k[3] >= 32 and k[2] % 4 == 0),
+    return sorted(((k + (n,)) for k, n in shapes.items() if min(k[1], k[3]) >= MINCH and (MINCH >= 32 or min(k[1], k[3]) < 32) and k[2] % 4 == 0),
                   key=lambda s: -s[0] * s[1] * s[2] * s[3] * s[4])
 
 
