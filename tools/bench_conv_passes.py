@@ -45,8 +45,9 @@ def record_shapes(name):
 
 
 from mvp_benchmark_amd import pointwise as _pw
-_pw.MFMA_TRAIN = False      # record through the library route (F.conv*)
+_pw.MFMA_TRAIN = _pw.USE_MFMA = False      # record through the library route (F.conv*)
 shapes = record_shapes(name)
+_pw.USE_MFMA = True
 
 
 def timeit(fn, reps=20):
