@@ -228,3 +228,17 @@ def test_emd_records_reads_the_scratch_tail():
     assert got["next_round"].tolist() == [0, 0, 300] and got["unassigned"].tolist() == [150, 90, 201]
     assert got["first_handover"].tolist() == [70, 0, 101]
     assert got["final_width"].tolist() == [8, 0, 4] and got["final_launch"].tolist() == [2, 0, 1]
+
+
+def test_pointwise_routing_rules():
+    """mvp_benchmark_amd/pointwise.py: which per-cloud GEMMs go to the MFMA kernels (host logic, no GPU):
+    short reductions always; long ones only with a chip's worth of 128 x 128 output tiles and full column tiles."""
+    from mvp_benchmark_amd import pointwise as pw
+    assert pw.MFMA_TRAIN and pw.MFMA_DGRAD and pw.MFMA_MIN_CH == 1
+    fits = pw._gemm_fits
+    assert fits(64, 1024, 512, 2048) and fits(64, 512, 1536, 384)          # VRCNet's widest layers
+    assert fits(32, 48, 240, 1024)                                         # few workgroups but a short reduction
+    assert not fits(32, 1024, 2824, 64) and not fits(32, 1024, 1800, 64)   # ECG, 64-point level: half-empty column tiles
+    assert not fits(32, 768, 1864, 256)                                    # 6 x 2 x 32 = 384 workgroups < 512
+    assert not fits(64, 128, 512, 384) and not fits(64, 32, 512, 384)      # one row of tiles, reduction of 512
+    assert fits(64, 512, 128, 384)                                         # the same layers' data gradients
