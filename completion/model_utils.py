@@ -250,48 +250,81 @@ def edge_preserve_features(feature_input, p_idx, pn_idx):
     return torch.cat((center_feature, neighbor_feature), 1)
 
 
+def fps_centres(point_input, num_samples):
+    """The FPS half of edge_preserve_geometry: p_idx (B,S) int32 and the centres' coordinates (B,S,3)."""
+    p_idx = furthest_point_sample(point_input, num_samples)
+    point_output = gather_points(point_input.transpose(1, 2).contiguous(), p_idx).transpose(1, 2).contiguous()
+    return p_idx, point_output
+
+
+def _tensors(value):
+    for t in (value if isinstance(value, (tuple, list)) else (value,)):
+        for u in (t if isinstance(t, (tuple, list)) else (t,)):
+            if torch.is_tensor(u):
+                yield u
+
+
 class GeometryAhead:
     """Runs the coordinate-only part of a point U-Net -- FPS, kNN graphs, three_nn weights of every
-    level: latency-bound kernels on a quarter of the CUs, none of them differentiable -- on a SIDE
-    stream while the main stream runs the levels' convolutions; `take(key)` makes the main stream wait
-    for exactly the item it needs next.  On the CPU (or with MVP_NO_SIDE_STREAM) everything runs in
-    line.  The reference computes the same items at the same places in its forward
+    level: latency-bound kernels on a quarter of the CUs, none of them differentiable -- on SIDE
+    streams while the main stream runs the levels' convolutions; `take(key)` makes the main stream wait
+    for exactly the item it needs next.  Two lanes (round 4): lane 0 carries the FPS chain of the
+    levels (m - 1 sequential rounds on <= 64 CUs each), lane 1 the neighbour searches, which only need
+    a level's centres (`after=`) -- the searches of level l run beside the FPS of level l + 1 instead
+    of queueing behind it.  On the CPU (or with MVP_NO_SIDE_STREAM) everything runs in line.  The
+    reference computes the same items at the same places in its forward
     (completion/models/vrcnet.py:236-296); only the order of independent launches differs."""
 
     _streams = {}
+    LANES = 2
 
     def __init__(self, device):
-        self.items, self.events = {}, {}
+        self.items, self.events, self.lane_of = {}, {}, {}
         self.main = self.side = None
         if device.type == "cuda" and not os.environ.get("MVP_NO_SIDE_STREAM"):
             self.main = torch.cuda.current_stream(device)
             self.side = GeometryAhead._streams.get(device)
             if self.side is None:
-                self.side = GeometryAhead._streams[device] = torch.cuda.Stream(device)
-            self.side.wait_stream(self.main)          # the coordinates are the main stream's
+                self.side = GeometryAhead._streams[device] = [torch.cuda.Stream(device) for _ in range(self.LANES)]
+            for lane in self.side:
+                lane.wait_stream(self.main)           # the coordinates are the main stream's
 
-    def run(self, key, fn):
-        """value of fn() under `key`, computed (without autograd) on the side stream."""
+    def run(self, key, fn, lane=0, after=()):
+        """value of fn() under `key`, computed (without autograd) on side stream `lane` once the
+        items `after` (computed on other lanes) are there."""
+        if os.environ.get("MVP_ONE_SIDE_STREAM"):
+            lane = 0
         with torch.no_grad():
             if self.side is None:
                 self.items[key] = fn()
                 return self.items[key]
-            with torch.cuda.stream(self.side):
+            stream = self.side[lane]
+            for dep in after:
+                if self.lane_of[dep] != lane:
+                    stream.wait_event(self.events[dep])
+                    for u in _tensors(self.items[dep]):
+                        u.record_stream(stream)       # allocated on the other lane's pool, read here
+            with torch.cuda.stream(stream):
                 value = fn()
                 ev = torch.cuda.Event()
-                ev.record(self.side)
-        self.items[key], self.events[key] = value, ev
-        return value     # (for the side stream's own next step; the main stream goes through take())
+                ev.record(stream)
+        self.items[key], self.events[key], self.lane_of[key] = value, ev, lane
+        return value     # (for the side streams' own next steps; the main stream goes through take())
 
     def take(self, key):
         value = self.items[key]
         if self.side is not None:
             self.main.wait_event(self.events[key])
-            for t in (value if isinstance(value, (tuple, list)) else (value,)):
-                for u in (t if isinstance(t, (tuple, list)) else (t,)):
-                    if torch.is_tensor(u):
-                        u.record_stream(self.main)   # allocated on the side stream's pool, used here
+            for u in _tensors(value):
+                u.record_stream(self.main)           # allocated on a side stream's pool, used here
         return value
+
+    def join(self):
+        """The main stream waits for everything issued (a lane whose last item nobody took would
+        otherwise be left dangling under stream capture)."""
+        if self.side is not None:
+            for lane in self.side:
+                self.main.wait_stream(lane)
 
 
 def three_nn_upsampling(target_points, source_points):

@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from model_utils import (GeometryAhead, edge_preserve_features, edge_preserve_geometry, edge_preserve_sampling,
+from model_utils import (GeometryAhead, edge_preserve_features, edge_preserve_geometry, edge_preserve_sampling, fps_centres,
+                         knn_point_idx,
                          get_edge_features, knn, three_nn_upsampling)
 from mm3d_pn2 import three_interpolate
 from models._common import dense, pointwise1d, pointwise2d
@@ -142,9 +143,16 @@ class EF_encoder(nn.Module):
         geo = GeometryAhead(x.device)
         pts = [geo.run(("pts", 0), lambda: xyz.transpose(1, 2).contiguous())]       # level-0 coordinates (B,N,3)
         for level in range(3):
-            pts.append(geo.run(("pool", level), lambda: edge_preserve_geometry(pts[level], self.hierarchy[level], self.k))[2])
+            # lane 0: the FPS chain; lane 1: the centres' neighbour searches and the way up's three_nn
+            p_idx, centres = geo.run(("centres", level), lambda: fps_centres(pts[level], self.hierarchy[level]))
+            src = pts[level]
+            pts.append(centres)
+            geo.run(("pool", level), lambda: (p_idx, knn_point_idx(int(min(self.k, src.size(1))), src, centres).detach().int(),
+                                              centres), lane=1,
+                    after=[("centres", level), ("centres", level - 1) if level > 0 else ("pts", 0)])
         for level in (2, 1, 0):
-            geo.run(("up", level), lambda: three_nn_upsampling(pts[level], pts[level + 1]))
+            geo.run(("up", level), lambda: three_nn_upsampling(pts[level], pts[level + 1]), lane=1,
+                    after=[("centres", level), ("centres", level - 1) if level > 0 else ("pts", 0)])
 
         # ---- down: level features f[l] (before pooling), pooled inputs
         x0 = F.relu(self.conv1(x))

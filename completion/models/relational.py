@@ -14,7 +14,8 @@ down, three_nn + three_interpolate on the way up.
 import torch
 import torch.nn as nn
 
-from model_utils import (GeometryAhead, aggregate_shared, edge_preserve_features, edge_preserve_geometry,
+from model_utils import (GeometryAhead, aggregate_shared, edge_preserve_features, edge_preserve_geometry, fps_centres,
+                         knn_point_idx,
                          edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling)
 from mm3d_pn2 import three_interpolate
 from models._common import dense, pointwise2d
@@ -161,13 +162,20 @@ class SA_SKN_Res_encoder(nn.Module):
         # values as the in-line order of the reference; none of these operators is differentiable.
         geo = GeometryAhead(features.device)
         pts = [geo.run(("pts", 0), lambda: xyz.transpose(1, 2).contiguous())]       # (B, N, 3) per level
-        geo.run(("graph", 0), lambda: self._graphs(xyz))
+        geo.run(("graph", 0), lambda: self._graphs(xyz), lane=1)
         for level in range(1, 4):
-            pool = geo.run(("pool", level), lambda: edge_preserve_geometry(pts[-1], self.pts_num[level], self.pk))
-            pts.append(pool[2])
-            geo.run(("graph", level), lambda: self._graphs(pts[-1].transpose(1, 2).contiguous()))
+            # lane 0: the FPS chain of the levels; lane 1: every neighbour search, as soon as its centres exist
+            p_idx, centres = geo.run(("centres", level), lambda: fps_centres(pts[-1], self.pts_num[level]))
+            src = pts[-1]
+            pts.append(centres)
+            geo.run(("pool", level), lambda: (p_idx, knn_point_idx(int(min(self.pk, src.size(1))), src, centres).detach().int(),
+                                              centres), lane=1,
+                    after=[("centres", level), ("centres", level - 1) if level > 1 else ("pts", 0)])
+            geo.run(("graph", level), lambda: self._graphs(centres.transpose(1, 2).contiguous()), lane=1,
+                    after=[("centres", level)])
         for level in (2, 1, 0):
-            geo.run(("up", level), lambda: three_nn_upsampling(pts[level], pts[level + 1]))
+            geo.run(("up", level), lambda: three_nn_upsampling(pts[level], pts[level + 1]), lane=1,
+                    after=[("pts", 0)] + [("centres", l) for l in (level, level + 1) if l > 0])
 
         skips = [self.af(units[0](features.unsqueeze(2), geo.take(("graph", 0))))]
         for level in range(1, 4):
