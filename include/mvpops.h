@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 12
+#define MVP_ABI_VERSION 13
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -411,7 +411,9 @@ int mvp_pointwise_dgrad(int b, int cin, int cout, int len, const float *weight,
  * reference, which calls cuDNN through nn.Conv1d / nn.Conv2d(kernel_size=1) and
  * separate bias / ReLU / add / max kernels (completion/model_utils.py:26-55,
  * completion/models/vrcnet.py:21-57, ecg.py:36-65, pcn.py).
- *   x (b, cin, len), w (cout, cin) [w_kmajor = 0] or (cin, cout) [w_kmajor = 1]
+ *   x (b, cin, len), w (cout, cin) [w_kmajor = 0] or (cin, cout) [w_kmajor = 1],
+ *         its rows ldw floats apart (0 = dense; a (cout, cin) weight with cin % 4 != 0
+ *         is read with 16-byte loads when the caller pads its rows to ldw % 4 == 0)
  *   xmask (b, cin, len) or NULL: x is taken as 0 where xmask <= 0 (the data
  *         gradient of a fused ReLU: x = grad_out, xmask = the layer's output)
  *   t[b,co,l] = sum_ci w(co,ci) x[b,ci,l] + bias[co]        (bias may be NULL)
@@ -424,7 +426,7 @@ int mvp_pointwise_dgrad(int b, int cin, int cout, int len, const float *weight,
  * aligned.  The data gradient of the plain map is the same call with the forward
  * weight, cin and cout swapped and w_kmajor = 1. */
 int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float *x,
-                       const float *xmask, const float *w, int w_kmajor,
+                       const float *xmask, const float *w, int ldw, int w_kmajor,
                        const float *bias, const float *residual, int relu,
                        int group, float *y, void *stream);
 

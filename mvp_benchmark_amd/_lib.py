@@ -49,13 +49,13 @@ SIGNATURES = {
     "mvp_pointwise_wgrad": "iiiipppppq",
     "mvp_pointwise_dgrad": "iiiippp",
     "mvp_kabsch_svd3": "ipppppp",
-    "mvp_pointwise_mfma": "iiiipppippiip",
+    "mvp_pointwise_mfma": "iiiipppiippiip",
     "mvp_pointwise_wgrad_mfma": "iiiippppppq",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 12  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 13  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
 EMD_DEFAULT_SPLIT = 5

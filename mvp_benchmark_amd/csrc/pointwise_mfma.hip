@@ -180,7 +180,7 @@ __device__ __forceinline__ long long pw_work_item(long long total) {
 // row-major [kXC: the data gradient multiplies by W^T]; X, xmask (K x N), Y per cloud.
 template <int TM, int TN, int BK, int AMODE, bool MASKED>
 __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
-    int M, int N, int K, int nb, const float *__restrict__ a, int a_vec, const float *__restrict__ x,
+    int M, int N, int K, int nb, const float *__restrict__ a, int a_ld, int a_vec, const float *__restrict__ x,
     const float *__restrict__ xmask, const float *__restrict__ bias, const float *__restrict__ residual, int relu,
     int group, float *__restrict__ y) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
   const int wm = wave >> 1, wn = wave & 1, lrow = lane & 31, lk = lane >> 5;
   const float *xb = x + (size_t)cloud * K * N;
   const float *mb = xmask ? xmask + (size_t)cloud * K * N : nullptr;
-  const size_t lda = AMODE == kKC ? K : M;
+  const size_t lda = a_ld;
 
   if (t < BM) sbias[t] = (bias && m0 + t < M) ? bias[m0 + t] : 0.f;
 
@@ -515,26 +515,28 @@ extern "C" int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const
 }
 
 extern "C" int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float *x, const float *xmask,
-                                  const float *w, int w_kmajor, const float *bias, const float *residual, int relu,
-                                  int group, float *y, void *stream) {
+                                  const float *w, int ldw, int w_kmajor, const float *bias, const float *residual,
+                                  int relu, int group, float *y, void *stream) {
   if (b < 0 || cin <= 0 || cout <= 0 || len < 0) return MVP_EBADSHAPE;
   if (group < 1 || group > 32 || (group & (group - 1)) != 0) return MVP_EBADSHAPE;
   if ((len & 3) != 0 || len % group != 0 || b > 65535) return MVP_EBADSHAPE;
   if (b == 0 || len == 0) return MVP_OK;
   if (!x || !w || !y) return MVP_EBADARG;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(xmask) & 15) != 0) return MVP_EBADARG;
-  if (w_kmajor && ((cout & 3) != 0 || (reinterpret_cast<uintptr_t>(w) & 15) != 0)) return MVP_EBADARG;
-  if (!w_kmajor && (cin & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) != 0) return MVP_EBADARG;
+  if (ldw == 0) ldw = w_kmajor ? cout : cin;                    // dense rows
+  if (ldw < (w_kmajor ? cout : cin)) return MVP_EBADARG;
+  if (w_kmajor && ((cout & 3) != 0 || (ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(w) & 15) != 0)) return MVP_EBADARG;
+  if (!w_kmajor && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) != 0) return MVP_EBADARG;
   hipStream_t st = as_stream(stream);
   const bool big = cout > 64;
   const int bm = big ? 128 : 64;
   const long long total = (long long)((cout + bm - 1) / bm) * ((len + 127) / 128) * b;
   const long long nwg = (total + 7) / 8 * 8;
   if (nwg > 2147483647LL) return MVP_EBADSHAPE;
-  const int a_vec = w_kmajor ? 1 : ((cin & 3) == 0);
+  const int a_vec = w_kmajor ? 1 : ((ldw & 3) == 0);            // 16-byte loads along k need aligned rows
 #define MVP_MM_(TM, MODE, MK)                                                                                       \
   hipLaunchKernelGGL((pointwise_mfma_kernel<TM, 2, 16, MODE, MK>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, cout, \
-                     len, cin, b, w, a_vec, x, xmask, bias, residual, relu, group, y)
+                     len, cin, b, w, ldw, a_vec, x, xmask, bias, residual, relu, group, y)
 #define MVP_MM(TM, MODE)              \
   do {                                \
     if (xmask) MVP_MM_(TM, MODE, true); \
