@@ -166,7 +166,7 @@ class EF_encoder(nn.Module):
             f.append(torch.cat((y, pooled), 1))
 
         # ---- bottleneck: global feature broadcast back onto the coarsest level
-        g = self.gf_conv(f[3]).max(dim=-1)[0]
+        g = self.gf_conv.max_over_positions(f[3])          # gf_conv(f[3]).max(dim=-1)[0], sparse backward
         g = F.relu(self.fc2(F.relu(self.fc1(g)))).unsqueeze(2).expand(-1, -1, self.hierarchy[2])
         up = F.relu(self.conv5(torch.cat((g, f[3]), 1)))
 

@@ -183,7 +183,7 @@ class SA_SKN_Res_encoder(nn.Module):
             x = edge_preserve_features(skips[-1].squeeze(2).contiguous(), p_idx, pn_idx).unsqueeze(2)
             skips.append(self.af(units[level](x, geo.take(("graph", level)))))
 
-        g = self.conv5(skips[3]).max(dim=-1)[0].view(batch_size, -1)
+        g = self.conv5.max_over_positions(skips[3])        # conv5(skips[3]).max over the points, sparse backward
         g = self.dropout(self.af(self.fc2(self.dropout(self.af(self.fc1(g))))))
         g = g.unsqueeze(2).expand(-1, -1, self.pts_num[3]).unsqueeze(2)
 

@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 13
+#define MVP_ABI_VERSION 14
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -444,6 +444,20 @@ int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const float *x,
                              const float *gy, const float *gymask, float *gw,
                              float *gb, void *scratch, long long scratch_bytes,
                              void *stream);
+
+/* Backward pass of a 1x1 convolution followed by a max over the positions,
+ * v[b][co] = max_l (W x + bias)[b][co][l] (the PointNet stage: completion/models/pcn.py:25-31,
+ * conv5 of vrcnet.py's relational encoder, ecg.py's gf_conv), through the b * cout winning
+ * positions only:
+ *   gw[co][ci]   = sum_b g[b][co] x[b][ci][idx[b][co]],   gb[co] = sum_b g[b][co]
+ *   gx[b][ci][l] = sum_{co : idx[b][co] = l} g[b][co] w[co][ci]     (0 elsewhere; every entry written)
+ * x (b,cin,len), w (cout,cin), g (b,cout) = the gradient of v, idx (b,cout) int32 = the position
+ * torch.max reported.  gx, gw may each be NULL (that gradient is not needed), gb too.
+ * len <= 16384, cout <= 4096.  Fixed summation orders: bit-reproducible.  The reference lets cuDNN run
+ * its dense data- and weight-gradient passes on the max's gradient, a tensor of zeros. */
+int mvp_pointwise_max_backward(int b, int cin, int cout, int len, const float *x,
+                               const float *w, const float *g, const int *idx,
+                               float *gx, float *gw, float *gb, void *stream);
 
 /* ------------------------------------------------ registration (DCP) head */
 

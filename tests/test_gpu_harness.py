@@ -645,3 +645,42 @@ def test_pointwise_conv_autograd_through_mfma():
                 scale = r.abs().max().item() + 1e-6
                 assert (a - r).abs().max().item() < 2e-5 * scale * math.sqrt(max(cin, L)), (cin, cout, relu, name)
     pw.MFMA_DGRAD, pw.MFMA_WGRAD_MIN_CIN, pw.MFMA_TRAIN, pw.MFMA_WGRAD_MIN_POSITIONS = defaults
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,L", [(8, 512, 1024, 2048), (3, 40, 33, 20), (64, 128, 96, 384), (2, 7, 9, 16384),
+                                          (5, 64, 1024, 64), (1, 3, 2, 1)])
+def test_pointwise_conv_max_backward_kernels(B, cin, cout, L):
+    """mvp_pointwise_max_backward (the conv -> max-over-positions backward through the B * Cout winning positions
+    only) against plain autograd on conv(x).max(dim=2): same values, gradients at float32 summation-order
+    tolerance, bit-reproducible; half of the columns duplicated so that maxima are attained twice (the gradient
+    goes to the position torch.max reports); (2, 7, 9, 16384) exceeds the kernel's LDS budget and takes the
+    PyTorch formulation of the same sparse pass."""
+    from mvp_benchmark_amd.pointwise import PointwiseConv1d
+    torch.manual_seed(B * 31 + L)
+    layer = PointwiseConv1d(cin, cout).to(DEV)
+    x = torch.randn(B, cin, L, device=DEV)
+    if L >= 4:
+        x[..., L // 2:L // 2 * 2] = x[..., :L // 2]
+    x.requires_grad_()
+    go = torch.randn(B, cout, device=DEV)
+    params = (x, layer.weight, layer.bias)
+    got = layer.max_over_positions(x)
+    y = layer(x)
+    ref, idx = y.max(dim=2)
+    assert torch.equal(got, ref)
+    g1 = torch.autograd.grad(got, params, go)
+    g2 = torch.autograd.grad(got.clone() if False else layer.max_over_positions(x), params, go)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)                                         # fixed summation order
+    # float64 statement of the same function, gradient routed to the positions torch.max reported
+    xd, wd, bd = x.detach().double(), layer.weight.detach().double().view(cout, cin), layer.bias.detach().double()
+    god = go.double()
+    cols = torch.gather(xd, 2, idx.unsqueeze(1).expand(B, cin, cout))    # [b, ci, co] = x[b, ci, idx[b, co]]
+    want_w = torch.einsum("bo,bio->oi", god, cols)
+    want_x = torch.zeros_like(xd).scatter_add_(2, idx.unsqueeze(1).expand(B, cin, cout), god.unsqueeze(1) * wd.t().unsqueeze(0))
+    tol = 1e-5 * max(1.0, float(want_w.abs().max()))
+    assert (g1[1].double().view(cout, cin) - want_w).abs().max().item() < tol
+    assert (g1[2].double() - god.sum(0)).abs().max().item() < 1e-5 * max(1.0, float(god.sum(0).abs().max()))
+    assert (g1[0].double() - want_x).abs().max().item() < 1e-5 * max(1.0, float(want_x.abs().max()))
+    assert bd.shape == (cout,)

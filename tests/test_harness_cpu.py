@@ -375,6 +375,71 @@ def test_pcn_forward_matches_reference_golden():
     np.testing.assert_allclose(res.numpy(), g["result"], rtol=1e-5, atol=1e-6)
 
 
+def test_pcn_folded_conv1_equals_concatenated_formulation():
+    """PCN_decoder._folded_conv1 splits conv1 over its three kinds of input channels (grid patch, coarse
+    point, global feature) instead of convolving the concatenated (B, 1029, Nf) tensor the reference builds
+    (pcn.py:60-68).  Same parameters, same function: compare with the concatenation written out, in float64,
+    values and every gradient."""
+    from models.pcn import PCN_decoder
+    torch.manual_seed(5)
+    B, Nc, S = 3, 8, 4
+    dec = PCN_decoder(Nc, Nc * S, S, 2 + 3 + 1024).double()
+    x = torch.randn(B, 1024, dtype=torch.float64, requires_grad=True)
+    coarse = torch.randn(B, 3, Nc, dtype=torch.float64, requires_grad=True)
+    got = dec._folded_conv1(x, coarse)
+    center = coarse.unsqueeze(3).expand(-1, -1, -1, S).reshape(B, 3, Nc * S)
+    grid_feat = dec.grid.detach().unsqueeze(0).repeat(B, 1, Nc)
+    feat = torch.cat((grid_feat, center, x.unsqueeze(2).expand(-1, -1, Nc * S)), 1)
+    ref = torch.relu(torch.nn.functional.conv1d(feat, dec.conv1.weight, dec.conv1.bias))
+    assert got.shape == ref.shape == (B, 512, Nc * S)
+    assert torch.allclose(got, ref, rtol=1e-10, atol=1e-10)
+    params = (x, coarse, dec.conv1.weight, dec.conv1.bias)
+    for a, b in zip(torch.autograd.grad(got.square().sum(), params), torch.autograd.grad(ref.square().sum(), params)):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
+def test_pcn_encoder_split_conv3_equals_concatenated_formulation():
+    """PCN_encoder applies conv3 to the per-point half of its input and adds the pooled half's product as one
+    vector per cloud; the reference (pcn.py:25-29) tiles the pooled feature, concatenates and convolves."""
+    from models.pcn import PCN_encoder
+    torch.manual_seed(6)
+    enc = PCN_encoder().double()
+    x = torch.randn(2, 3, 50, dtype=torch.float64, requires_grad=True)
+    got = enc(x)
+    F = torch.nn.functional
+    local = F.conv1d(torch.relu(F.conv1d(x, enc.conv1.weight, enc.conv1.bias)), enc.conv2.weight, enc.conv2.bias)
+    cat = torch.cat((local, local.max(dim=2, keepdim=True)[0].expand(-1, -1, 50)), 1)
+    ref = F.conv1d(torch.relu(F.conv1d(cat, enc.conv3.weight, enc.conv3.bias)), enc.conv4.weight, enc.conv4.bias).max(dim=2)[0]
+    assert torch.allclose(got, ref, rtol=1e-10, atol=1e-10)
+    params = (x,) + tuple(enc.parameters())
+    for a, b in zip(torch.autograd.grad(got.square().sum(), params), torch.autograd.grad(ref.square().sum(), params)):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
+def test_pointwise_conv_max_matches_autograd():
+    """pointwise_conv_max (values, and the gather / scatter backward through the winning positions only) against
+    conv(x).max over the positions under plain autograd; 1-D and (B, C, 1, N) inputs, with and without bias,
+    repeated maxima included (the gradient goes to the position torch.max reports)."""
+    from mvp_benchmark_amd.pointwise import PointwiseConv1d, PointwiseConv2d
+    torch.manual_seed(11)
+    for layer, shape in ((PointwiseConv1d(12, 20), (3, 12, 37)), (PointwiseConv2d(7, 9, bias=False), (2, 7, 1, 16)),
+                         (PointwiseConv1d(5, 6), (2, 5, 8))):
+        layer = layer.double()
+        x = torch.randn(*shape, dtype=torch.float64)
+        if shape == (2, 5, 8):
+            x[..., 4:] = x[..., :4]                        # every maximum is attained twice
+        x.requires_grad_()
+        got = layer.max_over_positions(x)
+        ref = layer(x).flatten(2).max(dim=2)[0]
+        assert torch.equal(got, ref)
+        go = torch.randn_like(ref)
+        params = (x,) + tuple(layer.parameters())
+        for a, b in zip(torch.autograd.grad(got, params, go), torch.autograd.grad(ref, params, go)):
+            assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+    with torch.no_grad():
+        assert torch.equal(layer.max_over_positions(x), ref)
+
+
 def test_sa_module_equals_gather_then_map_formulation():
     """SA_module maps the points with conv2 / conv3 before gathering the
     neighbours; the reference (vrcnet.py:36-57) gathers first.  Same parameters,
