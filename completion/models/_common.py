@@ -1,10 +1,11 @@
 """Pieces shared by the three completion networks: layer factories and the
 loss / metric tail of Model.forward (identical in the reference's pcn.py
 :93-112, ecg.py:233-253 and vrcnet.py:519-526, restated once here)."""
+import torch
 import torch.nn as nn
 
 from model_utils import calc_cd, calc_emd
-from mvp_benchmark_amd.pointwise import PointwiseConv1d, PointwiseConv2d
+from mvp_benchmark_amd.pointwise import PointwiseConv1d, PointwiseConv2d, pointwise_conv
 
 
 def pointwise1d(c_in, c_out, bias=True):
@@ -20,6 +21,23 @@ def pointwise2d(c_in, c_out, bias=True):
 
 
 dense = nn.Linear
+
+
+def conv_global_concat(conv, global_vec, feats, relu=False, global_first=True):
+    """conv(cat((global_vec tiled over the positions, feats), 1)) [then ReLU] without the concatenation: a 1x1
+    convolution is linear, so the global feature's share of the product is ONE vector per cloud,
+        W [g; f](b, :, n) = W[:, :Cg] g(b) + bias  +  W[:, Cg:] f(b, :, n),
+    computed once (a (B, Cg) x (Cg, Cout) product) and added to the convolution of the per-point channels --
+    the reference tiles the vector N times and pays Cg * Cout multiply-adds per point for it (vrcnet.py conv6,
+    ecg.py conv5, pcn.py conv3).  conv: a PointwiseConv1d / 2d over Cg + Cf channels, global_vec (B, Cg), feats
+    (B, Cf, N) / (B, Cf, 1, N).  Same parameters, same function up to float32 summation order."""
+    cout, cg = conv.out_channels, global_vec.size(1)
+    w = conv.weight.view(cout, -1)
+    wg, wf = (w[:, :cg], w[:, cg:]) if global_first else (w[:, w.size(1) - cg:], w[:, :w.size(1) - cg])
+    per_cloud = nn.functional.linear(global_vec, wg, conv.bias)
+    tail = (1,) * (feats.dim() - 2)
+    h = pointwise_conv(feats, wf.contiguous().view(cout, -1, *tail)) + per_cloud.view(per_cloud.shape + tail)
+    return torch.relu_(h) if relu else h
 
 
 def shape_loss(kind, pred, gt):

@@ -15,8 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from model_utils import gen_grid_up
-from models._common import dense, eval_outputs, pointwise1d, shape_loss
-from mvp_benchmark_amd.pointwise import pointwise_conv
+from models._common import conv_global_concat, dense, eval_outputs, pointwise1d, shape_loss
 
 
 class PCN_encoder(nn.Module):
@@ -38,11 +37,7 @@ class PCN_encoder(nn.Module):
         # conv3 over cat(local, pooled tiled N times) (the reference, pcn.py:25-29) = W[:, :256] local + one vector
         # per cloud (W[:, 256:] pooled + bias): half the reduction, no (B, 512, N) concatenation; same parameters,
         # same function up to float32 summation order (test_pcn_encoder_split_conv3_equals_concatenated_formulation)
-        half = local.size(1)
-        w = self.conv3.weight.view(self.conv3.out_channels, -1)
-        per_cloud = F.linear(pooled, w[:, half:], self.conv3.bias)     # (B, 512)
-        h = pointwise_conv(local, w[:, :half].contiguous().unsqueeze(2))
-        h = torch.relu_(h + per_cloud.unsqueeze(2))
+        h = conv_global_concat(self.conv3, pooled, local, relu=True, global_first=False)
         return self.conv4.max_over_positions(h)           # conv4(h).max(dim=2)[0], sparse backward (pointwise.py)
 
 

@@ -18,7 +18,7 @@ from model_utils import (GeometryAhead, aggregate_shared, edge_preserve_features
                          knn_point_idx,
                          edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling)
 from mm3d_pn2 import three_interpolate
-from models._common import dense, pointwise2d
+from models._common import conv_global_concat, dense, pointwise2d
 
 
 class SA_module(nn.Module):
@@ -185,9 +185,9 @@ class SA_SKN_Res_encoder(nn.Module):
 
         g = self.conv5.max_over_positions(skips[3])        # conv5(skips[3]).max over the points, sparse backward
         g = self.dropout(self.af(self.fc2(self.dropout(self.af(self.fc1(g))))))
-        g = g.unsqueeze(2).expand(-1, -1, self.pts_num[3]).unsqueeze(2)
-
-        x = self.conv6(torch.cat([g, skips[3]], 1), relu=True)
+        # conv6 over cat(g tiled over the points, skips[3]) (vrcnet.py:283-285): the global feature's share is one
+        # vector per cloud (models/_common.py: conv_global_concat)
+        x = conv_global_concat(self.conv6, g, skips[3], relu=True)
         for level, conv in ((2, self.conv7), (1, self.conv8), (0, self.conv9)):
             idx, weight = geo.take(("up", level))
             x = three_interpolate(x.squeeze(2).contiguous(), idx, weight).unsqueeze(2)

@@ -440,6 +440,30 @@ def test_pointwise_conv_max_matches_autograd():
         assert torch.equal(layer.max_over_positions(x), ref)
 
 
+def test_conv_global_concat_equals_concatenated_formulation():
+    """models/_common.py: conv_global_concat (the global feature's share of a 1x1 convolution as one vector per
+    cloud) against the convolution of the concatenated tensor the reference builds (vrcnet.py conv6, ecg.py conv5:
+    global first; pcn.py conv3: global last), float64, values and every gradient, 1-D and (B, C, 1, N) layouts."""
+    from models._common import conv_global_concat, pointwise1d, pointwise2d
+    torch.manual_seed(9)
+    F = torch.nn.functional
+    for make, shape, first in ((pointwise1d, (3, 10, 17), True), (pointwise1d, (2, 6, 9), False), (pointwise2d, (2, 8, 1, 12), True)):
+        B, cf, n, cg = shape[0], shape[1], shape[-1], 5
+        conv = make(cg + cf, 7).double()
+        g = torch.randn(B, cg, dtype=torch.float64, requires_grad=True)
+        f = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+        tiled = g.view(B, cg, *([1] * (len(shape) - 2))).expand(B, cg, *shape[2:])
+        cat = torch.cat((tiled, f) if first else (f, tiled), 1)
+        for relu in (False, True):
+            got = conv_global_concat(conv, g, f, relu=relu, global_first=first)
+            ref = conv(cat)
+            ref = torch.relu(ref) if relu else ref
+            assert torch.allclose(got, ref, rtol=1e-10, atol=1e-10)
+            params = (g, f) + tuple(conv.parameters())
+            for a, b in zip(torch.autograd.grad(got.square().sum(), params), torch.autograd.grad(ref.square().sum(), params)):
+                assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
 def test_sa_module_equals_gather_then_map_formulation():
     """SA_module maps the points with conv2 / conv3 before gathering the
     neighbours; the reference (vrcnet.py:36-57) gathers first.  Same parameters,
