@@ -453,11 +453,16 @@ int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const float *x,
  *   gx[b][ci][l] = sum_{co : idx[b][co] = l} g[b][co] w[co][ci]     (0 elsewhere; every entry written)
  * x (b,cin,len), w (cout,cin), g (b,cout) = the gradient of v, idx (b,cout) int32 = the position
  * torch.max reported.  gx, gw may each be NULL (that gradient is not needed), gb too.
- * len <= 16384, cout <= 4096.  Fixed summation orders: bit-reproducible.  The reference lets cuDNN run
- * its dense data- and weight-gradient passes on the max's gradient, a tensor of zeros. */
+ * len <= 16384, cout <= 4096.  Fixed summation orders: bit-reproducible.  scratch (may be NULL):
+ * mvp_pointwise_max_backward_scratch_bytes(...) bytes (0 = shape not covered by the staged pass) in which the
+ * weight gradient stages the b * cout winning columns of x with coalesced accesses; without it the columns are
+ * gathered directly (a 64-byte sector per value).  The reference lets cuDNN run its dense data- and
+ * weight-gradient passes on the max's gradient, a tensor of zeros. */
+long long mvp_pointwise_max_backward_scratch_bytes(int b, int cin, int cout, int len);
 int mvp_pointwise_max_backward(int b, int cin, int cout, int len, const float *x,
                                const float *w, const float *g, const int *idx,
-                               float *gx, float *gw, float *gb, void *stream);
+                               float *gx, float *gw, float *gb, void *scratch,
+                               long long scratch_bytes, void *stream);
 
 /* ------------------------------------------------ registration (DCP) head */
 

@@ -51,7 +51,7 @@ SIGNATURES = {
     "mvp_kabsch_svd3": "ipppppp",
     "mvp_pointwise_mfma": "iiiipppiippiip",
     "mvp_pointwise_wgrad_mfma": "iiiippppppq",
-    "mvp_pointwise_max_backward": "iiiippppppp",
+    "mvp_pointwise_max_backward": "iiiippppppppq",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
@@ -100,6 +100,8 @@ def load():
     lib.mvp_pointwise_wgrad_scratch_bytes.argtypes = [ctypes.c_int] * 4
     lib.mvp_pointwise_wgrad_mfma_scratch_bytes.restype = ctypes.c_longlong
     lib.mvp_pointwise_wgrad_mfma_scratch_bytes.argtypes = [ctypes.c_int] * 5
+    lib.mvp_pointwise_max_backward_scratch_bytes.restype = ctypes.c_longlong
+    lib.mvp_pointwise_max_backward_scratch_bytes.argtypes = [ctypes.c_int] * 4
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
@@ -211,8 +213,14 @@ def pointwise_wgrad_mfma_scratch_bytes(b, cin, cout, length, with_bias):
     return int(load().mvp_pointwise_wgrad_mfma_scratch_bytes(int(b), int(cin), int(cout), int(length), int(with_bias)))
 
 
+def pointwise_max_backward_scratch_bytes(b, cin, cout, length):
+    """Scratch of mvp_pointwise_max_backward's staged weight gradient (0: not covered, it gathers directly)."""
+    return int(load().mvp_pointwise_max_backward_scratch_bytes(int(b), int(cin), int(cout), int(length)))
+
+
 def exported_symbols():
     """All entry points include/mvpops.h declares."""
     return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_knn_scratch_bytes", "mvp_fps_scratch_bytes", "mvp_fps_cluster_scratch_bytes",
-            "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes", "mvp_pointwise_wgrad_mfma_scratch_bytes"] \
+            "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes", "mvp_pointwise_wgrad_mfma_scratch_bytes",
+            "mvp_pointwise_max_backward_scratch_bytes"] \
         + list(SIGNATURES)

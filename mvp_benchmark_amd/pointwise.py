@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from ._lib import call, pointwise_wgrad_mfma_scratch_bytes, pointwise_wgrad_scratch_bytes
+from ._lib import call, pointwise_max_backward_scratch_bytes, pointwise_wgrad_mfma_scratch_bytes, pointwise_wgrad_scratch_bytes
 
 MAX_COUT = 64   # mvp_pointwise_wgrad's limit
 MAX_CIN = 64
@@ -268,7 +268,10 @@ class _PointwiseConvMax(Function):
             gx = torch.empty_like(x3) if need_x else None
             gw = torch.empty_like(w2) if (need_w or need_b) else None
             gb = torch.empty(cout, dtype=torch.float32, device=x.device) if need_b else None
-            call("mvp_pointwise_max_backward", x.device, B, cin, cout, length, x3, w2, g, idx.int(), gx, gw, gb)
+            nbytes = pointwise_max_backward_scratch_bytes(B, cin, cout, length) if gw is not None else 0
+            scratch = _wgrad_scratch(x.device, nbytes) if nbytes else None     # the winning columns of x, staged
+            call("mvp_pointwise_max_backward", x.device, B, cin, cout, length, x3, w2, g, idx.int(), gx, gw, gb, scratch,
+                 nbytes)
             return (gx.view_as(x) if need_x else None, gw.view_as(weight) if need_w else None, gb)
         where = idx.unsqueeze(1).expand(B, cin, cout)                  # [b, ci, co] -> winning position of (b, co)
         if need_x:

@@ -662,6 +662,9 @@ def test_pointwise_conv_max_backward_kernels(B, cin, cout, L):
     x = torch.randn(B, cin, L, device=DEV)
     if L >= 4:
         x[..., L // 2:L // 2 * 2] = x[..., :L // 2]
+    if L >= 64:
+        x[..., 5] *= 40.0                                                # a "critical point": hundreds of channels win at one position
+        x[..., L // 2 + 5] = x[..., 5]
     x.requires_grad_()
     go = torch.randn(B, cout, device=DEV)
     params = (x, layer.weight, layer.bias)
