@@ -237,13 +237,15 @@ class Model(nn.Module):
         if train:
             # the reconstruction path sees the (sub-sampled) complete shape; both paths are decoded
             # in ONE doubled batch (:450-455)
-            if gt.size(1) == x.size(2) and os.environ.get("MVP_VRCNET_SKIP_FULL_FPS"):
-                # OPT-IN.  The reference samples x.size(2) of gt's points in FPS order (:451); when that is ALL of
-                # them the result is a permutation of gt, and the encoder that consumes it -- per-point maps and
-                # max-pools (PCN_encoder) -- computes the same feature for any order of the points (to the last
-                # bits: the GEMMs' tiles see the points in another order; tests/test_gpu_harness.py::
-                # test_vrcnet_full_fps_of_gt_changes_nothing).  Skipping those 2047 sequential FPS rounds saves
-                # 1.1 ms of a 30 ms step; the default keeps the reference's launch sequence.
+            if gt.size(1) == x.size(2) and not os.environ.get("MVP_VRCNET_FULL_FPS"):
+                # The reference samples x.size(2) of gt's points in FPS order (:451); when that is ALL of them the
+                # result is a permutation of gt, and the encoder that consumes it -- per-point maps and max-pools
+                # (PCN_encoder) -- cannot see the order of the points: on the op layer's convolution kernels (every
+                # output column is the same k-ordered fmaf chain wherever it sits) its feature is BIT-IDENTICAL for
+                # any order (tests/test_gpu_harness.py::test_vrcnet_full_fps_of_gt_changes_nothing).  Those 2047
+                # sequential FPS rounds (1.1 ms of the step, nothing can run beside them) are therefore not issued;
+                # MVP_VRCNET_FULL_FPS=1 restores the reference's launch sequence (round 3 had this as an opt-in:
+                # the library's GEMM tiles saw the order in the last bits).
                 y = gt.transpose(1, 2).contiguous()
             else:
                 y = gather_points(gt.transpose(1, 2).contiguous(), furthest_point_sample(gt, x.size(2)))

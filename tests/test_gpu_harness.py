@@ -386,9 +386,10 @@ def test_vrcnet_full_fps_of_gt_changes_nothing(monkeypatch):
     """VRCNet's training path feeds its PointNet encoder with gt re-ordered by an FPS of ALL its points
     (reference completion/models/vrcnet.py:451).  Shown here: (i) that FPS returns a permutation; (ii) the
     encoder's output for gt, for gt in FPS order and for a random permutation agree to float32 rounding
-    (per-point maps and max-pools cannot see the order; the GEMM tiles can, in the last bits); (iii) a training
-    forward with the opt-in shortcut (MVP_VRCNET_SKIP_FULL_FPS) and one with the reference's sequence return the
-    same loss and CD to 1e-4 / 1e-3 and the same fine clouds as point sets (same seed for the latent samples)."""
+    (per-point maps and max-pools cannot see the order) -- bit for bit on the op layer's convolution kernels;
+    (iii) a training forward without that FPS (the default since round 4) and one with the reference's sequence
+    (MVP_VRCNET_FULL_FPS=1) return the same loss and CD to 1e-4 / 1e-3 and the same fine clouds as point sets
+    (same seed for the latent samples; the decoder re-orders its own points by the order of its input)."""
     import importlib
     import train
     from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample, gather_points
@@ -405,14 +406,13 @@ def test_vrcnet_full_fps_of_gt_changes_nothing(monkeypatch):
         assert sorted(order[0].tolist()) == list(range(2048))                       # a permutation
         by_fps = net.encoder(gather_points(gt.transpose(1, 2).contiguous(), order))
         shuffled = net.encoder(gt[:, torch.randperm(2048, generator=g)].transpose(1, 2).contiguous())
-    scale = float(plain.abs().max())
-    assert float((plain - by_fps).abs().max()) <= 2e-6 * scale and float((plain - shuffled).abs().max()) <= 2e-6 * scale
+    assert torch.equal(plain, by_fps) and torch.equal(plain, shuffled)
     outs = []
     for skip in (False, True):
         if skip:
-            monkeypatch.setenv("MVP_VRCNET_SKIP_FULL_FPS", "1")
+            monkeypatch.delenv("MVP_VRCNET_FULL_FPS", raising=False)
         else:
-            monkeypatch.delenv("MVP_VRCNET_SKIP_FULL_FPS", raising=False)
+            monkeypatch.setenv("MVP_VRCNET_FULL_FPS", "1")
         torch.manual_seed(11)
         with torch.no_grad():
             outs.append(net(partial, gt, alpha=0.5))
