@@ -39,7 +39,7 @@ if "cfg2" in sys.argv:
         ms_noemd = timed(lambda: net(partial, gt, prefix="val"))
     print("cfg2 PCN eval (32, 2048->16384) CD+F1+EMD: %.1f ms/step (%.1f clouds/s); without EMD %.1f ms" % (ms, 32e3 / ms, ms_noemd), flush=True)
 
-for name in ("vrcnet", "ecg"):
+for name in ("vrcnet", "ecg", "pcn"):
     args = train.load_config(os.path.join(ROOT, "completion", "cfgs", name + ".yaml"))
     args.load_model = None
     net = importlib.import_module("models." + name).Model(args).to(dev).train()
