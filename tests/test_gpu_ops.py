@@ -3,6 +3,8 @@ through the reference-shaped Python API -> ctypes -> C ABI -> HIP kernels, is
 compared with the CPU oracle on identical seeded inputs.  Index outputs and
 forward values are BIT-EXACT (the kernels and the oracle share one canonical
 arithmetic); gradients that use float atomics are compared at 1e-5."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -1268,3 +1270,55 @@ def test_points_sampler(oracle):
     np.testing.assert_array_equal(idx.cpu().numpy(), np.concatenate([a, b], 1))
     idx = Points_Sampler([24], ['FS'], [-1])(dev(xyz), dev(feats))
     assert tuple(idx.shape) == (2, 48)
+
+
+def _surface_clouds(n, seed):
+    """Three surface-shaped cloud pairs of n points (MVP's clouds are samples of 2-manifolds,
+    completion/dataset.py:21-34): a sphere against independent samples of it, a torus against itself + noise
+    0.03, the faces of a box against itself + noise 0.01; in [0, 1]^3."""
+    g = torch.Generator().manual_seed(seed)
+
+    def sphere():
+        v = torch.randn(n, 3, generator=g)
+        return 0.5 + 0.4 * v / v.norm(dim=1, keepdim=True)
+
+    def torus():
+        u, v = 2 * math.pi * torch.rand(n, generator=g), 2 * math.pi * torch.rand(n, generator=g)
+        return torch.stack([0.5 + (0.3 + 0.12 * torch.cos(v)) * torch.cos(u), 0.5 + (0.3 + 0.12 * torch.cos(v)) * torch.sin(u),
+                            0.5 + 0.12 * torch.sin(v)], 1)
+
+    def box():
+        p = torch.rand(n, 3, generator=g)
+        face = torch.randint(0, 6, (n,), generator=g)
+        p.scatter_(1, (face % 3).unsqueeze(1), (face // 3).float().unsqueeze(1))
+        return 0.15 + 0.7 * p
+
+    gt = torch.stack([sphere(), torus(), box()])
+    t, b = gt[1], gt[2]
+    pred = torch.stack([sphere(), (t + 0.03 * torch.randn(n, 3, generator=g)).clamp(0, 1),
+                        (b + 0.01 * torch.randn(n, 3, generator=g)).clamp(0, 1)])
+    return pred.numpy().astype(np.float32), gt.numpy().astype(np.float32)
+
+
+@pytest.mark.parametrize("n,split", [(8192, 5), (16384, 5), (2048, 5), (2048, 2)])
+def test_emd_surface_shaped_clouds_match_oracle(oracle, emd_split, n, split):
+    """every EMD-vs-oracle case at the headline size was a pair of uniform volumes.  Surface-shaped
+    clouds put 30-200 objects into an occupied cell of the search grid (the chunked cell lists of round 4) and run
+    auctions of another shape: independent samples of a surface need ~1.4x the bids of two volumes, ground truth +
+    noise a quarter of them in as many rounds (profiles/r4_emd_surfaces.txt).  Bit for bit against the exhaustive
+    oracle, default launch sequence (gathered-bid rounds; LDS-resident tail at 2048 points) and the tiers alone."""
+    from mvp_benchmark_amd import _lib
+    x1, x2 = _surface_clouds(n, 7 + n)
+    emd_split(split)
+    b = x1.shape[0]
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    dist = torch.zeros(b, n, device=DEV)
+    ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_emd_forward", DEV, b, n, dev(x1), dev(x2), dist, ass, 0.004, 3000, scratch, nbytes)
+    torch.cuda.synchronize()
+    od, oa = oracle.emd_forward(x1, x2, 0.004, 3000)
+    np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
+    rec = _lib.emd_records(scratch, nbytes, b)
+    assert (rec["next_round"] == 0).all()
