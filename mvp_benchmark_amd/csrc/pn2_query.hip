@@ -706,9 +706,12 @@ extern "C" long long mvp_knn_scratch_bytes(int b, int n, int m) {
 
 extern "C" int mvp_knn_sorted(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx,
                               float *dist2, void *scratch, long long scratch_bytes, void *stream) {
-  // small clouds / many neighbours: the exhaustive kernel (break-even near 4096 candidates; the heaps of
-  // k + 1 <= 33 entries per query fit the workgroup's LDS)
-  if (b <= 0 || n < 4096 || m < 1024 || nsample < 1 || nsample > 32 || (n > m ? n : m) > (1 << 30))
+  // small clouds / many neighbours: the exhaustive kernel (the heaps of k + 1 <= 33 entries per query fit the
+  // workgroup's LDS)
+  // (round 4, at the networks' sizes: 3072 x 3072, k = 20: 0.67 against 0.93 ms, 2048 x 2048, k = 16: 0.28 against 0.32;
+  // 3072 -> 1536 and 1536 x 1536 stay with the exhaustive kernel: 0.40 / 0.32 against 0.44 / 0.56)
+  const bool large = (n >= 4096 && m >= 1024) || (n >= 2048 && m >= 2048);
+  if (b <= 0 || !large || nsample < 1 || nsample > 32 || (n > m ? n : m) > (1 << 30))
     return mvp_knn(b, n, m, nsample, xyz, new_xyz, idx, dist2, stream);
   if (!xyz || !new_xyz || !idx || !dist2 || !scratch) return MVP_EBADARG;
   if (scratch_bytes < mvp_knn_scratch_bytes(b, n, m)) return MVP_EBADARG;

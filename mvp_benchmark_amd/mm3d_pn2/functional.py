@@ -184,7 +184,7 @@ class KNN(Function):
         idx = _new(xyz, B, npoint, k, dtype=torch.int32, zero=True)
         dist2 = _new(xyz, B, npoint, k, zero=True)
         n = xyz.shape[1]
-        if n >= 4096 and npoint >= 1024 and k <= 32:
+        if ((n >= 4096 and npoint >= 1024) or (n >= 2048 and npoint >= 2048)) and k <= 32:
             # large clouds: Morton-sorted, pruned, the same bits (csrc/pn2_query.hip: knn_sorted_kernel)
             nbytes = knn_scratch_bytes(B, n, npoint)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)

@@ -884,9 +884,10 @@ def test_knn_matches_oracle(oracle, k, n, m):
 
 @pytest.mark.parametrize("k,n,m,kind", [(16, 4096, 4096, "random"), (1, 5000, 1024, "random"), (32, 4100, 1500, "random"),
                                         (9, 8192, 3000, "duplicates"), (16, 4096, 4096, "lattice"), (16, 6000, 2048, "clustered"),
-                                        (16, 16384, 16384, "self")])
+                                        (16, 16384, 16384, "self"), (20, 3072, 3072, "self"), (10, 2048, 2048, "duplicates"),
+                                        (16, 2048, 2048, "random"), (20, 2048, 2048, "lattice")])
 def test_knn_sorted_variant_is_bit_identical(oracle, k, n, m, kind):
-    """mvp_knn_sorted (clouds of >= 4096 candidates: Morton-sorted, pruned) against the oracle's replay of the
+    """mvp_knn_sorted (clouds of >= 4096 candidates, square searches from 2048 points: Morton-sorted, pruned) against the oracle's replay of the
     reference's heap (knn_cuda.cu:58-95), indices AND distances, through the C ABI: random clouds (the k + 1 nearest
     pairwise different: the pruned search alone decides), duplicated points and a lattice (equal distances: those
     queries are recomputed wave by wave with the reference's heap sequence -- the counters say how many), ragged sizes (padding of the sorted
@@ -898,8 +899,9 @@ def test_knn_sorted_variant_is_bit_identical(oracle, k, n, m, kind):
     if kind == "duplicates":
         xyz = np.concatenate([xyz[:, : n // 2], xyz[:, : n // 2]], 1)
     elif kind == "lattice":
-        g = np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) / 16
-        xyz = np.stack([g[np.random.default_rng(s).permutation(4096)] for s in range(b)])
+        side = (8, 16, 16) if n == 2048 else (16, 16, 16)              # (round 4: square searches from 2048 points take this route)
+        g = np.stack(np.meshgrid(*[np.arange(d) for d in side], indexing="ij"), -1).reshape(-1, 3).astype(np.float32) / 16
+        xyz = np.stack([g[np.random.default_rng(s).permutation(n)] for s in range(b)])
         ctr = xyz.copy()
     elif kind == "clustered":
         ctr = (0.9 + 0.05 * ctr).astype(np.float32)
