@@ -687,3 +687,13 @@ def test_pointwise_conv_max_backward_kernels(B, cin, cout, L):
     assert (g1[2].double() - god.sum(0)).abs().max().item() < 1e-5 * max(1.0, float(god.sum(0).abs().max()))
     assert (g1[0].double() - want_x).abs().max().item() < 1e-5 * max(1.0, float(want_x.abs().max()))
     assert bd.shape == (cout,)
+
+
+@pytest.mark.gpu
+def test_pointwise_kernels_fixed_seed_fuzz_slice():
+    """40 cases of tools/fuzz_pointwise.py (random batch / channel / position counts incl. 1-channel layers, ragged
+    tiles, 4-position clouds, masks, padded weight rows): the MFMA forward / data gradient / weight gradient and the
+    sparse conv -> max backward against float64 PyTorch.  The 300-case log: profiles/r4_fuzz_pointwise.txt."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_pointwise
+    assert fuzz_pointwise.run(40, 7, verbose=False) == 0
