@@ -492,6 +492,35 @@ def run_vrcnet_train(args, rank, world, dev):
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
+    # The step's dominant kernels are the float32-MFMA GEMMs of the 1x1 convolutions (csrc/pointwise_mfma.hip,
+    # ~10 of the step's ms): their three passes at the step's largest layer, 2 B x (512 -> 1024) x 2048, timed with
+    # events on the current stream (after the timed region, 5 repetitions), against the f32 MFMA peak.
+    from mvp_benchmark_amd.pointwise import mfma_linear, mfma_wgrad
+    cb, cin, cout, L = 2 * B, 512, 1024, 2048
+    gx = torch.Generator().manual_seed(5)
+    x = torch.randn(cb, cin, L, generator=gx).to(dev)
+    w = torch.randn(cout, cin, generator=gx).to(dev)
+    gy = torch.randn(cb, cout, L, generator=gx).to(dev)
+    flops = 2.0 * cb * cin * cout * L
+
+    def tflops(fn, reps=5):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return flops / (e0.elapsed_time(e1) / reps * 1e-3) / 1e12
+
+    passes = {"forward": tflops(lambda: mfma_linear(x, w)), "data_gradient": tflops(lambda: mfma_linear(gy, w, w_kmajor=True)),
+              "weight_gradient": tflops(lambda: mfma_wgrad(x, gy, cout, cin, True))}
+    achieved = 3.0 / sum(1.0 / v for v in passes.values())          # the three passes back to back
+    roofline = {"kernel": "pointwise_mfma_kernel (forward, data gradient) + pointwise_wgrad_mfma_kernel, (%d, 512 -> 1024, 2048)" % cb,
+                "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                "traffic": None, "per_pass_tflops": passes,
+                "note": "float32 in / float32 accumulate (v_mfma_f32_32x32x2_f32); peak at 2.4 GHz -- the chip holds ~2.05 GHz "
+                        "under this load (profiles/r4_pmc_pointwise_512_1024.json)"}
     return {
         "metric": "VRCNet train samples/sec (cfgs/vrcnet.yaml, DDP, batch 32 per GPU)",
         "value": B * world / (ms * 1e-3),
@@ -512,6 +541,7 @@ def run_vrcnet_train(args, rank, world, dev):
         "grad_allreduce_bytes_per_step": grad_bytes,
         "rccl": bus,
         "final_loss": float(loss.mean()),
+        "roofline": roofline,
     }
 
 
