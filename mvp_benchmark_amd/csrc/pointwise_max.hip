@@ -190,27 +190,51 @@ __global__ __launch_bounds__(kMxBlock) void convmax_cols_kernel(int cin, int cou
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int cloud = blockIdx.x, ci0 = blockIdx.y * kMxTC;
   convmax_sort_runs(cout, cout_p2, len, cloud, nullptr, idx, s_key, nullptr, s_end, s_wave);
-  // The four waves share a tile: a trained network's winners sit on a few critical points, and the run of one
-  // tile can hold hundreds of channels.
-  float *tile = s_tile[0];
+  // The four waves share a tile of 64 positions x 64 channels (the whole s_tile area): a trained network's winners
+  // sit on a few critical points, and the run of one tile can hold hundreds of channels.  A wave reads its 16 rows
+  // with the lanes along the positions (256-byte segments); the NEXT non-empty tile's rows are already in flight
+  // while this tile's columns are written out.
+  constexpr int kTL = 64, kRows = kMxTC / (kMxBlock / 64);      // positions per tile; rows per wave
+  static_assert((kMxBlock / 64) * kMxTL * kMxTStride >= kTL * kMxTStride, "the shared tile fits the per-wave tiles' area");
+  float *tile = &s_tile[0][0];
   const float *in = x + (size_t)cloud * cin * len;
-  const int hl = lane & 31, hc = lane >> 5;
   const bool ci_ok = ci0 + lane < cin;
-  for (int l0 = 0; l0 < len; l0 += kMxTL) {
-    const int l1 = min(len, l0 + kMxTL);
-    const int a = l0 ? s_end[l0 - 1] : 0, e = s_end[l1 - 1];   // (uniform over the workgroup)
-    if (a == e) continue;
-    __syncthreads();                                           // the previous tile has been read
-    for (int r = wave * (kMxTC / 4); r < (wave + 1) * (kMxTC / 4); r += 2) {
-      float v = 0.f;
-      if (l0 + hl < l1 && ci0 + r + hc < cin) v = in[(size_t)(ci0 + r + hc) * len + l0 + hl];
-      tile[hl * kMxTStride + r + hc] = v;
+  auto run_of = [&](int l0, int &a, int &e) {                  // the tile's run of the sorted list (uniform over the workgroup)
+    a = l0 ? s_end[l0 - 1] : 0;
+    e = s_end[min(len, l0 + kTL) - 1];
+  };
+  auto next_tile = [&](int l0) {                               // first non-empty tile at or after l0 (len: none)
+    for (; l0 < len; l0 += kTL) {
+      int a, e;
+      run_of(l0, a, e);
+      if (a != e) return l0;
     }
+    return len;
+  };
+  float v[kRows];
+  auto fetch = [&](int l0) {
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const int ci = ci0 + wave * kRows + r;
+      v[r] = (l0 + lane < len && ci < cin) ? in[(size_t)ci * len + l0 + lane] : 0.f;
+    }
+  };
+  int l0 = next_tile(0);
+  if (l0 < len) fetch(l0);
+  while (l0 < len) {
+    __syncthreads();                                           // the previous tile has been read
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) tile[lane * kMxTStride + wave * kRows + r] = v[r];
+    const int ln = next_tile(l0 + kTL);
+    if (ln < len) fetch(ln);                                   // in flight while this tile's columns go out
     __syncthreads();
+    int a, e;
+    run_of(l0, a, e);
     for (int q = a + wave; q < e; q += kMxBlock / 64) {
       const int key = s_key[q];
       if (ci_ok) cols[((size_t)cloud * cout + (key & 4095)) * cin + ci0 + lane] = tile[((key >> 12) - l0) * kMxTStride + lane];
     }
+    l0 = ln;
   }
 }
 
@@ -221,7 +245,18 @@ __global__ __launch_bounds__(kMxThreads) void convmax_wgrad_reduce_kernel(int b,
   const int co = blockIdx.x, t = threadIdx.x;
   for (int ci = t; ci < cin; ci += kMxThreads) {
     float s = 0.f;
-    for (int c = 0; c < b; ++c) s = __builtin_fmaf(g[(size_t)c * cout + co], cols[((size_t)c * cout + co) * cin + ci], s);
+    int c = 0;
+    for (; c + 8 <= b; c += 8) {                               // eight independent loads in flight, the sum in cloud order
+      float v[8], w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        w[u] = g[(size_t)(c + u) * cout + co];
+        v[u] = cols[((size_t)(c + u) * cout + co) * cin + ci];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s = __builtin_fmaf(w[u], v[u], s);
+    }
+    for (; c < b; ++c) s = __builtin_fmaf(g[(size_t)c * cout + co], cols[((size_t)c * cout + co) * cin + ci], s);
     gw[(size_t)co * cin + ci] = s;
   }
   if (gb && t == 0) {
