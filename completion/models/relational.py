@@ -14,7 +14,7 @@ down, three_nn + three_interpolate on the way up.
 import torch
 import torch.nn as nn
 
-from model_utils import (GeometryAhead, aggregate_shared, edge_preserve_features, edge_preserve_geometry, fps_centres,
+from model_utils import (GeometryAhead, aggregate_shared, aggregate_shared_gathered, neighbour_lists_k_major, edge_preserve_features, edge_preserve_geometry, fps_centres,
                          knn_point_idx,
                          edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling)
 from mm3d_pn2 import three_interpolate
@@ -51,12 +51,13 @@ class SA_module(nn.Module):
         # (B, C, k, N) intermediate) and gather the r and the mid mapped channels;
         # same parameters, same result up to fp32 summation order.
         query = self.conv1(act)                          # (B, r, 1, N)
-        keys = get_edge_features(self.conv2(act), idx).reshape(batch_size, -1, 1, num_points)   # (B, r*k, 1, N), channel = r_i*k + k_i
-        values = get_edge_features(self.conv3(act), idx)                     # (B, mid, k, N)
+        idx_t = neighbour_lists_k_major(idx) if act.is_cuda else None       # one index tensor for both gathers
+        keys = get_edge_features(self.conv2(act), idx, idx_t).reshape(batch_size, -1, 1, num_points)   # (B, r*k, 1, N), channel = r_i*k + k_i
 
         w = self.conv_w(torch.cat([query, keys], 1))     # (B, k*mid/share, 1, N)
-        # weights are shared by the `share_planes` channel groups: one fused pass, no repeat / product tensor
-        out = aggregate_shared(w.view(batch_size, -1, self.k, num_points), values, self.share_planes)
+        # weights are shared by the `share_planes` channel groups; the neighbours' values (conv3's output at the k
+        # neighbours of every point) are gathered and summed in ONE kernel: no (B, mid, k, N) tensor, no repeat / product
+        out = aggregate_shared_gathered(w.view(batch_size, -1, self.k, num_points), self.conv3(act), idx, self.share_planes, idx_t)
         out = out.view(batch_size, -1, 1, num_points)
         out = self.conv_out(self.activation_fn(out))     # (B, C_out, 1, N)
         return [out + x, idx]

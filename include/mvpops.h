@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 14
+#define MVP_ABI_VERSION 15
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -402,6 +402,20 @@ int mvp_pointwise_wgrad(int b, int cin, int cout, int len, const float *x,
  * ReLU mask is applied to gy beforehand (mvp_benchmark_amd/pointwise.py). */
 int mvp_pointwise_dgrad(int b, int cin, int cout, int len, const float *weight,
                         const float *gy, float *gx, void *stream);
+
+/* The same aggregation with the gather of the neighbours' values fused in:
+ *   out[b, s*cw + m, p] = sum_k w[b, m, k, p] * v[b, s*cw + m, idx[b, k, p]]
+ * w (b,cw,k,n), v (b,share*cw,n_src) the per-point values, idx (b,k,n) int32 the neighbour lists (k-major);
+ * the (b, share*cw, k, n) tensor of gathered values (vrcnet.py:45-55 builds it with get_edge_features) is never
+ * formed.  share * n_src * 4 <= 96 KiB (mvp_share_gather_sum_lds_bytes); bit-identical to mvp_group_points +
+ * mvp_share_weighted_sum.  _grad: grad_w (b,cw,k,n) and grad_vals (b,share*cw,k,n) = the gradient of the gathered
+ * values, to be scattered into grad_v by mvp_group_points_grad(_ws). */
+long long mvp_share_gather_sum_lds_bytes(int share, int n_src);
+int mvp_share_gather_sum(int b, int share, int cw, int k, int n_src, int n, const float *w,
+                         const float *v, const int *idx, float *out, void *stream);
+int mvp_share_gather_sum_grad(int b, int share, int cw, int k, int n_src, int n, const float *w,
+                              const float *v, const int *idx, const float *grad_out,
+                              float *grad_w, float *grad_vals, void *stream);
 
 /* ------------------------------------------- grouped-feature MLP on MFMA */
 

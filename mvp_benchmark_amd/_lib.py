@@ -46,6 +46,8 @@ SIGNATURES = {
     "mvp_three_interpolate_grad_ws": "iiiipppppqi",
     "mvp_share_weighted_sum": "iiiiippp",
     "mvp_share_weighted_sum_grad": "iiiiippppp",
+    "mvp_share_gather_sum": "iiiiiipppp",
+    "mvp_share_gather_sum_grad": "iiiiiipppppp",
     "mvp_pointwise_wgrad": "iiiipppppq",
     "mvp_pointwise_dgrad": "iiiippp",
     "mvp_kabsch_svd3": "ipppppp",
@@ -56,7 +58,7 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 14  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 15  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
 EMD_DEFAULT_SPLIT = 5
@@ -222,5 +224,5 @@ def exported_symbols():
     """All entry points include/mvpops.h declares."""
     return ["mvp_abi_version", "mvp_last_hip_error", "mvp_emd_scratch_bytes", "mvp_emd_configure", "mvp_chamfer_scratch_bytes", "mvp_knn_scratch_bytes", "mvp_fps_scratch_bytes", "mvp_fps_cluster_scratch_bytes",
             "mvp_scatter_scratch_bytes", "mvp_pointwise_wgrad_scratch_bytes", "mvp_pointwise_wgrad_mfma_scratch_bytes",
-            "mvp_pointwise_max_backward_scratch_bytes"] \
+            "mvp_pointwise_max_backward_scratch_bytes", "mvp_share_gather_sum_lds_bytes"] \
         + list(SIGNATURES)

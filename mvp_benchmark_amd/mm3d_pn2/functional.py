@@ -392,8 +392,54 @@ class ShareWeightedSum(Function):
         return grad_w, grad_v
 
 
+class ShareGatherSum(Function):
+    """out[b, s*Cw + m, p] = sum_k w[b, m, k, p] * v[b, s*Cw + m, idx[b, k, p]]: ShareWeightedSum with the gather of the
+    neighbours' values (the grouping operator) fused in -- the (B, share*Cw, k, N) tensor of gathered values is never
+    formed, forward or backward.  (w (B,Cw,k,N), v (B,share*Cw,Nsrc), idx (B,k,N) int32) -> (B, share*Cw, N);
+    differentiable in w and v; bit-identical to share_weighted_sum(w, grouping_operation(v, idx)).  The gradient of
+    v goes through the grouping operator's scatter (inverted index, no atomics)."""
+
+    LDS_BYTES = 96 * 1024
+
+    @staticmethod
+    def covers(share, n_src):
+        return share in ShareWeightedSum.SHARES and share * n_src * 4 <= ShareGatherSum.LDS_BYTES
+
+    @staticmethod
+    def forward(ctx, w, v, idx):
+        _need_contiguous(w, v, idx)
+        B, Cw, k, N = w.shape
+        C, n_src = v.shape[1], v.shape[2]
+        share = C // max(Cw, 1)
+        assert v.shape[0] == B and share * Cw == C and idx.shape == (B, k, N) and ShareGatherSum.covers(share, n_src)
+        out = _new(v, B, C, N)
+        call("mvp_share_gather_sum", v.device, B, share, Cw, k, n_src, N, w, v, idx, out)
+        ctx.save_for_backward(w, v, idx)
+        ctx.mark_non_differentiable(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        w, v, idx = ctx.saved_tensors
+        B, Cw, k, N = w.shape
+        C, n_src = v.shape[1], v.shape[2]
+        share = C // max(Cw, 1)
+        grad_w = torch.empty_like(w)
+        grad_v = _new(v, B, C, n_src)
+        if k == 0:
+            return grad_w, grad_v.zero_(), None
+        grad_vals = _new(v, B, C, k, N)
+        call("mvp_share_gather_sum_grad", v.device, B, share, Cw, k, n_src, N, w, v, idx, grad_out.data.contiguous(),
+             grad_w, grad_vals)
+        scratch, nbytes, mode, key = _scatter_scratch(idx, None, B, n_src, k * N, 1)
+        call("mvp_group_points_grad_ws", v.device, B, C, n_src, k, N, grad_vals, idx, grad_v, scratch, nbytes, mode)
+        _scatter_commit(key, idx, None, scratch)
+        return grad_w, grad_v, None
+
+
 furthest_point_sample = FurthestPointSampling.apply
 share_weighted_sum = ShareWeightedSum.apply
+share_gather_sum = ShareGatherSum.apply
 furthest_point_sample_with_dist = FurthestPointSamplingWithDist.apply
 ball_query = BallQuery.apply
 knn = KNN.apply

@@ -10,6 +10,7 @@ import train
 import mvp_benchmark_amd.pointwise as pw
 if "MVP_MFMA_TRAIN" in os.environ:                       # A/B of the training-path routing (pointwise.py)
     pw.MFMA_TRAIN = os.environ["MVP_MFMA_TRAIN"] == "1"
+if "MVP_NO_GATHER_SUM" in os.environ: pass   # (read by model_utils.aggregate_shared_gathered: the two-step formulation)
 if "MVP_MFMA_WGRAD_TRAIN" in os.environ:                 # A/B: only the weight gradients leave the library
     pw.MFMA_WGRAD_TRAIN = os.environ["MVP_MFMA_WGRAD_TRAIN"] == "1"
 REPS = int(os.environ.get("MVP_BENCH_REPS", "10"))
