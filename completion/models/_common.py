@@ -1,6 +1,8 @@
 """Pieces shared by the three completion networks: layer factories and the
 loss / metric tail of Model.forward (identical in the reference's pcn.py
 :93-112, ecg.py:233-253 and vrcnet.py:519-526, restated once here)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -38,6 +40,44 @@ def conv_global_concat(conv, global_vec, feats, relu=False, global_first=True):
     tail = (1,) * (feats.dim() - 2)
     h = pointwise_conv(feats, wf.contiguous().view(cout, -1, *tail)) + per_cloud.view(per_cloud.shape + tail)
     return torch.relu_(h) if relu else h
+
+
+def conv_folded_concat(conv, parts, scale, relu=True):
+    """conv(cat(parts, 1)) [then ReLU] for the inputs of a FOLDING layer, without the concatenated tensor or its GEMM.
+    A folding layer lifts every one of Nc coarse points to S = `scale` fine points by convolving, per fine point
+    n = c S + s, the concatenation of (i) a global feature, the same for all n, (ii) the coarse point's own feature,
+    the same for its S fine points, (iii) a small grid patch, the same under every coarse point (the reference tiles,
+    repeats and concatenates all three: pcn.py:60-68, vrcnet.py Folding :60-75 -- 2 * (Cg + Cp + 2) * Cout flops per
+    fine point).  The convolution is linear, so its output is the broadcast sum of three tiny products:
+        W_g g[b] + bias   (B, Cout)        W_p p[b, :, c]   (B, Cout, Nc)        W_grid grid[:, s]   (Cout, S).
+    parts: [(kind, tensor)] in the concatenation's channel order, kind = 'global' (B, Cg) | 'point' (B, Cp, Nc) |
+    'grid' (Cgrid, S).  -> (B, Cout, Nc * S).  Same parameters, same function up to float32 summation order
+    (tests/test_harness_cpu.py::test_*folded*_equals_concatenated_formulation)."""
+    cout = conv.out_channels
+    if os.environ.get("MVP_NO_FOLDED_CONV"):       # A/B: the reference's tile / repeat / concatenate / convolve
+        nc = next(t for kind, t in parts if kind == 'point').size(2)
+        b = next(t for kind, t in parts if kind == 'point').size(0)
+        full = [t.unsqueeze(2).expand(-1, -1, nc * scale) if kind == 'global' else
+                t.unsqueeze(3).expand(-1, -1, -1, scale).reshape(b, t.size(1), nc * scale) if kind == 'point' else
+                t.to(conv.weight.dtype).unsqueeze(0).repeat(b, 1, nc) for kind, t in parts]
+        return conv(torch.cat(full, 1).contiguous(), relu=relu)
+    w = conv.weight.view(cout, -1)
+    per_cloud = per_point = per_grid = None
+    off = 0
+    for kind, t in parts:
+        c = t.size(0) if kind == 'grid' else t.size(1)
+        wk = w[:, off:off + c]
+        off += c
+        if kind == 'global':
+            per_cloud = nn.functional.linear(t, wk, conv.bias)                       # (B, Cout)
+        elif kind == 'point':
+            per_point = pointwise_conv(t, wk.contiguous().unsqueeze(2))              # (B, Cout, Nc)
+        else:
+            per_grid = torch.matmul(wk, t.to(wk.dtype))                              # (Cout, S)
+    assert off == w.size(1) and per_cloud is not None and per_point is not None and per_grid is not None
+    h = (per_point + per_cloud.unsqueeze(2)).unsqueeze(3) + per_grid.view(1, cout, 1, scale)   # (B, Cout, Nc, S): n = c S + s
+    h = torch.relu_(h) if relu else h
+    return h.view(h.size(0), cout, -1)
 
 
 def shape_loss(kind, pred, gt):

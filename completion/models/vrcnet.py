@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from model_utils import EF_expansion, calc_cd, furthest_point_sample, gather_points, gen_grid_up
-from models._common import dense, eval_outputs, pointwise1d
+from models._common import conv_folded_concat, dense, eval_outputs, pointwise1d
 from models.pcn import PCN_encoder
 from models.relational import SA_module, SA_SKN_Res_encoder, SK_SA_module, SKN_Res_unit  # noqa: F401
 
@@ -48,13 +48,13 @@ class Folding(nn.Module):
         self.grid = gen_grid_up(step_ratio, 0.2).transpose(0, 1).contiguous()
 
     def forward(self, point_feat, global_feat):
-        batch_size, num_features, num_points = point_feat.size()
-        total = num_points * self.step_ratio
-        point_feat = point_feat.unsqueeze(3).expand(-1, -1, -1, self.step_ratio).reshape(batch_size, num_features, total)
-        global_feat = global_feat.unsqueeze(2).expand(-1, -1, total).repeat(self.num_models, 1, 1)
-        grid_feat = self.grid.to(point_feat.device).unsqueeze(0).repeat(batch_size, num_points, 1).transpose(1, 2)
-        features = torch.cat([global_feat, point_feat, grid_feat], dim=1)
-        return self.conv(features.contiguous(), relu=True)
+        # conv over cat(global feature tiled, point feature repeated step_ratio times, grid tiled) (vrcnet.py:60-75) as the
+        # broadcast sum of three tiny products (models/_common.py: conv_folded_concat): a (1024 + C + 2) -> out GEMM over
+        # B x total positions (0.65 ms forward at the training setting, as much again for each gradient) becomes a
+        # C -> out GEMM over the coarse points and one elementwise pass.
+        assert self.num_models == 1
+        grid = self.grid.to(point_feat.device).t().contiguous()                       # (2, step_ratio)
+        return conv_folded_concat(self.conv, [('global', global_feat), ('point', point_feat), ('grid', grid)], self.step_ratio)
 
 
 class Linear_ResBlock(nn.Module):

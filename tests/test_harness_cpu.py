@@ -464,6 +464,29 @@ def test_conv_global_concat_equals_concatenated_formulation():
                 assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
 
 
+def test_vrcnet_folding_equals_concatenated_formulation():
+    """models/vrcnet.py Folding (conv_folded_concat: global feature, repeated point feature and tiled grid as three tiny
+    products) against the reference's formulation written out (vrcnet.py:60-75: tile / repeat / concatenate, one
+    convolution, ReLU), float64, values and every gradient."""
+    from models.vrcnet import Folding
+    torch.manual_seed(12)
+    B, C, Nc, S = 2, 6, 5, 4
+    fold = Folding(C, 7, S, global_feature_size=9).double()
+    pf = torch.randn(B, C, Nc, dtype=torch.float64, requires_grad=True)
+    gf = torch.randn(B, 9, dtype=torch.float64, requires_grad=True)
+    got = fold(pf, gf)
+    total = Nc * S
+    point = pf.unsqueeze(3).expand(-1, -1, -1, S).reshape(B, C, total)
+    glob = gf.unsqueeze(2).expand(-1, -1, total)
+    grid = fold.grid.double().unsqueeze(0).repeat(B, Nc, 1).transpose(1, 2)
+    ref = torch.relu(torch.nn.functional.conv1d(torch.cat([glob, point, grid], dim=1), fold.conv.weight, fold.conv.bias))
+    assert got.shape == ref.shape == (B, 7, total)
+    assert torch.allclose(got, ref, rtol=1e-10, atol=1e-10)
+    params = (pf, gf, fold.conv.weight, fold.conv.bias)
+    for a, b in zip(torch.autograd.grad(got.square().sum(), params), torch.autograd.grad(ref.square().sum(), params)):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
 def test_sa_module_equals_gather_then_map_formulation():
     """SA_module maps the points with conv2 / conv3 before gathering the
     neighbours; the reference (vrcnet.py:36-57) gathers first.  Same parameters,
