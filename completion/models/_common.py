@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from model_utils import calc_cd, calc_emd
+from mm3d_pn2 import three_interpolate
 from mvp_benchmark_amd.pointwise import PointwiseConv1d, PointwiseConv2d, pointwise_conv
 
 
@@ -40,6 +41,30 @@ def conv_global_concat(conv, global_vec, feats, relu=False, global_first=True):
     tail = (1,) * (feats.dim() - 2)
     h = pointwise_conv(feats, wf.contiguous().view(cout, -1, *tail)) + per_cloud.view(per_cloud.shape + tail)
     return torch.relu_(h) if relu else h
+
+
+def conv_interp_concat(conv, coarse, skip, idx, weight, interp_first=True, relu=True):
+    """conv(cat((three_interpolate(coarse, idx, weight), skip), 1)) [then ReLU] -- the way up of the point U-Nets
+    (vrcnet.py:287-296, ecg.py:143-150) -- with the convolution of the interpolated half done BEFORE the
+    interpolation: three_interpolate is a weighted sum of three coarse points and a 1x1 convolution is linear, so
+        W_c interp(coarse) = interp(W_c coarse),
+    and W_c meets the coarse level's points (half as many) and hands the interpolation Cout instead of Cc channels;
+    the concatenated (B, Cc + Cs, N) tensor is never built.  coarse (B, Cc, Nc) / (B, Cc, 1, Nc), skip (B, Cs, N) /
+    (B, Cs, 1, N), idx / weight (B, N, 3); interp_first: the concatenation's order.  Same parameters, same function up
+    to float32 summation order."""
+    cout, cc = conv.out_channels, coarse.size(1)
+    four_d = skip.dim() == 4
+    if os.environ.get("MVP_NO_CONV_BEFORE_INTERP"):      # A/B: the reference's order -- interpolate, concatenate, convolve
+        up = three_interpolate(coarse.reshape(coarse.size(0), cc, -1).contiguous(), idx, weight)
+        up = up.unsqueeze(2) if four_d else up
+        return conv(torch.cat((up, skip) if interp_first else (skip, up), 1), relu=relu)
+    w = conv.weight.view(cout, -1)
+    wc, ws = (w[:, :cc], w[:, cc:]) if interp_first else (w[:, w.size(1) - cc:], w[:, :w.size(1) - cc])
+    yc = pointwise_conv(coarse.reshape(coarse.size(0), cc, -1), wc.contiguous().unsqueeze(2))      # (B, Cout, Nc)
+    y = three_interpolate(yc.contiguous(), idx, weight)                                              # (B, Cout, N)
+    h = pointwise_conv(skip.reshape(skip.size(0), skip.size(1), -1), ws.contiguous().unsqueeze(2), conv.bias) + y
+    h = torch.relu_(h) if relu else h
+    return h.unsqueeze(2) if four_d else h
 
 
 def conv_folded_concat(conv, parts, scale, relu=True):

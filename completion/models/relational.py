@@ -18,7 +18,7 @@ from model_utils import (GeometryAhead, aggregate_shared, aggregate_shared_gathe
                          knn_point_idx,
                          edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling)
 from mm3d_pn2 import three_interpolate
-from models._common import conv_global_concat, dense, pointwise2d
+from models._common import conv_global_concat, conv_interp_concat, dense, pointwise2d
 
 
 class SA_module(nn.Module):
@@ -191,6 +191,6 @@ class SA_SKN_Res_encoder(nn.Module):
         x = conv_global_concat(self.conv6, g, skips[3], relu=True)
         for level, conv in ((2, self.conv7), (1, self.conv8), (0, self.conv9)):
             idx, weight = geo.take(("up", level))
-            x = three_interpolate(x.squeeze(2).contiguous(), idx, weight).unsqueeze(2)
-            x = conv(torch.cat([x, skips[level]], 1), relu=True)
+            # conv(cat([interpolate(x), skip])) with x's share convolved at the coarse level (models/_common.py)
+            x = conv_interp_concat(conv, x, skips[level], idx, weight, interp_first=True, relu=True)
         return self.conv_out(x).squeeze(2)

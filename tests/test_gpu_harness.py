@@ -718,3 +718,32 @@ def test_share_gather_sum_equals_gather_then_weighted_sum(B, share, Cw, k, N):
     assert torch.equal(got, ref)
     for a, b in zip(torch.autograd.grad(got, (w, v), go), torch.autograd.grad(ref, (w, v), go)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first,four_d,relu", [(True, True, True), (False, False, True), (False, False, False)])
+def test_conv_interp_concat_equals_interpolate_then_convolve(first, four_d, relu, monkeypatch):
+    """models/_common.py: conv_interp_concat (the interpolated half of a U-Net's up-convolution convolved at the coarse
+    level, before three_interpolate) against the reference's order -- interpolate, concatenate, convolve (vrcnet.py
+    :287-296, ecg.py:143-150) -- values and every gradient at float32 summation-order tolerance."""
+    sys.path.insert(0, COMPLETION)
+    from models._common import conv_interp_concat, pointwise1d, pointwise2d
+    from model_utils import three_nn_upsampling
+    torch.manual_seed(21)
+    B, cc, cs, cout, nc, n = 4, 96, 40, 64, 192, 384
+    conv = (pointwise2d if four_d else pointwise1d)(cc + cs, cout).to(DEV)
+    pts_f, pts_c = torch.rand(B, n, 3, device=DEV), torch.rand(B, nc, 3, device=DEV)
+    idx, weight = three_nn_upsampling(pts_f, pts_c)
+    coarse = torch.randn(B, cc, *((1, nc) if four_d else (nc,)), device=DEV, requires_grad=True)
+    skip = torch.randn(B, cs, *((1, n) if four_d else (n,)), device=DEV, requires_grad=True)
+    params = (coarse, skip) + tuple(conv.parameters())
+    out = []
+    for ref in (False, True):
+        if ref:
+            monkeypatch.setenv("MVP_NO_CONV_BEFORE_INTERP", "1")
+        else:
+            monkeypatch.delenv("MVP_NO_CONV_BEFORE_INTERP", raising=False)
+        y = conv_interp_concat(conv, coarse, skip, idx, weight, interp_first=first, relu=relu)
+        out.append((y,) + torch.autograd.grad(y.square().sum(), params))
+    for a, b in zip(*out):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
