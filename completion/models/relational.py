@@ -68,7 +68,9 @@ class SA_module(nn.Module):
             query, key_pts, val_pts = torch.split(pointwise_conv(self.activation_fn(x), weight, bias), sizes, dim=1)
         keys = get_edge_features(key_pts, idx, idx_t).reshape(batch_size, -1, 1, num_points)   # (B, r*k, 1, N), channel = r_i*k + k_i
 
-        w = self.conv_w(torch.cat([query, keys], 1))     # (B, k*mid/share, 1, N)
+        # conv_w = ReLU, conv, ReLU, conv (vrcnet.py:28-33): the inner ReLU rides in the first convolution's epilogue
+        t = self.conv_w[0](torch.cat([query, keys], 1))
+        w = self.conv_w[3](self.conv_w[1](t, relu=True))  # (B, k*mid/share, 1, N)
         # weights are shared by the `share_planes` channel groups; the neighbours' values (conv3's output at the k
         # neighbours of every point) are gathered and summed in ONE kernel: no (B, mid, k, N) tensor, no repeat / product
         out = aggregate_shared_gathered(w.view(batch_size, -1, self.k, num_points), val_pts, idx, self.share_planes, idx_t)
