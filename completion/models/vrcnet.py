@@ -66,7 +66,13 @@ class Linear_ResBlock(nn.Module):
         self.af = nn.ReLU(inplace=False)
 
     def forward(self, feature):
-        return self.conv2(self.af(self.conv1(self.af(feature)))) + self.conv_res(feature)
+        """conv2(relu(conv1(relu(f)))) + conv_res(relu(f)).  The shortcut sees relu(f), not f: the reference's block
+        holds ONE nn.ReLU(inplace=True) (vrcnet.py:102) and applies it to its input first (:105) -- the input tensor is
+        overwritten before `self.conv_res(feature)` reads it.  The caller's tensor is overwritten too; this block leaves
+        it alone and Model.forward applies that ReLU where the reference's later code reads the overwritten feature
+        (pinned by tests/test_model_golden.py against the reference's own run)."""
+        act = self.af(feature)
+        return self.conv2(self.af(self.conv1(act))) + self.conv_res(act)
 
 
 class MSAP_SKN_decoder(nn.Module):
@@ -253,11 +259,14 @@ class Model(nn.Module):
             q = self._posterior(feat_x)
             p = _normal_dist(*self._normal(self.prior_infer(feat_y)))
             z = torch.cat([q.rsample(), p.rsample()], dim=0)
+            # posterior_infer1's in-place ReLU has overwritten feat_x by the time the reference decodes it (:461, :474)
+            feat_x = F.relu(feat_x)
             feat = torch.cat([feat_x, feat_x], dim=0)
             x, gt = torch.cat([x, x], dim=0), torch.cat([gt, gt], dim=0)
         else:
             feat = self.encoder(x)
             z = self._posterior(feat).rsample()
+            feat = F.relu(feat)      # overwritten in place by posterior_infer1 in the reference (:477, :486)
 
         outputs = self.decoder(feat + self.generator(z), x)
         coarse_raw, coarse_high, coarse, fine = [t.transpose(1, 2).contiguous() for t in outputs]
