@@ -11,9 +11,11 @@ TEST INFRASTRUCTURE.
 * `Recorder` / `Replayer`: the index-producing steps of a forward pass (FPS,
   kNN graphs, pooling neighbours, three_nn, ball_query) are recorded from the
   reference run; the replayer lets the code under test compute each of them
-  itself, COUNTS the rows that differ from the recorded ones, and hands the
-  recorded ones on -- so one neighbour flipped by a last-bit difference in a
-  distance shows up as a counted flip, not as a different network downstream.
+  itself, COUNTS the rows that differ from the recorded ones, checks that each
+  of them is a tie up to float32 rounding (`unexplained` stays empty), and
+  hands the recorded ones on -- so one neighbour flipped by a last-bit
+  difference in a distance shows up as a counted, explained flip, not as a
+  different network downstream.
 """
 import math
 import zlib
@@ -166,6 +168,7 @@ class Replayer:
             self.rec.setdefault(key, {})[int(i)] = v
         self.cursor = {}
         self.flips = {}
+        self.unexplained = []
         self.max_dist_err = 0.0
 
     def _next(self, key):
@@ -175,7 +178,7 @@ class Replayer:
         self.cursor[key] = i + 1
         return have[i]
 
-    def _idx(self, key, got):
+    def _idx(self, key, got, explain=None):
         want = self._next(key)
         g = got.detach().cpu().numpy()
         assert g.shape == want.shape, (key, g.shape, want.shape)
@@ -183,22 +186,60 @@ class Replayer:
         f = self.flips.setdefault(key, [0, 0])
         f[0] += int(rows.sum())
         f[1] += int(rows.size)
+        if rows.any() and explain is not None:
+            for r in np.nonzero(rows)[0]:
+                if not explain(int(r), g.reshape(-1, g.shape[-1])[r], want.reshape(-1, want.shape[-1])[r].astype(np.int64)):
+                    self.unexplained.append((key, int(r)))
         return torch.from_numpy(want.astype(np.int64)).to(device=got.device, dtype=got.dtype)
 
+    # A flip is EXPLAINED when the two answers are equally good up to float32 rounding of the inputs' distances:
+    # recomputed in float64 from the inputs the code under test actually saw.
+    TIE = 1e-5
+
+    @staticmethod
+    def _sq(a, b):
+        d = a.astype(np.float64) - b.astype(np.float64)
+        return (d * d).sum(axis=-1)
+
     def fps(self, fn):
-        return lambda xyz, m: self._idx(key_fps(xyz, m), fn(xyz, m))
+        def wrapped(xyz, m):
+            pts = xyz.detach().cpu().numpy()
+
+            def explain(b, got, want):
+                j = int(np.nonzero(got != want)[0][0])          # the first pick that differs; later ones follow from it
+                mind = np.min(self._sq(pts[b][:, None, :], pts[b][want[:j]][None, :, :]), axis=1)
+                return abs(mind[got[j]] - mind[want[j]]) <= self.TIE * mind.max()
+            return self._idx(key_fps(xyz, m), fn(xyz, m), explain)
+        return wrapped
+
+    def _ranked(self, key, got, queries, cands):
+        """queries (B, M, C), cands (B, N, C) numpy; got (B, M, k): a differing row is explained when the two lists'
+        sorted distances agree within TIE of the row's largest."""
+        m = queries.shape[1]
+
+        def explain(r, g_row, w_row):
+            b, q = divmod(r, m)
+            dg = np.sort(self._sq(cands[b][g_row], queries[b, q][None, :]))
+            dw = np.sort(self._sq(cands[b][w_row], queries[b, q][None, :]))
+            return np.abs(dg - dw).max() <= self.TIE * max(dw.max(), 1e-30)
+        return self._idx(key, got, explain)
 
     def knn(self, fn):
-        return lambda x, k: self._idx(key_knn(x, k), fn(x, k))
+        def wrapped(x, k):
+            pts = x.detach().transpose(1, 2).cpu().numpy()
+            return self._ranked(key_knn(x, k), fn(x, k), pts, pts)
+        return wrapped
 
     def knn_point_idx(self, fn):
-        return lambda pk, pi, po: self._idx(key_knn_point(pk, pi, po), fn(pk, pi, po))
+        def wrapped(pk, pi, po):
+            return self._ranked(key_knn_point(pk, pi, po), fn(pk, pi, po), po.detach().cpu().numpy(), pi.detach().cpu().numpy())
+        return wrapped
 
     def three_nn(self, fn):
         def wrapped(target, source):
             dist, idx = fn(target, source)
             key = key_three_nn(target, source)
-            idx = self._idx(key + "|idx", idx)
+            idx = self._ranked(key + "|idx", idx, target.detach().cpu().numpy(), source.detach().cpu().numpy())
             want = torch.from_numpy(self._next(key + "|dist")).to(dist.device)
             self.max_dist_err = max(self.max_dist_err, float((dist - want).abs().max()))
             return want, idx
