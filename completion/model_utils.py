@@ -26,6 +26,7 @@ from metrics import cd, fscore, emd  # noqa: E402
 from mm3d_pn2 import (furthest_point_sample, gather_points, grouping_operation,  # noqa: E402
                       ball_query, three_nn)
 from mm3d_pn2 import knn as knn_op  # noqa: E402
+from op_config import OPS  # noqa: E402
 from mvp_benchmark_amd.mm3d_pn2.functional import (ShareGatherSum, ShareWeightedSum, gather_max, gram_topk,  # noqa: E402
                                                    share_gather_sum, share_weighted_sum)
 
@@ -186,12 +187,12 @@ def aggregate_shared(w, values, share):
 
 def aggregate_shared_gathered(w, v, idx, share, idx_t=None):
     """aggregate_shared(w, get_edge_features(v, idx), share) -- the neighbours' values gathered AND summed with
-    their weights in one kernel (mvp_share_gather_sum): the (B, C, k, N) tensor of gathered values is never formed,
-    forward or backward (252 MB per SA_module of VRCNet at every level).  w (B,Cw,k,N), v (B,C,1,N) / (B,C,N) with
+    their weights in one kernel (mvp_share_gather_sum): the forward never forms the (B, C, k, N) tensor of gathered
+    values (252 MB per SA_module of VRCNet at every level; the backward builds its gradient once, as a temporary).  w (B,Cw,k,N), v (B,C,1,N) / (B,C,N) with
     C = share * Cw, idx (B,N,k); bit-identical to the two-step formulation."""
     if v.dim() == 4:
         v = v.squeeze(2)
-    if _on_op_layer(v) and ShareGatherSum.covers(share, v.size(2)) and not os.environ.get("MVP_NO_GATHER_SUM"):
+    if _on_op_layer(v) and ShareGatherSum.covers(share, v.size(2)) and OPS.gather_sum:
         return share_gather_sum(w.contiguous(), v.contiguous(), idx_t if idx_t is not None else neighbour_lists_k_major(idx))
     return aggregate_shared(w, get_edge_features(v, idx, idx_t), share)
 
@@ -225,7 +226,7 @@ def edge_preserve_sampling(feature_input, point_input, num_samples, k=10):
     pk = int(min(k, num_points))
     pn_idx = knn_point_idx(pk, point_input, point_output)
     pn_idx = pn_idx.detach().int()
-    if feature_input.is_cuda and feature_input.dtype == torch.float32 and not os.environ.get("MVP_NO_GATHER_MAX"):
+    if feature_input.is_cuda and feature_input.dtype == torch.float32 and OPS.gather_max:
         # gather + max over the pk neighbours in one kernel: the (B, C, pk, S) neighbour tensor is
         # never written (0.8 GB at VRCNet's first level, four passes over it per training step)
         neighbor_feature = gather_max(feature_input.contiguous(), pn_idx.contiguous())
@@ -259,7 +260,7 @@ def edge_preserve_features(feature_input, p_idx, pn_idx):
     """The feature half of edge_preserve_sampling for precomputed indices -> net (B,2C,S)."""
     batch_size, feature_size, _ = feature_input.size()
     num_samples, pk = pn_idx.size(1), pn_idx.size(2)
-    if feature_input.is_cuda and feature_input.dtype == torch.float32 and not os.environ.get("MVP_NO_GATHER_MAX"):
+    if feature_input.is_cuda and feature_input.dtype == torch.float32 and OPS.gather_max:
         neighbor_feature = gather_max(feature_input.contiguous(), pn_idx.contiguous())
     else:
         nbr_major = pn_idx.transpose(1, 2).contiguous().view(batch_size, pk * num_samples)
@@ -290,7 +291,7 @@ class GeometryAhead:
     for exactly the item it needs next.  Two lanes (round 4): lane 0 carries the FPS chain of the
     levels (m - 1 sequential rounds on <= 64 CUs each), lane 1 the neighbour searches, which only need
     a level's centres (`after=`) -- the searches of level l run beside the FPS of level l + 1 instead
-    of queueing behind it.  On the CPU (or with MVP_NO_SIDE_STREAM) everything runs in line.  The
+    of queueing behind it.  On the CPU (or with op_config side_lanes = 0) everything runs in line; side_lanes = 1 puts both on one lane.  The
     reference computes the same items at the same places in its forward
     (completion/models/vrcnet.py:236-296); only the order of independent launches differs."""
 
@@ -300,7 +301,7 @@ class GeometryAhead:
     def __init__(self, device):
         self.items, self.events, self.lane_of = {}, {}, {}
         self.main = self.side = None
-        if device.type == "cuda" and not os.environ.get("MVP_NO_SIDE_STREAM"):
+        if device.type == "cuda" and OPS.side_lanes > 0:
             self.main = torch.cuda.current_stream(device)
             self.side = GeometryAhead._streams.get(device)
             if self.side is None:
@@ -311,7 +312,7 @@ class GeometryAhead:
     def run(self, key, fn, lane=0, after=()):
         """value of fn() under `key`, computed (without autograd) on side stream `lane` once the
         items `after` (computed on other lanes) are there."""
-        if os.environ.get("MVP_ONE_SIDE_STREAM"):
+        if OPS.side_lanes == 1:
             lane = 0
         with torch.no_grad():
             if self.side is None:

@@ -176,4 +176,5 @@ class EF_encoder(nn.Module):
             # relu(conv(cat((skip, interpolate(up))))) with up's share convolved at the coarse level (models/_common.py)
             up = conv_interp_concat(conv, up, f[level], idx, weight, interp_first=False, relu=True)
         idx, weight = geo.take(("up", 0))
+        geo.join()      # every lane is back on the main stream (a lane whose last item nobody took would dangle under capture)
         return conv_interp_concat(self.conv8, up, f[0], idx, weight, interp_first=False, relu=False)

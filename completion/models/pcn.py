@@ -22,6 +22,10 @@ class PCN_encoder(nn.Module):
     """Two stacked PointNet stages: per-point MLP -> global max -> concat ->
     per-point MLP -> global max."""
 
+    # per-point maps and max-pools only: the feature does not depend on the order of the input points (VRCNet's
+    # training path relies on it to skip a full-size FPS that only permutes gt: models/vrcnet.py)
+    order_invariant = True
+
     def __init__(self, output_size=1024):
         super().__init__()
         self.conv1 = pointwise1d(3, 128)

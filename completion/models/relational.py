@@ -11,8 +11,6 @@ Op-layer calls per encoder forward: kNN graphs (model_utils.knn) at the four
 resolutions, FPS + gather + group inside edge_preserve_sampling on the way
 down, three_nn + three_interpolate on the way up.
 """
-import os
-
 import torch
 import torch.nn as nn
 
@@ -20,6 +18,7 @@ from model_utils import (GeometryAhead, aggregate_shared, aggregate_shared_gathe
                          knn_point_idx,
                          edge_preserve_sampling, get_edge_features, knn, three_nn_upsampling)
 from mm3d_pn2 import three_interpolate
+from op_config import OPS
 from models._common import conv_global_concat, conv_interp_concat, dense, pointwise2d
 from mvp_benchmark_amd.pointwise import pointwise_conv
 
@@ -60,7 +59,7 @@ class SA_module(nn.Module):
         # (B, C, k, N) intermediate) and gather the r and the mid mapped channels;
         # same parameters, same result up to fp32 summation order.
         idx_t = neighbour_lists_k_major(idx) if x.is_cuda else None         # one index tensor for both gathers
-        if os.environ.get("MVP_SA_SEPARATE_CONVS"):       # A/B: conv1 / conv2 / conv3 as three convolutions
+        if not OPS.stacked_projections:                   # A/B: conv1 / conv2 / conv3 as three convolutions
             act = self.activation_fn(x)
             query, key_pts, val_pts = self.conv1(act), self.conv2(act), self.conv3(act)
         else:
@@ -118,7 +117,7 @@ class SKN_Res_unit(nn.Module):
                                for _ in range(blocks)])
 
     def forward(self, feat, idx):
-        if os.environ.get("MVP_SA_SEPARATE_CONVS"):
+        if not OPS.stacked_projections:
             first, res = self.conv1(feat), self.conv_res(feat)
         else:                                             # conv1 and conv_res read the same input: one convolution
             first, res = torch.split(pointwise_conv(feat, torch.cat((self.conv1.weight, self.conv_res.weight), 0)),
@@ -215,4 +214,5 @@ class SA_SKN_Res_encoder(nn.Module):
             idx, weight = geo.take(("up", level))
             # conv(cat([interpolate(x), skip])) with x's share convolved at the coarse level (models/_common.py)
             x = conv_interp_concat(conv, x, skips[level], idx, weight, interp_first=True, relu=True)
+        geo.join()      # every lane is back on the main stream (a lane whose last item nobody took would dangle under capture)
         return self.conv_out(x).squeeze(2)

@@ -12,13 +12,12 @@ score-ranked gathers, and 4 Chamfer distances.
 """
 import math
 
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from model_utils import EF_expansion, calc_cd, furthest_point_sample, gather_points, gen_grid_up
+from op_config import OPS
 from models._common import conv_folded_concat, dense, eval_outputs, pointwise1d
 from models.pcn import PCN_encoder
 from models.relational import SA_module, SA_SKN_Res_encoder, SK_SA_module, SKN_Res_unit  # noqa: F401
@@ -243,15 +242,16 @@ class Model(nn.Module):
         if train:
             # the reconstruction path sees the (sub-sampled) complete shape; both paths are decoded
             # in ONE doubled batch (:450-455)
-            if gt.size(1) == x.size(2) and not os.environ.get("MVP_VRCNET_FULL_FPS"):
+            if gt.size(1) == x.size(2) and OPS.skip_full_fps_of_gt and getattr(self.encoder, "order_invariant", False):
                 # The reference samples x.size(2) of gt's points in FPS order (:451); when that is ALL of them the
                 # result is a permutation of gt, and the encoder that consumes it -- per-point maps and max-pools
                 # (PCN_encoder) -- cannot see the order of the points: on the op layer's convolution kernels (every
                 # output column is the same k-ordered fmaf chain wherever it sits) its feature is BIT-IDENTICAL for
                 # any order (tests/test_gpu_harness.py::test_vrcnet_full_fps_of_gt_changes_nothing).  Those 2047
-                # sequential FPS rounds (1.1 ms of the step, nothing can run beside them) are therefore not issued;
-                # MVP_VRCNET_FULL_FPS=1 restores the reference's launch sequence (round 3 had this as an opt-in:
-                # the library's GEMM tiles saw the order in the last bits).
+                # sequential FPS rounds (1.1 ms of the step, nothing can run beside them) are therefore not issued --
+                # only in front of an encoder that declares itself `order_invariant` (PCN_encoder does);
+                # op_config skip_full_fps_of_gt = False restores the reference's launch sequence (round 3 had this as
+                # an opt-in: the library's GEMM tiles saw the order in the last bits).
                 y = gt.transpose(1, 2).contiguous()
             else:
                 y = gather_points(gt.transpose(1, 2).contiguous(), furthest_point_sample(gt, x.size(2)))

@@ -81,6 +81,8 @@ def main():
     parser.add_argument('-c', '--config', help='path to config file', required=True)
     arg = parser.parse_args()
     args = AttrDict(yaml.safe_load(open(arg.config)))
+    import op_config
+    op_config.configure_from_cfg(args)
     if not args.load_model:
         raise ValueError('Model path must be provided to load model!')
     log_dir = os.path.dirname(args.load_model)

@@ -376,7 +376,11 @@ def train(args, log_dir, exp_name):
 
 
 def load_config(path):
-    return AttrDict(yaml.safe_load(open(path)))
+    """yaml -> attribute dict; the optional `op_layer:` mapping sets the op-layer switches (op_config.py)."""
+    args = AttrDict(yaml.safe_load(open(path)))
+    import op_config
+    op_config.configure_from_cfg(args)
+    return args
 
 
 def main():

@@ -1470,15 +1470,16 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(
   grad_xyz[a + 2] += g * (xyz1[a + 2] - xyz2[c + 2]);
 }
 
-// Tuning / A-B knobs of the auction.  Process-wide; the defaults come from the
-// environment ONCE (first use), mvp_emd_configure() overrides them at run time:
-//   MVP_EMD_CLUSTER=1|2|4|8   cap of the workgroups per cloud
-//   MVP_EMD_SAME_XCD=0        keep the write-through stores even when a cluster shares an XCD
-//   MVP_EMD_SPLIT=0|1|2|3     0: one kernel runs every round; 1: the rounds after the last four-bidders-per-wave
-//                             round run in the lean kernel (emd_lean.hip); 2: + cluster widths dealt out by load
-//                             at round 300 (33..64 clouds of > 4096 points); 3: + clouds of <= 4096 points finish
-//                             LDS-resident on one workgroup, in a launch of their own (emd_resident.hip); 4 (default):
-//                             ... inside the lean launch, on member 0 of the cloud's cluster (no launch boundary)
+// Tuning / A-B knobs of the auction.  Process-wide; compiled-in defaults, mvp_emd_configure() changes them at run time
+// (cluster, same_xcd, split, resident_cap).  The release library reads NOTHING from the environment; a build with
+// -DMVP_TEST_HOOKS (`make hooks` -> libmvpops_hooks.so, loaded by the tests / tools that need it) also takes, ONCE at first use,
+//   MVP_EMD_CLUSTER / MVP_EMD_SAME_XCD / MVP_EMD_SPLIT / MVP_EMD_RESIDENT_CAP   the same four knobs
+//   MVP_EMD_PLAN_ROUND / MVP_EMD_PLAN_EVERY / MVP_EMD_PLAN_WIDTHS               the tiered launch's plan (emd_lean.hip)
+//   MVP_EMD_TIERS_FAIL                                                          "the tiered kernel does not fit this device"
+// split: 0 one kernel runs every round; 1: the rounds after the last four-bidders-per-wave round run in the lean kernel
+// (emd_lean.hip); 2: + cluster widths dealt out by load at round 300 (33..64 clouds of >= 4096 points); 3: + clouds of
+// <= 4096 points finish LDS-resident on one workgroup, in a launch of their own (emd_resident.hip); 4: ... inside the lean
+// launch, on member 0 of the cloud's cluster; 5 (default): + gathered-bid rounds.
 // The results do not depend on any of them (bit-identical; tests/test_gpu_ops.py).
 struct EmdKnobs {
   int cluster, same_xcd, split;   // split: 0 one kernel, 1 + the lean kernel, 2 + planned cluster widths (emd_lean.hip), 3 + resident tail (own launch), 4 fused into the lean launch, 5 + gathered-bid rounds
@@ -1490,6 +1491,7 @@ static std::mutex g_knob_mutex;
 static EmdKnobs &emd_knobs_locked() {   // (callers hold g_knob_mutex)
   static EmdKnobs k = [] {
     EmdKnobs v{kMaxCluster, 1, 5, 300, 4096, 0ull, 16};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
+#ifdef MVP_TEST_HOOKS
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
     if (const char *e = getenv("MVP_EMD_SPLIT")) v.split = atoi(e) < 0 ? 0 : atoi(e) > 5 ? 5 : atoi(e);
@@ -1506,6 +1508,7 @@ static EmdKnobs &emd_knobs_locked() {   // (callers hold g_knob_mutex)
       }
       v.plan_widths = pat;
     }
+#endif
     return v;
   }();
   return k;

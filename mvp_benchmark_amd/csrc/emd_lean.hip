@@ -1744,7 +1744,11 @@ hipError_t emd_lean_launch(int b, int n, int w, const float *xyz1, float *dist, 
       int stop = r + plan_every + 256 > iters ? iters : r + plan_every;   // (no short last launch)
       int which = 2;
       void *args[] = {&b, &bpad, &n, &xyz1, &dist, &assignment, &eps, &iters, &scratch, &fast_ok, &stop, &which, &pattern};
-      static const bool refuse = std::getenv("MVP_EMD_TIERS_FAIL") != nullptr;   // (test hook: behave as if it did not fit)
+#ifdef MVP_TEST_HOOKS
+      static const bool refuse = std::getenv("MVP_EMD_TIERS_FAIL") != nullptr;   // (libmvpops_hooks.so only: behave as if it did not fit)
+#else
+      constexpr bool refuse = false;
+#endif
       e = refuse ? hipErrorCooperativeLaunchTooLarge
                  : hipLaunchCooperativeKernel(reinterpret_cast<const void *>(emd_lean_tiers_kernel), dim3(4 * bpad),
                                               dim3(kEmdThreads), args, 0, stream);

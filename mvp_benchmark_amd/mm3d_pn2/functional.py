@@ -394,10 +394,12 @@ class ShareWeightedSum(Function):
 
 class ShareGatherSum(Function):
     """out[b, s*Cw + m, p] = sum_k w[b, m, k, p] * v[b, s*Cw + m, idx[b, k, p]]: ShareWeightedSum with the gather of the
-    neighbours' values (the grouping operator) fused in -- the (B, share*Cw, k, N) tensor of gathered values is never
-    formed, forward or backward.  (w (B,Cw,k,N), v (B,share*Cw,Nsrc), idx (B,k,N) int32) -> (B, share*Cw, N);
-    differentiable in w and v; bit-identical to share_weighted_sum(w, grouping_operation(v, idx)).  The gradient of
-    v goes through the grouping operator's scatter (inverted index, no atomics)."""
+    neighbours' values (the grouping operator) fused in.  The FORWARD never forms the (B, share*Cw, k, N) tensor of gathered
+    values (written by the grouping kernel, read by the weighted sum and kept for its gradient in the two-step route); the
+    BACKWARD gathers again, emits grad_w and -- when v needs a gradient -- the gathered values' gradient as ONE
+    (B, share*Cw, k, N) temporary, which the grouping operator's scatter (inverted index, no atomics) sums into grad_v.
+    (w (B,Cw,k,N), v (B,share*Cw,Nsrc), idx (B,k,N) int32) -> (B, share*Cw, N); differentiable in w and v; bit-identical
+    to share_weighted_sum(w, grouping_operation(v, idx))."""
 
     LDS_BYTES = 96 * 1024
 
@@ -431,6 +433,8 @@ class ShareGatherSum(Function):
         grad_vals = _new(v, B, C, k, N)
         call("mvp_share_gather_sum_grad", v.device, B, share, Cw, k, n_src, N, w, v, idx, grad_out.data.contiguous(),
              grad_w, grad_vals)
+        if not ctx.needs_input_grad[1]:          # (frozen values: no scatter pass)
+            return grad_w, None, None
         scratch, nbytes, mode, key = _scatter_scratch(idx, None, B, n_src, k * N, 1)
         call("mvp_group_points_grad_ws", v.device, B, C, n_src, k, N, grad_vals, idx, grad_v, scratch, nbytes, mode)
         _scatter_commit(key, idx, None, scratch)

@@ -262,9 +262,7 @@ class _PointwiseConvMax(Function):
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         length = x3.size(2)
         gx = gw = gb = None
-        if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and g.dtype == torch.float32 \
-                and length <= 16384 and cout <= 4096 and (3 * cout + length) * 4 <= 30000 and B <= 65535 \
-                and x3.is_contiguous() and w2.is_contiguous():
+        if _conv_max_kernel_covers(x, weight) and g.dtype == torch.float32 and x3.is_contiguous() and w2.is_contiguous():
             gx = torch.empty_like(x3) if need_x else None
             gw = torch.empty_like(w2) if (need_w or need_b) else None
             gb = torch.empty(cout, dtype=torch.float32, device=x.device) if need_b else None
@@ -273,6 +271,9 @@ class _PointwiseConvMax(Function):
             call("mvp_pointwise_max_backward", x.device, B, cin, cout, length, x3, w2, g, idx.int(), gx, gw, gb, scratch,
                  nbytes)
             return (gx.view_as(x) if need_x else None, gw.view_as(weight) if need_w else None, gb)
+        # host tensors / other dtypes (the CPU tests): the same two index passes in PyTorch.  CUDA float32 shapes the
+        # kernel does not cover never get here (pointwise_conv_max routes them to conv + max under plain autograd: this
+        # formulation's expanded index tensors would cost more than the dense GEMMs)
         where = idx.unsqueeze(1).expand(B, cin, cout)                  # [b, ci, co] -> winning position of (b, co)
         if need_x:
             gx = torch.zeros_like(x3).scatter_add_(2, where, g.unsqueeze(1) * w2.t().unsqueeze(0)).view_as(x)
@@ -283,10 +284,29 @@ class _PointwiseConvMax(Function):
         return gx, gw, gb
 
 
+def _conv_max_kernel_covers(x, weight):
+    """Shapes mvp_pointwise_max_backward takes: its per-cloud sort of the winners lives in LDS ((3 Cout + L) * 4 <= 30000
+    bytes: L <= 4428 positions at Cout = 1024)."""
+    cout = weight.size(0)
+    length = x[0, 0].numel() if x.numel() else 0
+    return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and length <= 16384 and cout <= 4096 \
+        and (3 * cout + length) * 4 <= 30000 and x.size(0) <= 65535
+
+
+_conv_max_uncovered_seen = set()
+
+
 def pointwise_conv_max(x, weight, bias=None):
     """(W x + bias).max over the positions: x (B,Cin,N) / (B,Cin,H,W), weight (Cout,Cin,1[,1]) -> (B, Cout)."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
-        return _PointwiseConvMax.apply(x, weight, bias)
+        if not x.is_cuda or _conv_max_kernel_covers(x, weight):
+            return _PointwiseConvMax.apply(x, weight, bias)
+        shape = (weight.size(0), x[0, 0].numel())
+        if shape not in _conv_max_uncovered_seen:          # (once per shape)
+            _conv_max_uncovered_seen.add(shape)
+            import logging
+            logging.getLogger(__name__).info("conv -> max over %d positions x %d channels: outside the sparse backward kernel's "
+                                             "LDS budget, dense autograd route", shape[1], shape[0])
     return pointwise_conv(x, weight, bias).flatten(2).max(dim=2)[0]
 
 

@@ -69,7 +69,8 @@ def record_abi_calls(names):
 
 
 def test_cfg3_per_rank_step_ops_match_oracle(oracle, monkeypatch):
-    monkeypatch.setenv("MVP_VRCNET_FULL_FPS", "1")        # the reference's launch sequence, incl. the FPS of all of gt's points
+    import op_config
+    monkeypatch.setattr(op_config.OPS, "skip_full_fps_of_gt", False)   # the reference's launch sequence, incl. the FPS of all of gt's points
     import importlib
     import train
     args = train.load_config(os.path.join(COMPLETION, "cfgs", "vrcnet.yaml"))

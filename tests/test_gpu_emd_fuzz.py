@@ -18,15 +18,17 @@ def _cases(count, seed):
     return [fz.draw_case(rng) for _ in range(count)]
 
 
-@pytest.mark.parametrize("case", _cases(10, 2024), ids=lambda c: "b%d-n%d-it%d-eps%g-%s" % c[:5])
+@pytest.mark.parametrize("case", _cases(12, 2025), ids=lambda c: "b%d-n%d-it%d-eps%g-%s-w%d" % (c[:5] + (c[6],)))
 def test_emd_launch_sequences_agree_on_random_cases(case):
     import fuzz_emd_tiers as fz
     ok, what = fz.run_case(case)
     assert ok, (case, what)
 
 
-def test_fuzz_slice_covers_both_families():
-    """The slice holds tiered batches (33..64 clouds of >= 4096 points) and resident-size clouds, several input kinds."""
-    cases = _cases(10, 2024)
-    assert any(c[0] >= 33 and c[1] >= 4096 for c in cases) and any(c[1] <= 2048 for c in cases)
+def test_fuzz_slice_covers_every_family():
+    """The slice holds tiered batches (33..64 clouds of >= 4096 points), resident-size clouds, clusters of ONE workgroup
+    (forced, and by batch size: > 128 clouds) and several input kinds."""
+    cases = _cases(12, 2025)
+    assert any(33 <= c[0] <= 64 and c[1] >= 4096 for c in cases) and any(c[1] <= 2048 for c in cases)
+    assert any(c[6] == 1 for c in cases) and any(c[0] > 128 for c in cases)
     assert len(set(c[4] for c in cases)) >= 3

@@ -109,3 +109,31 @@ def test_gathered_full_batch_equals_plain_rounds(knobs, n):
     np.testing.assert_array_equal(out[2][2]["rounds"], out[5][2]["rounds"])
     np.testing.assert_array_equal(out[2][2]["bids"], out[5][2]["bids"])
     assert (out[5][2]["gathered_rounds"] > 0).all() and (out[2][2]["gathered_rounds"] == 0).all()
+
+
+def test_cfg4_n8192_full_batch_default_path_matches_oracle(oracle, knobs):
+    """BASELINE cfg 4, n = 8192 at its FULL batch on the DEFAULT launch sequence (split 5: tiered widths + gathered-bid
+    rounds) -- until round 5 covered only transitively (split 2 == split 0 == oracle at 8192; split 5 == split 2 at
+    16384 / 4096).  The four heaviest and the four lightest clouds against the exhaustive oracle directly (~10 s of CPU
+    each, OpenMP over the clouds), all 64 against the first kernel running every round alone."""
+    from mvp_benchmark_amd import _lib
+    b, n = 64, 8192
+    x1n, x2n = rand_clouds(195, b, n, 3), rand_clouds(196, b, n, 3)
+    x1, x2 = dev(x1n), dev(x2n)
+    knobs(split=_lib.EMD_DEFAULT_SPLIT)
+    assert _lib.EMD_DEFAULT_SPLIT == 5
+    d5, a5, r5 = _run(x1, x2, 0.004, 3000)
+    assert (r5["gathered_rounds"] > 0).all() and (r5["next_round"] == 0).all()
+    assert (r5["final_launch"] == 2).sum() >= 56 and len(set(r5["final_width"][r5["final_launch"] == 2].tolist())) >= 3
+    order = np.argsort(r5["bids"])
+    pick = np.concatenate([order[:4], order[-4:]])
+    od, oa, ost = oracle.emd_forward(x1n[pick], x2n[pick], 0.004, 3000, return_stats=True)
+    np.testing.assert_array_equal(a5[pick], oa)
+    np.testing.assert_array_equal(d5[pick], od)
+    np.testing.assert_array_equal(r5["rounds"][pick], ost[:, 0])
+    np.testing.assert_array_equal(r5["bids"][pick], ost[:, 1])
+    knobs(split=0)
+    d0, a0, r0 = _run(x1, x2, 0.004, 3000)
+    np.testing.assert_array_equal(a5, a0)
+    np.testing.assert_array_equal(d5, d0)
+    np.testing.assert_array_equal(r5["bids"], r0["bids"])

@@ -388,7 +388,7 @@ def test_vrcnet_full_fps_of_gt_changes_nothing(monkeypatch):
     encoder's output for gt, for gt in FPS order and for a random permutation agree to float32 rounding
     (per-point maps and max-pools cannot see the order) -- bit for bit on the op layer's convolution kernels;
     (iii) a training forward without that FPS (the default since round 4) and one with the reference's sequence
-    (MVP_VRCNET_FULL_FPS=1) return the same loss and CD to 1e-4 / 1e-3 and the same fine clouds as point sets
+    (op_config skip_full_fps_of_gt = False) return the same loss and CD to 1e-4 / 1e-3 and the same fine clouds as point sets
     (same seed for the latent samples; the decoder re-orders its own points by the order of its input)."""
     import importlib
     import train
@@ -409,10 +409,8 @@ def test_vrcnet_full_fps_of_gt_changes_nothing(monkeypatch):
     assert torch.equal(plain, by_fps) and torch.equal(plain, shuffled)
     outs = []
     for skip in (False, True):
-        if skip:
-            monkeypatch.delenv("MVP_VRCNET_FULL_FPS", raising=False)
-        else:
-            monkeypatch.setenv("MVP_VRCNET_FULL_FPS", "1")
+        import op_config
+        monkeypatch.setattr(op_config.OPS, "skip_full_fps_of_gt", skip)
         torch.manual_seed(11)
         with torch.no_grad():
             outs.append(net(partial, gt, alpha=0.5))
@@ -739,10 +737,8 @@ def test_conv_interp_concat_equals_interpolate_then_convolve(first, four_d, relu
     params = (coarse, skip) + tuple(conv.parameters())
     out = []
     for ref in (False, True):
-        if ref:
-            monkeypatch.setenv("MVP_NO_CONV_BEFORE_INTERP", "1")
-        else:
-            monkeypatch.delenv("MVP_NO_CONV_BEFORE_INTERP", raising=False)
+        import op_config
+        monkeypatch.setattr(op_config.OPS, "conv_before_interp", not ref)
         y = conv_interp_concat(conv, coarse, skip, idx, weight, interp_first=first, relu=relu)
         out.append((y,) + torch.autograd.grad(y.square().sum(), params))
     for a, b in zip(*out):

@@ -430,13 +430,15 @@ def test_emd_tiered_widths_ragged_batches_match_oracle(oracle, b):
 
 def test_emd_tiered_launch_refused_late_or_repeated_gives_the_same_bits():
     """A device the tiered kernel's grid does not fit on: the launcher must finish the auction with the
-    fixed-width kernel from the round the first lean launch stopped at.  Simulated in a child process
-    (MVP_EMD_TIERS_FAIL is read once per process); digest of the results against this process's."""
+    fixed-width kernel from the round the first lean launch stopped at.  Simulated in child processes that load
+    libmvpops_hooks.so (the release sources + -DMVP_TEST_HOOKS: the only build that reads MVP_EMD_TIERS_FAIL and the plan
+    knobs, once per process); digests of the results against each other and against the release library's."""
     import hashlib, subprocess, sys, os
     code = (
         "import sys, hashlib, numpy as np, torch\n"
         "sys.path.insert(0, %r)\n"
         "from mvp_benchmark_amd import _lib\n"
+        "_lib.LIB_PATH = _lib.LIB_PATH.replace('libmvpops.so', 'libmvpops_hooks.so')\n"     # the build with -DMVP_TEST_HOOKS: reads the MVP_EMD_* knobs
         "rng = np.random.default_rng(123)\n"
         "b, n = 40, 4096\n"
         "x1 = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32)).cuda(); x2 = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32)).cuda()\n"
@@ -1077,7 +1079,7 @@ def test_gather_max_matches_oracle_composition(oracle, b, c, n, p, k, kind):
 def test_gather_max_propagates_nan_like_torch_max():
     """A NaN among the neighbours gives NaN (and the first NaN as the winner), a row of -inf keeps -inf and the
     first neighbour -- torch.max's rules, i.e. what the gather_points + torch.max route of the same wrapper
-    (rows longer than the LDS strip, MVP_NO_GATHER_MAX) and the reference (model_utils.py:101-104) give."""
+    (rows longer than the LDS strip, op_config gather_max = False) and the reference (model_utils.py:101-104) give."""
     from mvp_benchmark_amd import _lib
     b, c, n, p, k = 2, 5, 300, 64, 8
     rng = np.random.default_rng(3)

@@ -11,11 +11,10 @@ g = torch.Generator().manual_seed(0)
 x1 = torch.rand(b, n, 3, generator=g).to(dev); x2 = torch.rand(b, n, 3, generator=g).to(dev)
 shape = os.environ.get("MVP_BENCH_SHAPE")   # e.g. "sphere", "chair:0.03" (gt + noise), "torus:indep": tools/emd_surfaces.py's clouds
 if shape:
-    import emd_surfaces
+    from mvp_benchmark_amd.synthetic import prediction_pair
     name, _, mode = shape.partition(":")
-    gt = emd_surfaces.SHAPES[name](g, b, n)
-    pred = emd_surfaces.SHAPES[name](g, b, n) if mode in ("", "indep") else gt + float(mode) * torch.randn(b, n, 3, generator=g)
-    x1, x2 = pred.float().to(dev).contiguous(), gt.float().to(dev).contiguous()
+    pred, gt = prediction_pair(name, mode or "indep", g, b, n)
+    x1, x2 = pred.to(dev), gt.to(dev)
 nbytes = _lib.emd_scratch_bytes(b, n)
 scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
 dist = torch.zeros(b, n, device=dev); ass = torch.zeros(b, n, dtype=torch.int32, device=dev)

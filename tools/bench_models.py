@@ -10,7 +10,10 @@ import train
 import mvp_benchmark_amd.pointwise as pw
 if "MVP_MFMA_TRAIN" in os.environ:                       # A/B of the training-path routing (pointwise.py)
     pw.MFMA_TRAIN = os.environ["MVP_MFMA_TRAIN"] == "1"
-if "MVP_NO_GATHER_SUM" in os.environ: pass   # (read by model_utils.aggregate_shared_gathered: the two-step formulation)
+import op_config
+# A/B of the networks' formulations: MVP_OPS="gather_sum=0,side_lanes=1" (completion/op_config.py)
+if os.environ.get("MVP_OPS"):
+    op_config.configure(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["MVP_OPS"].split(","))})
 if "MVP_MFMA_WGRAD_TRAIN" in os.environ:                 # A/B: only the weight gradients leave the library
     pw.MFMA_WGRAD_TRAIN = os.environ["MVP_MFMA_WGRAD_TRAIN"] == "1"
 REPS = int(os.environ.get("MVP_BENCH_REPS", "10"))

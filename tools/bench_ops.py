@@ -89,3 +89,28 @@ if which in ("all", "topk"):
         sq = (x * x).sum(1).contiguous()
         ms = timeit(lambda: gram_topk(dot, sq, k))
         print("gram top-k (%d,%d,%d) k=%d: %.3f ms  %.1f GB/s of the Gram matrix" % (b, n, n, k, ms, 4.0 * b * n * n / ms / 1e6), flush=True)
+if which in ("all", "harness"):
+    # The reference's own two timing harnesses, as it runs them:
+    #  * utils/metrics/CD/unit_test.py:38-62 `timings()`: 100 iterations of chamfer forward + backward at (32, 2000, 3) /
+    #    (32, 1000, 3), loss = d1.sum() + d2.sum() (it prints seconds per 100 iterations; nothing is recorded in the repo)
+    #  * utils/metrics/EMD/emd_module.py:90-104 `test_emd()`: ONE call at (20, 8192, 3), eps 0.05, 3000 iterations
+    import time
+    from mvp_benchmark_amd.metrics import emd
+    p1, p2 = R(32, 2000, 3).requires_grad_(), R(32, 1000, 3)
+    cham = cd()
+    def cd_iter():
+        d1, d2, _, _ = cham(p1, p2)
+        (d1.sum() + d2.sum()).backward()
+    for _ in range(3):
+        cd_iter()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(100):
+        cd_iter()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print("reference harness CD (unit_test.py:38-62): 100 x forward+backward at (32,2000,3)/(32,1000,3): %.4f s total, %.3f ms / iteration" % (t1 - t0, (t1 - t0) * 10), flush=True)
+    x1, x2 = R(20, 8192, 3), R(20, 8192, 3)
+    e = emd()
+    ms = timeit(lambda: e(x1, x2, 0.05, 3000), 3)
+    dist, ass = e(x1, x2, 0.05, 3000)
+    print("reference harness EMD (emd_module.py:90-104): (20,8192,3) eps 0.05, 3000 iterations: %.3f ms; mean sqrt(dist) %.5f; distinct targets %d of %d"
+          % (ms, dist.sqrt().mean().item(), int(torch.unique(ass[0]).numel()), ass.size(1)), flush=True)

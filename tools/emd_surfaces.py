@@ -18,41 +18,7 @@ from mvp_benchmark_amd import _lib  # noqa: E402
 dev = torch.device("cuda:0")
 
 
-def sphere(g, b, n):
-    v = torch.randn(b, n, 3, generator=g)
-    return 0.5 + 0.4 * v / v.norm(dim=2, keepdim=True)
-
-
-def torus(g, b, n):
-    u, v = 2 * np.pi * torch.rand(b, n, generator=g), 2 * np.pi * torch.rand(b, n, generator=g)
-    R, r = 0.3, 0.12
-    return torch.stack([0.5 + (R + r * torch.cos(v)) * torch.cos(u), 0.5 + (R + r * torch.cos(v)) * torch.sin(u),
-                        0.5 + r * torch.sin(v)], 2)
-
-
-def box(g, b, n):
-    p = torch.rand(b, n, 3, generator=g)
-    face = torch.randint(0, 6, (b, n), generator=g)
-    axis, side = face % 3, (face // 3).float()
-    p.scatter_(2, axis.unsqueeze(2), side.unsqueeze(2))
-    return 0.15 + 0.7 * p
-
-
-def chair(g, b, n):
-    """A crude MVP-like shape: seat + back (thin slabs' surfaces) + four legs (thin cylinders)."""
-    part = torch.rand(b, n, generator=g)
-    p = torch.rand(b, n, 3, generator=g)
-    seat = torch.stack([0.2 + 0.6 * p[..., 0], 0.2 + 0.6 * p[..., 1], 0.45 + 0.04 * (p[..., 2] > 0.5).float()], 2)
-    back = torch.stack([0.2 + 0.6 * p[..., 0], 0.76 + 0.04 * (p[..., 1] > 0.5).float(), 0.49 + 0.4 * p[..., 2]], 2)
-    ang = 2 * np.pi * p[..., 0]
-    leg = (p[..., 1] * 4).long().clamp(max=3)
-    cx, cy = 0.25 + 0.5 * (leg % 2).float(), 0.25 + 0.5 * (leg // 2).float()
-    legs = torch.stack([cx + 0.02 * torch.cos(ang), cy + 0.02 * torch.sin(ang), 0.05 + 0.4 * p[..., 2]], 2)
-    out = torch.where((part < 0.45).unsqueeze(2), seat, torch.where((part < 0.8).unsqueeze(2), back, legs))
-    return out
-
-
-SHAPES = {"sphere": sphere, "torus": torus, "box": box, "chair": chair}
+from mvp_benchmark_amd.synthetic import SHAPES, sphere  # noqa: E402
 
 
 def run(x1, x2, split):

@@ -17,15 +17,23 @@ KINDS = ["uniform", "mixed", "shells", "near", "dups", "surface"]
 
 
 def draw_case(rng):
-    """One random case: (b, n, iters, eps, kind, input seed).  Two families: the batches the tiered launch serves
-    (33..64 clouds of 4096 / 8192 points) and the small clouds the resident tail serves (any batch)."""
-    if rng.random() < 0.5:
+    """One random case: (b, n, iters, eps, kind, input seed, cluster).  Three families: the batches the tiered launch
+    serves (33..64 clouds of 4096 / 8192 points), the small clouds the resident tail serves (any batch), and -- round 5:
+    the round-4 campaign never drew one and missed a W = 1 bug -- clusters of ONE workgroup: batches of more than 128
+    clouds (the automatic width) or `cluster` forced to 1 / 2 on small batches."""
+    r = rng.random()
+    cluster = 0
+    if r < 0.4:
         b, n = int(rng.integers(33, 65)), int(rng.choice([4096, 4096, 8192]))
-    else:
+    elif r < 0.75:
         b, n = int(rng.choice([1, 2, 3, 7, 16, 40, 64])), int(rng.choice([1024, 2048, 2048, 3072, 4096]))
+    elif r < 0.85:
+        b, n = int(rng.choice([129, 160, 200])), int(rng.choice([1024, 2048]))
+    else:
+        b, n, cluster = int(rng.choice([1, 3, 16, 40])), int(rng.choice([1024, 2048, 4096, 8192])), int(rng.choice([1, 1, 2]))
     iters = int(rng.choice([700, 1200, 3000]))
     eps = float(rng.choice([0.004, 0.002, 0.008]))
-    return b, n, iters, eps, str(rng.choice(KINDS)), int(rng.integers(1 << 30))
+    return b, n, iters, eps, str(rng.choice(KINDS)), int(rng.integers(1 << 30)), cluster
 
 
 def make_inputs(b, n, kind, seed):
@@ -53,9 +61,9 @@ def make_inputs(b, n, kind, seed):
     return x1.float().contiguous(), x2.float().contiguous()
 
 
-def run(x1, x2, eps, iters, split, dev):
+def run(x1, x2, eps, iters, split, dev, cluster=0):
     from mvp_benchmark_amd import _lib
-    _lib.emd_configure(split=split)
+    _lib.emd_configure(split=split, cluster=cluster)
     b, n = x1.shape[:2]
     nbytes = _lib.emd_scratch_bytes(b, n)
     scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
@@ -70,20 +78,20 @@ def run(x1, x2, eps, iters, split, dev):
 def run_case(case, dev="cuda:0"):
     """-> (identical, description of what ran)."""
     from mvp_benchmark_amd import _lib
-    b, n, iters, eps, kind, seed = case
+    b, n, iters, eps, kind, seed, cluster = case
     x1, x2 = make_inputs(b, n, kind, seed)
     x1, x2 = x1.to(dev), x2.to(dev)
     try:
-        d0, a0, s0, _ = run(x1, x2, eps, iters, 0, dev)
+        d0, a0, s0, _ = run(x1, x2, eps, iters, 0, dev, cluster)
         ok, notes = True, []
         for split in (2, 3, 4, 5):
-            d, a, s, rec = run(x1, x2, eps, iters, split, dev)
+            d, a, s, rec = run(x1, x2, eps, iters, split, dev, cluster)
             ok = ok and torch.equal(d0, d) and torch.equal(a0, a) and torch.equal(s0, s)
             fl = rec["final_launch"]
             notes.append("split %d: launches %s widths %s" % (split, sorted(set(fl.tolist())),
                                                              sorted(set(rec["final_width"][fl > 0].tolist()))))
     finally:
-        _lib.emd_configure(split=_lib.EMD_DEFAULT_SPLIT)
+        _lib.emd_configure(split=_lib.EMD_DEFAULT_SPLIT, cluster=0)
     return ok, "; ".join(notes)
 
 
@@ -94,8 +102,8 @@ def main():
     for c in range(cases):
         case = draw_case(rng)
         ok, what = run_case(case)
-        print("case %2d: b %2d n %5d iters %4d eps %.3f %-7s -> %s | %s" % (
-            (c,) + case[:5] + ("identical" if ok else "MISMATCH", what)), flush=True)
+        print("case %2d: b %3d n %5d iters %4d eps %.3f %-7s cluster %d -> %s | %s" % (
+            (c,) + case[:5] + (case[6], "identical" if ok else "MISMATCH", what)), flush=True)
         bad += 0 if ok else 1
     print("mismatches:", bad)
     sys.exit(1 if bad else 0)
