@@ -106,6 +106,72 @@ __device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v
   return ((unsigned long long)mh << 32) | ml;
 }
 
+// Squared distances of P points to (x1, y1, z1) -- sqdist3's chain fma(dz, dz, fma(dy, dy, dx * dx)) -- two points per
+// instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on a register pair with one result per component,
+// rounded exactly as their scalar forms (three packed instructions per point instead of six; the CU's packed FP32
+// rate is what the 157 TFLOP/s vector peak counts).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f sqdist3_pair(float xa, float xb, float ya, float yb, float za, float zb, float x1, float y1,
+                                            float z1) {
+  const v2f dx = v2f{xa, xb} - x1, dy = v2f{ya, yb} - y1, dz = v2f{za, zb} - z1;
+  v2f m = dx * dx;
+  m = __builtin_elementwise_fma(dy, dy, m);
+  m = __builtin_elementwise_fma(dz, dz, m);
+  return m;
+}
+// distance of point i of a lane's P: pairs (i, i + 1) share their instructions (the compiler merges the two calls of
+// a pair); an odd last point takes the scalar chain
+template <int P>
+__device__ __forceinline__ float sqdist3_of(const float (&px)[P], const float (&py)[P], const float (&pz)[P], int i, float x1,
+                                            float y1, float z1) {
+  const int a = i & ~1;
+  if (a + 1 < P) {
+    const v2f m = sqdist3_pair(px[a], px[a + 1], py[a], py[a + 1], pz[a], pz[a + 1], x1, y1, z1);
+    return (i & 1) ? m.y : m.x;
+  }
+  return sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
+}
+
+// min(d, t) as ONE v_min_f32: no NaN ever enters here, so it equals the reference's `d < t ? d : t`
+// (furthest_point_sample_cuda.cu:62-66 `min(d, temp[k])`); spelled in assembly because __builtin_fminf adds a
+// canonicalising v_max_f32 in front (IEEE mode) and the select form costs v_cmp + wait state + v_cndmask.
+__device__ __forceinline__ float fmin_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// (x, y, z) of point `ci` of lane `hl` -- both wave-uniform -- out of the lanes' register arrays: a balanced tree of
+// scalar branches down to three v_readlane (registers cannot be indexed: the alternative, carrying the arg-max
+// point's coordinates through the update loop, costs three v_cndmask per point and three VGPRs)
+template <int LO, int HI, int P>
+__device__ __forceinline__ void pick_point(const float (&px)[P], const float (&py)[P], const float (&pz)[P], int ci, int hl,
+                                           float &x, float &y, float &z) {
+  if constexpr (HI - LO == 1) {
+    x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[LO]), hl));
+    y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[LO]), hl));
+    z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[LO]), hl));
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (ci < MID) pick_point<LO, MID, P>(px, py, pz, ci, hl, x, y, z);
+    else pick_point<MID, HI, P>(px, py, pz, ci, hl, x, y, z);
+  }
+}
+
+// wave_max_u64 that also reports whether more than one lane holds the maximal VALUE (high word)
+__device__ __forceinline__ unsigned long long wave_max_u64_dup(unsigned long long v, bool &several) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = wave_umax32(hi);
+  const unsigned long long holders = __ballot(hi == mh);  // never empty
+  several = (holders & (holders - 1ull)) != 0ull;
+  unsigned ml;
+  if (!several)  // wave-uniform
+    ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(holders));
+  else
+    ml = wave_umax32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
+}
+
 // P > 0: register-resident (n <= P*BS).  P == 0: streaming fallback.
 // WITH_DIST: dataset is a (N,N) distance matrix per cloud (F-FPS).
 template <int P, bool WITH_DIST>
@@ -405,8 +471,8 @@ __global__ __launch_bounds__(1024) void fps_sort_kernel(int n, int npad, const f
 // Tie round, out of line: every lane has copied its running minima to s_pt; the
 // lanes that hold the maximum rank their points by the reference's order on the
 // original indices; returns {thread << 4 | point} of the winner to every lane.
-template <int P>
-__device__ __noinline__ unsigned fps_resolve_tie(const float (*s_pt)[1024], const int (*s_pk)[1024],
+template <int P, int NT>
+__device__ __noinline__ unsigned fps_resolve_tie(const float (*s_pt)[NT], const int (*s_pk)[NT],
                                                  unsigned long long (*wbest)[16], int slot, float vbest) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   unsigned tk = 0u;  // {1023 - rev(slot), 1023 - k / 1024, i}: 10 + 10 + 4 bits
@@ -430,21 +496,29 @@ template <int P>
 __global__ __launch_bounds__(1024) void fps_sorted_kernel(int n, int m, const float *__restrict__ dataset,
                                                           const float4 *__restrict__ sorted,
                                                           float *__restrict__ temp, int *__restrict__ idxs) {
+  // (16 waves per cloud.  Round 5 also ran this kernel on 2 / 4 / 8 waves with P up to 32 points per lane -- lanes here
+  // are not the reference's threads, so the block size is free -- to pay the per-wave cost of a round fewer times: slower
+  // everywhere, e.g. (64, 2048 -> 2048) 1.41-1.80 ms against 1.12 for fps_kernel<2>: a round is bound by the dependent
+  // chain of ONE wave, which grows with the points a lane owns; profiles/r5_fps_experiments.txt)
+  constexpr int NW = 16;
+  constexpr int NT = 64 * NW;
   if (m <= 0) return;
   const int t = threadIdx.x, lane = t & 63;
   const int cloud = blockIdx.x;
   dataset += (size_t)cloud * n * 3;
-  sorted += (size_t)cloud * (1024 * P);
+  sorted += (size_t)cloud * (NT * P);
   temp += (size_t)cloud * n;
   idxs += (size_t)cloud * m;
   __shared__ unsigned long long wbest[2][16];
-  __shared__ float s_sel[2][4];
-  __shared__ int s_tie[2];  // last round (by parity) in which the maximum was not unique
-  __shared__ unsigned long long s_max[2];  // block maximum {value bits, a holder}, by round parity
+  __shared__ float s_sel[2][4];   // tie rounds: the resolved point
+  // every wave's candidate of the round, by round parity: {value bits << 32 | several holders << 10 | a holder thread}
+  // and that holder's point {original index bits, x, y, z} -- ONE barrier per round (see fps_kernel's round_reg)
+  __shared__ unsigned long long s_wkey[2][16];
+  __shared__ float4 s_wsel[2][16];
   // original indices ([i][t]: conflict-free): read only by the publishing lane
   // and in tie rounds; s_pt receives the running minima in tie rounds
-  __shared__ int s_pk[P][1024];
-  __shared__ float s_pt[P][1024];
+  __shared__ int s_pk[P][NT];
+  __shared__ float s_pt[P][NT];
 
   float px[P], py[P], pz[P], pt[P];
   float blo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
@@ -465,66 +539,72 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(int n, int m, const fl
 #pragma unroll
   for (int i = 1; i < P; ++i) lane_max = __builtin_fmaxf(lane_max, pt[i]);
   bool lane_dup = true;  // all valid points start equal
+  // the lane's arg-max point, carried from the last update of its wave (every wave with a valid point updates in
+  // round 1: every running minimum starts at 1e10)
+  int ci = 0;
+  int cpk = __float_as_int(sorted[t * P].w);
 
-  if (t < 2) {
-    s_tie[t] = 0;
-    s_max[t] = 0ull;
-  }
   if (t == 0) idxs[0] = 0;
+  if (t < 32) wbest[t >> 4][t & 15] = 0ull;   // (tie rounds reduce all 16 slots; only NW are ever written)
   float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (uniform: the LDS addresses below are scalar work)
   __syncthreads();
 
   for (int j = 1; j < m; ++j) {
+    const int par = j & 1;
     const float gx = __builtin_fmaxf(__builtin_fmaxf(blo[0] - x1, x1 - bhi[0]), 0.f);
     const float gy = __builtin_fmaxf(__builtin_fmaxf(blo[1] - y1, y1 - bhi[1]), 0.f);
     const float gz = __builtin_fmaxf(__builtin_fmaxf(blo[2] - z1, z1 - bhi[2]), 0.f);
     const bool need = sqdist3(gx, gy, gz) < lane_max;  // a lane of padding only: -inf, never
     if (__any(need)) {
       float best = -__builtin_inff(), second = -__builtin_inff();
+      ci = 0;
 #pragma unroll
       for (int i = 0; i < P; ++i) {
-        const float d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
-        pt[i] = d < pt[i] ? d : pt[i];
-        second = __builtin_fmaxf(second, __builtin_fminf(best, pt[i]));
+        const float d = sqdist3_of<P>(px, py, pz, i, x1, y1, z1);
+        pt[i] = fmin_raw(d, pt[i]);
+        const bool gt = pt[i] > best;    // strict: the first of equal maxima (a tie round re-ranks them anyway)
+        second = __builtin_amdgcn_fmed3f(best, second, pt[i]);   // = max(second, min(best, pt[i])) as best >= second
         best = __builtin_fmaxf(best, pt[i]);
+        ci = gt ? i : ci;
       }
       lane_max = best;
       lane_dup = second == best;  // the two largest coincide
+      cpk = s_pk[ci][t];
     }
     // lane_max >= 0 for a lane with a valid point (bits order like unsigned);
     // lanes of padding contribute the smallest key
     unsigned long long key = lane_max >= 0.f ? ((unsigned long long)__float_as_uint(lane_max) << 32) | (unsigned)t : 0ull;
-    key = wave_max_u64(key);
-    if (lane == 0) atomicMax(&s_max[j & 1], key);
-    lds_barrier();
-    key = s_max[j & 1];
-    if (t == 0) s_max[(j + 1) & 1] = 0ull;
-    const float vbest = __uint_as_float((unsigned)(key >> 32));
-    int tstar = (int)((unsigned)key & 0x3FFu);   // a holder of the maximum
-    // is the maximum attained once only?  (another lane, or twice in the holder)
-    if (__any(lane_max == vbest && (t != tstar || lane_dup)) && lane == 0) s_tie[j & 1] = j;
-    if (t == tstar) {  // publish, assuming it is (the common case)
-      int istar = 0;
-      float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-      for (int i = P - 1; i >= 0; --i) {
-        const bool hit = pt[i] == vbest;
-        istar = hit ? i : istar;
-        sx = hit ? px[i] : sx;
-        sy = hit ? py[i] : sy;
-        sz = hit ? pz[i] : sz;
+    bool several;
+    key = wave_max_u64_dup(key, several);
+    const int hl = (int)(key & 63ull);   // a lane that holds the wave's maximum
+    several |= __builtin_amdgcn_readlane((int)lane_dup, hl) != 0;
+    {
+      float hx, hy, hz;
+      pick_point<0, P, P>(px, py, pz, __builtin_amdgcn_readlane(ci, hl), hl, hx, hy, hz);
+      const int hpk = __builtin_amdgcn_readlane(cpk, hl);
+      if (lane == 0) {
+        s_wkey[par][wave] = key | (several ? 1024ull : 0ull);
+        s_wsel[par][wave] = make_float4(__int_as_float(hpk), hx, hy, hz);
       }
-      s_sel[j & 1][0] = __int_as_float(s_pk[istar][t]);
-      s_sel[j & 1][1] = sx;
-      s_sel[j & 1][2] = sy;
-      s_sel[j & 1][3] = sz;
     }
     lds_barrier();
-    if (s_tie[j & 1] == j) {  // block-uniform
+    // lanes 0..15 of every wave take one wave's candidate each; the maximal value names the winner; the maximum is
+    // attained once only iff one wave holds it and that wave saw one holder with one maximal point
+    const unsigned long long kw = (lane & 15) < NW ? s_wkey[par][lane & 15] : 0ull;
+    const float4 cw = s_wsel[par][(lane & 15) < NW ? (lane & 15) : 0];
+    const unsigned hi = (unsigned)(kw >> 32);
+    const unsigned mh = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_umax32(hi));
+    const unsigned long long hold = __ballot(hi == mh) & 0xFFFFull;   // row 0: one lane per wave of the block
+    const int ww = (int)__builtin_ctzll(hold);
+    const unsigned lo_w = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kw, ww);
+    const float vbest = __uint_as_float(mh);
+    int old;
+    if (__builtin_expect((hold & (hold - 1ull)) != 0ull || (lo_w & 1024u) != 0u, 0)) {   // block-uniform: a tie round
 #pragma unroll
       for (int i = 0; i < P; ++i) s_pt[i][t] = pt[i];
-      const unsigned r = fps_resolve_tie<P>(s_pt, s_pk, wbest, j & 1, vbest);
-      tstar = (int)(r >> 4);
+      const unsigned r = fps_resolve_tie<P, NT>(s_pt, s_pk, wbest, par, vbest);
+      const int tstar = (int)(r >> 4);
       const int istar = (int)(r & 15u);
       if (t == tstar) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -535,17 +615,23 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(int n, int m, const fl
           sy = hit ? py[i] : sy;
           sz = hit ? pz[i] : sz;
         }
-        s_sel[j & 1][0] = __int_as_float(s_pk[istar][t]);
-        s_sel[j & 1][1] = sx;
-        s_sel[j & 1][2] = sy;
-        s_sel[j & 1][3] = sz;
+        s_sel[par][0] = __int_as_float(s_pk[istar][t]);
+        s_sel[par][1] = sx;
+        s_sel[par][2] = sy;
+        s_sel[par][3] = sz;
       }
       lds_barrier();
+      old = __builtin_amdgcn_readfirstlane(__float_as_int(s_sel[par][0]));
+      x1 = s_sel[par][1];
+      y1 = s_sel[par][2];
+      z1 = s_sel[par][3];
+      lds_barrier();   // (s_sel[par] may be rewritten by a tie two rounds on; wbest likewise)
+    } else {
+      old = __builtin_amdgcn_readlane(__float_as_int(cw.x), ww);
+      x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw.y), ww));
+      y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw.z), ww));
+      z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw.w), ww));
     }
-    const int old = __builtin_amdgcn_readfirstlane(__float_as_int(s_sel[j & 1][0]));
-    x1 = s_sel[j & 1][1];
-    y1 = s_sel[j & 1][2];
-    z1 = s_sel[j & 1][3];
     if (t == 0) idxs[j] = old;
   }
 #pragma unroll

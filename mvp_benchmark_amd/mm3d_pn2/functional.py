@@ -96,6 +96,9 @@ def _scatter_commit(key, idx, weight, scratch):
 
 
 # ------------------------------------------------------------------ sampling
+FPS_SORTED_MIN_N = 8193      # clouds of at least this many points (<= 16384) take the Morton-sorted kernel (csrc/fps.hip)
+
+
 class FurthestPointSampling(Function):
     """D-FPS: start at point 0, repeatedly add the point farthest from the
     chosen set.  (B, N, 3) float32, num_points -> (B, num_points) int32."""
@@ -106,7 +109,7 @@ class FurthestPointSampling(Function):
         B, N = points_xyz.shape[:2]
         out = _new(points_xyz, B, num_points, dtype=torch.int32, zero=True)
         scratch = _new(points_xyz, B, N).fill_(1e10)      # running min-distances
-        if 8192 < N <= 16384 and num_points > 1:
+        if FPS_SORTED_MIN_N <= N <= 16384 and num_points > 1:
             # the largest clouds: Morton-sorted copy + wave-level skipping of the distance update (same indices)
             nbytes = fps_scratch_bytes(B, N)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=points_xyz.device)
