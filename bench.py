@@ -454,7 +454,7 @@ def run_vrcnet_train(args, rank, world, dev):
     net = importlib.import_module("models.vrcnet").Model(cfg).to(dev)
     net = train.wrap_ddp(net, dev, world, cfg)
     torch.manual_seed(1000 * (rank + 1))      # per-rank dropout / rsample streams
-    opt = torch.optim.Adam(unwrap(net).parameters(), lr=cfg.lr, betas=(0.9, 0.999))
+    opt = torch.optim.Adam(unwrap(net).parameters(), lr=cfg.lr, betas=(0.9, 0.999), fused=True)   # (as completion/train.py builds it)
     g = torch.Generator().manual_seed(1000 + rank)
     gt = torch.rand(B, cfg.num_points, 3, generator=g).to(dev)
     partial = torch.rand(B, 2048, 3, generator=g).to(dev).transpose(2, 1).contiguous()

@@ -47,7 +47,7 @@ for name in ("vrcnet", "ecg", "pcn"):
     args = train.load_config(os.path.join(ROOT, "completion", "cfgs", name + ".yaml"))
     args.load_model = None
     net = importlib.import_module("models." + name).Model(args).to(dev).train()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=os.environ.get("MVP_FOREACH_ADAM") != "1")   # (fused: as completion/train.py builds it)
     gt = torch.rand(32, 2048, 3, generator=g).to(dev)
     partial = gt.transpose(2, 1).contiguous()
     def step():

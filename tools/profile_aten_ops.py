@@ -11,7 +11,7 @@ g = torch.Generator().manual_seed(0)
 for name in sys.argv[1:] or ("vrcnet",):
     args = train.load_config(os.path.join(ROOT, "completion", "cfgs", name + ".yaml")); args.load_model = None
     net = importlib.import_module("models." + name).Model(args).to(dev).train()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
     gt = torch.rand(32, 2048, 3, generator=g).to(dev); partial = gt.transpose(2, 1).contiguous()
     def step():
         opt.zero_grad(); _, _, loss = net(partial, gt, alpha=0.5); loss.backward(); opt.step()

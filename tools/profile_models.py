@@ -17,7 +17,7 @@ for name in names or ("vrcnet", "ecg"):
     if hires:
         args.num_points = 8192
     net = importlib.import_module("models." + name).Model(args).to(dev).train()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
     gt = torch.rand(32, 2048, 3, generator=g).to(dev)
     partial = gt.transpose(2, 1).contiguous()
     if hires:
