@@ -16,6 +16,11 @@
 //   emd_lean_kernel<W>      every cloud on the cluster width the first kernel ran with
 //   emd_lean_tiers_kernel   from round 300 on: the workgroups dealt out again, 8 .. 2 per cloud by the
 //                           clouds' load (a launch lasts as long as its slowest cloud; DESIGN.md 5.2, notebook 5e)
+// The round loop of emd_lean_body is kept in four fragments included into it (round 5; one file had grown to 1766 lines):
+//   emd_lean_bid.inc             Bid: one wave per bidder (both round shapes)
+//   emd_lean_round_plain.inc     plain rounds: bid atomics, all-gather, GetMax, Assign
+//   emd_lean_round_gathered.inc  gathered-bid rounds: bid records, one cluster-wide wait, every member settles every bid
+//   emd_lean_round_end.inc       list sizes, hand-over / stop checks, price bounds, entry into the gathered rounds
 #include <cstdlib>
 #include <type_traits>
 
@@ -416,352 +421,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     float pend_inc = 0.f;
     bool alarm = false;
     {
-    // ---------------- Bid (emd_cuda.cu:95-179): one wave per bidder
-    // Every bidder's record is in LDS (a list never outgrows the hand-over's <= kLeanCap
-    // persons).  Bids differ in length (4k to 16k cycles), so a wave that finishes draws the
-    // next list position from a shared counter instead of owning every 16th one: the phase
-    // lasts sum / 16 instead of the longest pair.  (The loop is bounded independently of the
-    // drawn position.)
-    int u = wave;
-    for (int guard = 0; guard <= kRecCap && u < U; ++guard) {
-      const float4 ra = s_rq[cur][u];
-      const int4 rb = s_ri[cur][u];
-      int drawn = 0;
-      const int j = rb.x;
-      const float qx = ra.x, qy = ra.y, qz = ra.z;
-      const int p1 = rb.y, p2 = rb.z;
-#ifdef MVP_EMD_PROFILE
-      const long long tb0 = __builtin_readcyclecounter();
-      int prof_cells = 0;
-#endif
-      // grid coordinates of the bidder (emd_cell's arithmetic) and its home cell
-      // (wave-uniform work on the vector unit: lane l < 6 takes axis l % 3 -- one chain instead of three here,
-      // and the value the cube's six bounds start from below)
-      const int ax = lane < 3 ? lane : lane - 3;
-      const float f_ax = ((ax == 0 ? qx : ax == 1 ? qy : qz) - (ax == 0 ? gg.lox : ax == 1 ? gg.loy : gg.loz)) * gg.invh;
-      const int ci_ax = min(gg.g - 1, max(0, (int)f_ax));
-      const int cix = __builtin_amdgcn_readlane(ci_ax, 0), ciy = __builtin_amdgcn_readlane(ci_ax, 1),
-                ciz = __builtin_amdgcn_readlane(ci_ax, 2);
-      const int c0 = (ciz * gg.g + ciy) * gg.g + cix;
-
-      // (1) seed: second-largest exact value among DISTINCT real objects --
-      // the home cell's members plus the previous best / second best when
-      // they live elsewhere.  Two real objects reach it, so it is a valid
-      // lower bound of the final second-best value.
-      BidState st;
-      st.b1 = -1e9f;
-      st.b2 = -1e9f;
-      st.bk = -1;
-      st.b2k = -1;
-      st.bp = 0.f;
-      st.bc = 0x7FF;
-      const int s0 = c_start[c0], s1 = c_start[c0 + 1];
-      // One pass, one value per lane: lanes 0.. take the home cell's members, lanes 62 / 63 the
-      // previous best / second best when they live in another cell (the slots are cell-sorted:
-      // outside [s0, s1)).  p1 != p2 (distinct objects of the last search) or -1.
-      int seed_slot = s0 + lane;
-      bool seed_valid = seed_slot < s1;
-      if (lane >= kWave - 2) {
-        seed_slot = lane == kWave - 2 ? p1 : p2;
-        seed_valid = seed_slot >= 0 && (seed_slot < s0 || seed_slot >= s1);
-      }
-      // (issued unconditionally: straight-line code up to the reduction)
-      const float4 o_seed = ld_obj(seed_valid ? seed_slot : 0);
-      {
-        float seed_b2;
-        if (__builtin_expect(s1 - s0 <= kWave - 2, 1)) {
-          const bool valid = seed_valid;
-          float v = -__builtin_inff();
-          if (valid) v = emd_value(sqdist3(o_seed.x - qx, o_seed.y - qy, o_seed.z - qz), o_seed.w);
-          if (__builtin_expect(__builtin_popcountll(__ballot(valid)) < 2, 0)) {  // rare: the first 64 slots instead
-            const float4 o = ld_obj(lane);
-            v = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
-          }
-          seed_b2 = emd_wave_second(v);   // (two 6-instruction DPP reductions; the merge-step form was ~55: 34.57 -> 34.43 ms, noise)
-        } else
-        {
-          float a1 = -1e9f, a2 = -1e9f;
-          // (the hint objects' load is issued first: it shares the round trip of the home cell's)
-          const bool hint = (lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0);
-          float4 oh = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (hint) oh = ld_obj(lane == 0 ? p1 : p2);
-          for (int s = s0 + lane; s < s1; s += kWave) {
-            const float4 o = ld_obj(s);
-            top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
-          }
-          bool extra = false;
-          if (hint) {
-            const float4 o = oh;
-            if (emd_cell(gg, o.x, o.y, o.z) != c0) {
-              extra = true;
-              top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
-            }
-          }
-          const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
-          if (__builtin_expect(have < 2, 0)) {  // wave-uniform; rare: fall back to the first 64 slots
-            const float4 o = ld_obj(lane);
-            a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
-            a2 = -1e9f;
-          }
-          seed_b2 = wave_second_largest(a1, a2);
-        }
-        st.tm = (3.0f - seed_b2) + kMargin;
-      }
-#ifdef MVP_EMD_PROFILE
-      const long long tb1 = __builtin_readcyclecounter();
-      const float prof_tm_seed = st.tm;
-      long long t_visit = 0;
-      int n_visit = 0, prof_fold = 0, prof_more = 0;
-#endif
-
-      // (2) Only cells that intersect the cube |o - q|_inf <= tm can hold a
-      // relevant object (prices are >= 0).  Enumerate that sub-box of the
-      // grid 64 cells at a time and test each cell's exact bounding box and
-      // price lower bound; (3) visit the survivors, 4 cells per step with 16
-      // lanes each.
-      const int sub = lane >> 4, sl = lane & 15;
-      unsigned short *wl = w_list[wave];
-      int nlist = 0;
-      // (3) visit listed cells, 16 per step: each 16-lane row takes 4 cells
-      // (a cell holds ~10 objects), so 4 independent 16-byte loads per lane are
-      // in flight at once and a typical bid (~10 surviving cells) needs ONE
-      // dependent memory round trip here.
-      auto visit = [&]() {
-#ifdef MVP_EMD_PROFILE
-        const long long tv0 = __builtin_readcyclecounter();
-        n_visit += (nlist + 15) / 16;
-#endif
-        for (int k0 = 0; k0 < nlist; k0 += 16) {
-          // (straight-line: the four list entries, then the four cells' offsets, are read unconditionally -- entries
-          // behind the list's end are clamped and discarded -- so that each set shares ONE LDS round trip; guarded by
-          // `k < nlist` the compiler put a full wait behind every single read: eight dependent trips per step)
-          int s[4], s1[4], cw[4], m0[4], m1[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cw[r] = wl[min(k0 + r * 4 + sub, 4 * kRowListCap - 1)];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int cc = min(cw[r] & 0x7FF, kMaxCells - 1);
-            m0[r] = c_start[cc];
-            m1[r] = c_start[cc + 1];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int q = cw[r] >> 11;   // chunk of 16 members of the cell
-            const bool in = k0 + r * 4 + sub < nlist;
-            const int b0 = m0[r] + 16 * q;
-            s[r] = in ? b0 + sl : 0;
-            s1[r] = in ? (q == 31 ? m1[r] : min(m1[r], b0 + 16)) : 0;   // (chunk 31 stands for everything behind it: cells of > 512 members)
-          }
-          bool more = true;
-          while (more) {  // (a second pass only for cells of more than 32 members)
-            float4 o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              o[r] = s[r] < s1[r] ? ld_obj(s[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
-              const float tq = st.tm - o[r].w;
-              const bool ps = s[r] < s1[r] && tq >= 0.f && sd <= tq * tq;
-              const unsigned long long m = __ballot(ps);
-#ifdef MVP_EMD_PROFILE
-              prof_fold += __builtin_popcountll(m);
-#endif
-              if (m) emd_fold<GM>(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm, o[r].w, cw[r]);
-            }
-            // cells with more than 16 members (rare): next 16
-            bool mine = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              s[r] += 16;
-              mine |= s[r] < s1[r];
-            }
-            more = __builtin_expect(__any(mine), 0);
-#ifdef MVP_EMD_PROFILE
-            prof_more += more ? 1 : 0;
-#endif
-          }
-        }
-        nlist = 0;
-#ifdef MVP_EMD_PROFILE
-        t_visit += __builtin_readcyclecounter() - tv0;
-#endif
-      };
-      int nsub = 0;          // cells tested
-      bool linear = false;
-      {
-        int ix0, iy0, iz0, nx, ny, nz;
-        {
-          const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
-          const float gmax = (float)(gg.g - 1);
-          // the six bounds in six lanes of ONE instruction stream (lane l: axis l % 3, lower bound for
-          // l < 3, upper bound otherwise) instead of six wave-uniform chains on the vector unit
-          const int bound = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(lane < 3 ? f_ax - r : f_ax + r), 0.f), gmax);
-          ix0 = __builtin_amdgcn_readlane(bound, 0);
-          iy0 = __builtin_amdgcn_readlane(bound, 1);
-          iz0 = __builtin_amdgcn_readlane(bound, 2);
-          nx = __builtin_amdgcn_readlane(bound, 3) - ix0 + 1;
-          ny = __builtin_amdgcn_readlane(bound, 4) - iy0 + 1;
-          nz = __builtin_amdgcn_readlane(bound, 5) - iz0 + 1;
-        }
-        const int nxy = nx * ny;
-        nsub = nxy * nz;
-        // approximate reciprocals are enough: (i + 0.5) / m is >= 0.5/144 away
-        // from an integer, far above the 1 ulp error of v_rcp_f32
-        const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
-        // When the search cube covers most of the grid (high prices everywhere,
-        // e.g. a clustered prediction against a spread target) the cell
-        // machinery only adds overhead: scan the cell-sorted objects linearly,
-        // 4 x 64 per step, with the same lossless filter.
-        linear = 2 * nsub > ncell;
-        if (__builtin_expect(linear, 0)) {
-          for (int base = 0; base < n; base += 4 * kWave) {
-            float4 o[4];
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = ld_obj(base + r * kWave + lane);  // n % 1024 == 0
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
-              const float tq = st.tm - o[r].w;
-              const bool ps = tq >= 0.f && sd <= tq * tq;
-              const unsigned long long m = __ballot(ps);
-              if (m) emd_fold<GM>(st, m, emd_value(sd, o[r].w), base + r * kWave + lane, n, tpu, sc.perm, o[r].w, 0x7FF);
-            }
-          }
-        }
-        for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
-          const int i = cb + lane;
-          bool cpass = false;
-          int extra = 0;
-          int c = 0;
-          if (i < nsub) {
-            // exact small-integer division via float (i < 1728, divisors <= 144)
-            const int kz = (int)(((float)i + 0.5f) * inv_nxy);
-            const int rem = i - kz * nxy;
-            const int ky = (int)(((float)rem + 0.5f) * inv_nx);
-            const int kx = rem - ky * nx;
-            c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
-            const float4 cl = c_lo[c], ch = c_hi[c];
-            const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
-            const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
-            const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
-            const float tq = st.tm - cl.w;
-            cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
-            extra = cpass ? (int)ch.w : 0;
-          }
-          // A cell is listed once per chunk of 16 members (round 2 listed cells of 17..32 members twice):
-          // everything of the cell travels in the round trips of the visit steps, 16 chunks per step, instead
-          // of in dependent passes of 16 members each -- on surface-shaped clouds (MVP's: 30-200 objects in an
-          // occupied cell) a visit took 3-8 such extra passes (profiles/r4_emd_surfaces.txt).  The first two
-          // chunks are placed by the lanes themselves; cells of more than 32 members (none in most searches on
-          // uniform clouds) are taken one by one below.
-          const bool big = extra >= 1, huge = extra >= 2;
-          const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
-          unsigned long long hmask = __ballot(huge);
-          if (cpass) {
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(bmask & lt);
-            wl[pos] = (unsigned short)c;
-            if (big) wl[pos + 1] = (unsigned short)(c | (1 << 11));
-          }
-          nlist += __builtin_popcountll(cmask) + __builtin_popcountll(bmask);
-          while (__builtin_expect(hmask != 0ull, 0)) {
-            const int l = (int)__builtin_ctzll(hmask);
-            hmask &= hmask - 1ull;
-            const int cc = __builtin_amdgcn_readlane(c, l), ne = __builtin_amdgcn_readlane(extra, l) - 1;   // chunks 2 .. extra
-            if (nlist + ne > 4 * kRowListCap) visit();
-            if (lane < ne) wl[nlist + lane] = (unsigned short)(cc | ((lane + 2) << 11));
-            nlist += ne;
-          }
-          if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells' first two chunks
-  #ifdef MVP_EMD_PROFILE
-          prof_cells += __builtin_popcountll(cmask);
-  #endif
-        }
-      }
-      visit();
-#ifdef MVP_EMD_PROFILE
-      if (lane == 0 && it >= 100) {
-        const long long d = __builtin_readcyclecounter() - tb0;
-        int bkt = 0;
-        while (bkt < 7 && d >= (2000ll << bkt)) ++bkt;
-        atomicAdd(&s_hist[bkt], 1ull);
-        atomicAdd(&s_hist[8], (unsigned long long)nsub);
-        atomicAdd(&s_hist[9], (unsigned long long)prof_cells);
-        atomicAdd(&s_hist[10], 1ull);
-        if (linear) atomicAdd(&s_hist[11], 1ull);
-        atomicAdd(&s_hist[12], (unsigned long long)d);
-        atomicAdd(&s_hist2[0], (unsigned long long)(tb1 - tb0));
-        atomicAdd(&s_hist2[1], (unsigned long long)t_visit);
-        atomicAdd(&s_hist2[2], (unsigned long long)n_visit);
-        atomicAdd(&s_hist2[3], (unsigned long long)prof_fold);
-        atomicAdd(&s_loose[d >= 10000 ? 1 : 0][0], (prof_tm_seed - ((3.0f - st.b2) + kMargin)) * gg.invh);
-        atomicAdd(&s_loose[d >= 10000 ? 1 : 0][1], prof_tm_seed * gg.invh);
-        unsigned long long *sl = s_slow[d >= 10000 ? 1 : 0];
-        atomicAdd(&sl[0], 1ull);
-        atomicAdd(&sl[1], (unsigned long long)nsub);
-        atomicAdd(&sl[2], (unsigned long long)prof_cells);
-        atomicAdd(&sl[3], (unsigned long long)n_visit);
-        atomicAdd(&sl[4], (unsigned long long)prof_more);
-        atomicAdd(&sl[5], (unsigned long long)prof_fold);
-        atomicAdd(&sl[6], (unsigned long long)(tb1 - tb0));
-        atomicAdd(&sl[7], (unsigned long long)t_visit);
-      }
-#endif
-      if (st.bk < 0) {  // cannot happen (>= 2 objects always survive); never index with -1
-        if (lane == 0) s_err = 1;
-        st.bk = 0;
-        st.b2k = -1;
-      }
-      if (lane == 0) {
-        const float inc = st.b1 - st.b2 + eps;
-        st_person_hi(j, st.bk, st.bk, st.b2k, inc);
-        if constexpr (GM) {
-          // The bid as a granule at this bidder's position of the cloud-wide order: two 8-byte words, each with a
-          // tag of the round -- {increment | object 14 | bidder 14 | tag 4}, {the object's new price | second-best
-          // slot + 1 (next round's hint) 15 | its cell 11 | the bidder's member 3 | tag 3} -- so that every member can settle it without
-          // reading anything else.  (A position below the cloud's bidder count is rewritten every round of its
-          // parity: the tags only have to tell a round from the one two before.)
-          const float np = st.bp + inc;
-          const u64 g0 = ((u64)__float_as_uint(inc) << 32) | ((u64)(unsigned)st.bk << 18) | ((u64)(unsigned)j << 4) |
-                         (u64)(eg % 15u + 1u);
-          const u64 g1 = ((u64)__float_as_uint(np) << 32) | ((u64)(unsigned)(st.b2k + 1) << 17) |
-                         ((u64)(unsigned)(st.bc & 0x7FF) << 6) | ((u64)(unsigned)wg << 3) | (u64)(eg % 7u + 1u);
-          u64 *slot = bid_area + (size_t)(eg & 1u) * kGStride + 2 * (size_t)(goff + u);
-          if (same_xcd) {
-            __hip_atomic_store(slot, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(slot + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          } else {
-            __hip_atomic_store(slot, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          // The member's word of the round ("all my bids are out; everything I stored in earlier rounds is performed"
-          // -- the previous settle ended with a drain): raised with the member's last bid.  It is what the others
-          // spin on (W words per poll instead of every bid: polling the bids themselves by every waiting wave of 256
-          // CUs saturated the L2 and doubled the round); only a hint for the bids -- each carries its own tags.
-#ifdef MVP_EMD_HBTOP
-          if (false) {
-#else
-          if (atomicAdd(&s_pub, 1) == U - 1) {
-#endif
-            u64 *hb = bid_area + (size_t)(eg & 1u) * kGStride + 2 * kGCap + wg;
-            if (same_xcd) __hip_atomic_store(hb, (u64)eg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(hb, (u64)eg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        } else {
-          s_bj[u] = j;
-          s_bo[u] = st.bk;
-          s_b2k[u] = st.b2k;
-          s_binc[u] = inc;
-          alarm |= emd_band_alarm(pend_old, pend_inc);
-          pend_old = atomicMax(reinterpret_cast<u64 *>(&sc.ostate[st.bk]),
-                               ((u64)emd_f2ord(inc) << 32) | (u64)((unsigned)j + 1u));
-          pend_inc = inc;
-        }
-        drawn = atomicAdd(&s_next, 1);
-      }
-      u = __builtin_amdgcn_readlane(drawn, 0);
-    }
+#include "emd_lean_bid.inc"
     }
     const int nxt = cur ^ 1;
 #ifdef MVP_EMD_PROFILE
@@ -770,614 +430,11 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     if (lane == 0) s_wbusy[wave] = (int)(tp1 - tp0);
 #endif
     if constexpr (!GM) {
-    alarm |= emd_band_alarm(pend_old, pend_inc);
-    int *my_alarm = &s_alarm[it & 1];
-    if (alarm) *my_alarm = 1;
-    if (t == 0) s_cnt[cur ^ 1] = 0;
-    // ---------------- all bids of the round are placed
-    bool any_alarm;
-    if (clustered) {
-      // The bids themselves are complete (their atomics have returned); the
-      // bidders' hint records are only read after the next draining gather.
-      if (!emd_cluster_gather_n<WM, false>(slots, W, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort, same_xcd)) {
-        aborted = true;
-        break;
-      }
-      any_alarm = false;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) any_alarm |= w < W && s_gout[2 * w] != 0u;
+#include "emd_lean_round_plain.inc"
     } else {
-      __syncthreads();
-      any_alarm = *my_alarm != 0;
+#include "emd_lean_round_gathered.inc"
     }
-
-    // ---------------- GetMax (emd_cuda.cu:181-194): only when two different
-    // increments within the 1e-6 band met on one object this round.  Every
-    // bidder inside the band of the object's maximal increment raises the
-    // key's bidder field; the increment field stays.
-    if (__builtin_expect(any_alarm, 0)) {
-#ifdef MVP_EMD_PROFILE
-      n_alarm += 1;
-#endif
-      for (int u = t; u < U; u += kEmdThreads) {
-        const int j = s_bj[u], o = s_bo[u];
-        const float bi = s_binc[u];
-        const u64 key = ld_key(o);
-        if (emd_in_band(bi, emd_ord2f((unsigned)(key >> 32))))
-          atomicMax(reinterpret_cast<u64 *>(&sc.ostate[o]), (key & 0xFFFFFFFF00000000ull) | (u64)((unsigned)j + 1u));
-      }
-      if (clustered) {
-        if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, my_alarm, my_alarm, s_gout, &s_abort, same_xcd)) {
-          aborted = true;
-          break;
-        }
-      } else {
-        __syncthreads();
-      }
-    }
-    if (t == 0) {
-      s_alarm[(it + 1) & 1] = 0;  // next round's flag; its writers are a barrier away
-      s_next = kEmdWaves;         // list positions 0..15 belong to the waves, the rest are drawn
-    }
-#ifdef MVP_EMD_PROFILE
-    tp2 = __builtin_readcyclecounter();
-#endif
-
-    // ---------------- Assign (emd_cuda.cu:196-215)
-    u64 *my_chg = sc.chg + (size_t)wg * kChgCap;
-    // Few bidders (the long tail): one or two per WAVE instead of all of them in
-    // the lanes of wave 0 -- winners, losers and bound refreshes are divergent
-    // paths with their own memory round trips, which a single wave would run
-    // one after the other.  (Many bidders: consecutive lanes, conflict-free LDS.)
-    const bool spread = U <= 4 * kEmdWaves * 4;
-    // next round's list (position, or -1: no room -- cannot happen, the lists never outgrow the hand-over's)
-    auto append = [&]() {
-      const int pos = atomicAdd(&s_cnt[nxt], 1);
-      if (__builtin_expect(pos >= kRecCap, 0)) {
-        s_err = 1;
-        return -1;
-      }
-      return pos;
-    };
-    for (int ub = 0; ub < U; ub += kEmdThreads) {
-      const int u = ub + (spread ? lane * kEmdWaves + wave : t);
-      if (u >= U) continue;
-      const int j = s_bj[u], o = s_bo[u], b2k = s_b2k[u];
-      const float bi = s_binc[u];
-#ifdef MVP_EMD_PROFILE
-      const long long ta0 = __builtin_readcyclecounter();
-#endif
-      const int4 os = ld_ostate(o);
-      const float4 oo = ld_obj(o);  // independent of `os`: same round trip
-#ifdef MVP_EMD_PROFILE
-      if (t == 0 && it >= 100) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        prof_a1 += __builtin_readcyclecounter() - ta0;
-        prof_an += 1;
-      }
-#endif
-      if (last || (unsigned)os.x == (unsigned)j + 1u) {  // a loser may read after the winner reset the key to 0
-        const int prev = os.z;
-        if (!last && prev != -1) {
-          // the evicted owner bids again next round, in this workgroup's list
-          st_i32(&ass[prev], -1);
-          const int pos = append();
-          if (__builtin_expect(pos >= 0, 1)) {
-            {
-              const float4 pa = ld_person(prev, 0);
-              const float4 pb = ld_person(prev, 1);
-              s_rq[nxt][pos] = pa;
-              s_ri[nxt][pos] = make_int4(prev, __float_as_int(pb.y), __float_as_int(pb.z), 0);
-            }
-          }
-        }
-#ifdef MVP_EMD_PROFILE
-        if (t == 0 && it >= 100) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); prof_a2 += __builtin_readcyclecounter() - ta0; }
-#endif
-        st_ostate(o, j);
-        st_i32(&ass[j], o);
-        st_f32(&sc.obj[o].w, oo.w + bi);
-        // The cell's price lower bound only changes when the object that just got dearer was (one
-        // of) the cheapest of its cell (the bounds are exact at this point, see the re-scan after
-        // the closing barrier): report the cell; every member of the cluster re-scans the reported
-        // cells once all of this round's prices are in memory.
-        const int c = emd_cell(gg, oo.x, oo.y, oo.z);
-        if (oo.w <= c_lo[c].w) {
-          const int q = atomicAdd(&s_nchg, 1);
-          if (q < kLeanBid) s_own_chg[q] = c;
-          if (clustered && q < kChgCap) {
-            const u64 e = (u64)(unsigned)c << 32;
-            if (same_xcd) __hip_atomic_store(my_chg + q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(my_chg + q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      } else {
-        // lost: stays in the list, record carried over through LDS
-        const int pos = append();
-        if (__builtin_expect(pos >= 0, 1)) {
-          s_rq[nxt][pos] = s_rq[cur][u];
-          s_ri[nxt][pos] = make_int4(j, o, b2k, 0);
-        }
-      }
-#ifdef MVP_EMD_PROFILE
-      if (t == 0 && it >= 100) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); prof_a3 += __builtin_readcyclecounter() - ta0; }
-#endif
-    }
-#ifdef MVP_EMD_PROFILE
-    tp3 = __builtin_readcyclecounter();
-    if (t == 0 && it >= 100) prof_a4 += tp3 - tp2;
-#endif
-    } else {
-      // ---------------- gathered-bid round: wait for the round's bids, then EVERY member settles ALL
-      // of them on its own view of the cloud.  One cluster-wide wait per round: no bid atomic to wait for, no key to
-      // read back, no closing barrier -- a member only ever reads what it wrote itself (prices: every member stores
-      // every winner's new price, the same value) or what a heartbeat vouches for (hint records, written a round or
-      // more before they are read).  emd_cuda.cu:181-215 (GetMax + Assign).
-      if constexpr (WB != 1) {
-        GMT(1)   // [1] own bids done
-        u64 *ba = bid_area + (size_t)(eg & 1u) * kGStride;
-        const unsigned T4 = eg % 15u + 1u, T6 = eg % 7u + 1u;
-        u64 g0 = 0ull, g1 = 0ull;
-        if (wave * kWave < Utot) {   // the waves of threads p < Utot: thread p takes bid p
-          // (1) spin on the members' words of the round, (2) read the bids (normally there at once)
-          for (unsigned spins = 0;; ++spins) {
-            u64 x = (u64)eg;
-            if (lane < W) x = __hip_atomic_load(ba + 2 * kGCap + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(x == (u64)eg)) break;
-            if (spins >= kSpinLimit) {
-              if (lane == 0) s_abort = 1;
-#ifdef MVP_EMD_STUCKDUMP
-              if (wave == 0) {
-                int *dd = ass + wg * 32;
-                if (lane < W) dd[lane] = (int)x;
-                if (lane == 8) dd[8] = (int)eg;
-                if (lane == 9) dd[9] = it;
-                if (lane == 10) dd[10] = Utot;
-                if (lane == 11) dd[11] = U;
-                if (lane == 12) dd[12] = s_pub;
-                if (lane == 13) dd[13] = goff;
-                if (lane == 14) dd[14] = gi;
-                if (lane == 15) dd[15] = 777;
-                if (lane >= 16 && lane < 16 + WM) dd[lane] = s_gc[gcur][lane - 16];
-              }
-#endif
-#if defined(MVP_EMD_PROFILE) || defined(MVP_EMD_STUCK)
-              if (lane < W) printf("cloud %d wg %d wave %d: member word %d stuck at %llu, want %u (it %d Utot %d U %d goff %d gi %d pub %d)\n", cloud, wg, wave, lane, x, eg, it, Utot, U, goff, gi, s_pub);
-#endif
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          GMT(2)   // [2] every member's word raised
-          const bool isb = t < Utot;
-          bool ok = !isb;
-          for (unsigned spins = 0;; ++spins) {
-            if (isb && !ok) {
-              g0 = __hip_atomic_load(ba + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              g1 = __hip_atomic_load(ba + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              ok = (unsigned)(g0 & 15ull) == T4 && (unsigned)(g1 & 7ull) == T6;
-            }
-            if (__all(ok)) break;
-            if (spins >= kSpinLimit) {
-              if (lane == 0) s_abort = 1;
-#if defined(MVP_EMD_PROFILE) || defined(MVP_EMD_STUCK)
-              if (!ok) printf("cloud %d wg %d: bid %d stuck: %llx %llx, want tags %u %u (it %d Utot %d U %d goff %d)\n", cloud, wg, t, g0, g1, T4, T6, it, Utot, U, goff);
-#endif
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        GMT(3)   // [3] bids read
-        // Everything of a bid's settlement that does not depend on the other bids is done here, in the shadow of the
-        // wait for the round's last bid: who placed it, who owns the object now (the map only changes after the
-        // barrier), where an evicted owner would go -- and, if to this member, the load of its record.
-        int go = 0, gj = 0, gb2 = -1, gcell = 0x7FF, gm_m = 0, prev = 0xFFFF;
-        float ginc = 0.f, gnp = 0.f;
-        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
-        if (t < Utot) {
-          ginc = __uint_as_float((unsigned)(g0 >> 32));
-          go = (int)(g0 >> 18) & 0x3FFF;
-          gj = (int)(g0 >> 4) & 0x3FFF;
-          gnp = __uint_as_float((unsigned)(g1 >> 32));
-          gb2 = ((int)(g1 >> 17) & 0x7FFF) - 1;
-          gcell = (int)(g1 >> 6) & 0x7FF;
-          gm_m = (int)(g1 >> 3) & 7;
-          s_go[t] = (unsigned short)go;
-          s_gj[t] = (unsigned short)gj;
-          s_ginc[t] = ginc;
-          {
-            unsigned char *bc = bid_count(go);
-            atomicAdd(reinterpret_cast<unsigned *>(bc - (go & 3)), 1u << ((go & 3) * 8));
-          }
-          if (!last) {
-            prev = s_owner[go];
-            if (prev != 0xFFFF && t % W == wg) {
-              pa = ld_person(prev, 0);
-              pb = ld_person(prev, 1);
-            }
-          }
-        }
-        GMT(4)   // [4] decoded, owner looked up
-        lds_barrier();
-        GMT(5)   // [5] barrier after the poll
-        if (s_abort) {
-          aborted = true;
-          break;
-        }
-#ifdef MVP_EMD_PROFILE
-        tp2 = __builtin_readcyclecounter();
-#endif
-        int rec_pos = -1;
-        // Bids for an object that got more than one bid (~0.3 per round at the headline): the wave settles one of
-        // them at a time -- the maximal increment bid on the object, then the highest bidder inside its 1e-6 band
-        // (emd_cuda.cu:181-194), over all of the round's bids, four per lane.
-        int contested = 0;   // 1: another bid wins my object
-#ifdef MVP_EMD_PROFILE
-        const long long tq0 = __builtin_readcyclecounter();
-#endif
-        if (wave * kWave < Utot && !last) {
-          bool flagged = false;
-          if (t < Utot) {
-            unsigned char *bc = bid_count(go);
-            flagged = *bc != 1;
-            *bc = 0;   // (a bid for the same object that reads after this sees 0: flagged as well)
-          }
-          unsigned long long fm = __ballot(flagged);
-#ifdef MVP_EMD_PROFILE
-          if (lane == 0) atomicAdd(&s_hist2[3], (unsigned long long)__builtin_popcountll(fm) << 32);
-#endif
-          while (fm) {
-            const int l = (int)__builtin_ctzll(fm);
-            fm &= fm - 1ull;
-            const int ol = __builtin_amdgcn_readlane(go, l), pl = (wave << 6) + l;
-            bool same = false;
-            for (int q = lane; q < Utot; q += kWave) same |= q != pl && s_go[q] == ol;
-            if (__builtin_expect(__any(same), 0)) {
-              // a real contest: the maximal increment bid on the object, then the highest bidder inside its 1e-6 band
-              // (emd_cuda.cu:181-194), over all of the round's bids, four per lane
-              float mi = -__builtin_inff();
-              for (int q = lane; q < Utot; q += kWave)
-                if (s_go[q] == ol) mi = __builtin_fmaxf(mi, s_ginc[q]);
-              mi = emd_wave_max(mi);
-              float wjf = -1.f;   // (indices < 2^14: exact in float)
-              for (int q = lane; q < Utot; q += kWave)
-                if (s_go[q] == ol && emd_in_band(s_ginc[q], mi)) wjf = __builtin_fmaxf(wjf, (float)s_gj[q]);
-              wjf = emd_wave_max(wjf);
-              if (lane == l && (int)wjf != gj) contested = 1;   // (1: lost the contest)
-            }
-          }
-        }
-#ifdef MVP_EMD_PROFILE
-        const long long tq1 = __builtin_readcyclecounter();
-        if (contested) atomicAdd(&s_hist2[2], 1ull << 32);
-#endif
-        GMT(6)   // [6] contest check
-        if (t < Utot) {
-          const int m = gm_m;   // the member that placed bid t (it does the stores only one member needs to do)
-          if (!contested) {
-            if (!last) {
-              s_owner[go] = (unsigned short)gj;
-              st_f32(&sc.obj[go].w, gnp);   // (every member: its own next searches read its own store)
-              if (prev != 0xFFFF) {
-                // the evicted owner bids again next round: in the list of member (position % W) -- the lists stay
-                // even without any exchange
-                const int d = t % W;
-                const int pos = atomicAdd(&s_gc[gnxt][d], 1);
-                if (d == wg) rec_pos = pos;
-                if (m == wg) st_i32(&ass[prev], -1);
-              }
-              if (gcell < ncell) s_won[eg & 1u][atomicAdd(&s_nwon[eg & 1u], 1)] = (unsigned short)gcell;
-            }
-            if (m == wg) {
-              st_ostate(go, gj);
-              st_i32(&ass[gj], go);
-              if (last) st_f32(&sc.obj[go].w, gnp);
-            }
-          } else {
-            // lost: stays in its member's list, record carried over through LDS
-            const int pos = atomicAdd(&s_gc[gnxt][m], 1);
-            if (m == wg) {
-              s_rq[nxt][pos] = s_rq[cur][t - goff];
-              s_ri[nxt][pos] = make_int4(gj, go, gb2, 0);
-            }
-          }
-        }
-        GMT(7)   // [7] outcome applied (owner map, list positions, stores issued)
-        // (what the next round starts from; nobody reads these before the barrier below.  By the last wave: it has
-        // no bid to settle)
-        if (t >= kEmdThreads - WM) s_gc[gzero][t - (kEmdThreads - WM)] = 0;
-        if (t == kEmdThreads - 1) {
-          s_nwon[(eg + 1u) & 1u] = 0;
-          s_next = kEmdWaves;
-          s_pub = 0;
-        }
-        // drain: this member's stores are performed before its next heartbeat says so (and before its own next
-        // searches read the prices); the evicted persons' records have arrived
-#ifdef MVP_EMD_PROFILE
-        const long long tq2 = __builtin_readcyclecounter();
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef MVP_EMD_PROFILE
-        const long long tq3 = __builtin_readcyclecounter();
-#endif
-        GMT(8)   // [8] drained
-        if (rec_pos >= 0) {
-          s_rq[nxt][rec_pos] = pa;
-          s_ri[nxt][rec_pos] = make_int4(prev, __float_as_int(pb.y), __float_as_int(pb.z), 0);
-        }
-        lds_barrier();
-        GMT(9)   // [9] closing barrier
-        if (t == 0) s_cnt[nxt] = s_gc[gnxt][wg];
-#ifdef MVP_EMD_PROFILE
-        tp3 = __builtin_readcyclecounter();
-        if (t == 0) { prof_a1 += tq1 - tq0; prof_a2 += tq2 - tq1; prof_a3 += tq3 - tq2; prof_a4 += tp3 - tq3; prof_an += 1; }
-#endif
-      }
-    }
-    // ---------------- end of round: next list sizes + refreshed price bounds
-    if (clustered) {
-#ifdef MVP_EMD_PROFILE
-      long long tpd = tp3, tpg2 = tp3;
-#endif
-      Utot = 0;
-      bool overflow = false;
-      int cntw[WM], chgw[WM];  // (the same for every lane: kept in scalar registers, the arithmetic on them is SALU work)
-      if constexpr (!GM) {
-#ifdef MVP_EMD_PROFILE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tpd = __builtin_readcyclecounter();
-#endif
-        if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_cnt[nxt], &s_nchg, s_gout, &s_abort, same_xcd)) {
-          aborted = true;
-          break;
-        }
-#ifdef MVP_EMD_PROFILE
-        tpg2 = __builtin_readcyclecounter();
-        prof_drain += tpd - tp3;
-        prof_gather += tpg2 - tpd;
-#endif
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          cntw[w] = w < W ? __builtin_amdgcn_readfirstlane((int)s_gout[2 * w]) : 0;
-          chgw[w] = w < W ? __builtin_amdgcn_readfirstlane((int)s_gout[2 * w + 1]) : 0;
-          Utot += cntw[w];
-          if (w != wg) overflow |= chgw[w] > kChgCap;
-        }
-      } else {
-        // gathered-bid round: every member counted every member's next list itself
-        {
-          const int cv = s_gc[gnxt][lane & (kMaxCluster - 1)];   // (one LDS read; the rest is scalar work)
-#pragma unroll
-          for (int w = 0; w < WM; ++w) {
-            cntw[w] = w < W ? __builtin_amdgcn_readlane(cv, w) : 0;
-            chgw[w] = 0;
-            Utot += cntw[w];
-          }
-        }
-        // the rounds end here (last round, or everybody assigned): what follows reads the other members' stores
-        if (it + 1 >= iters || Utot == 0) {
-          if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
-            aborted = true;
-            break;
-          }
-        }
-      }
-      if (__builtin_expect((it + 1 == it_stop && it + 1 < iters && Utot > 0) ||
-                           (Utot <= u_stop && Utot > 0 && iters - (it + 1) >= kResMinRounds), 0)) {
-        // ---- this launch's last round: the lists are left for the next launch below the loop
-        stop_cnt = cntw[wg];
-        stop_for_res = !(it + 1 == it_stop);
-        break;
-      }
-      if (__builtin_expect(Utot > 0 && Utot <= kSoloMax && it + 1 < iters, 0)) {
-        // ---- hand everything to member 0 (lists of <= kSoloMax persons live
-        // in LDS only: publish the person ids; their records are in memory)
-        if (wg != 0 && t < cntw[wg]) st_i32(my_ulist + t, s_ri[nxt][t].x);
-        if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
-          aborted = true;
-          break;
-        }
-        if (wg != 0) {
-          if (t == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)n_bids);
-          ret_early = true;
-          return 0;
-        }
-        int idx = t;
-#pragma unroll
-        for (int w = 1; w < WM; ++w) {
-          if (idx >= 0 && idx < cntw[w]) {
-            const int jj = __hip_atomic_load(sc.ulist + (size_t)w * 2 * n + idx, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-            const float4 pa = ld_person(jj, 0);
-            const float4 pb = ld_person(jj, 1);
-            const int pos = atomicAdd(&s_cnt[nxt], 1);
-            s_rq[nxt][pos] = pa;
-            s_ri[nxt][pos] = make_int4(jj, __float_as_int(pb.y), __float_as_int(pb.z), 0);
-          }
-          idx -= cntw[w];
-        }
-        clustered = false;
-        if constexpr (GM) sw = 3;
-        if (t == 0) s_nchg = 0;
-        __syncthreads();
-      } else {
-        // ---- rebalance: the round lasts as long as the fullest workgroup's
-        // bid passes (16 bidders per pass, 64 in row mode).  When an even
-        // split would need fewer passes than the fullest list does, lists
-        // above their even share hand the surplus (their last entries) to the
-        // lists below it.  Everybody derives the same plan from the gathered
-        // counts; the ids travel through the donors' dead current lists.
-        int maxc = 0;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) maxc = max(maxc, cntw[w]);
-        const int even = (Utot + W - 1) / W;
-        const int cap = (even + 15) / 16 * 16;
-        if (__builtin_expect(!gm && maxc > cap && it + 1 < iters, 0)) {
-          const int base = Utot / W, rem = Utot % W;
-          int exc[WM], dfc[WM], exoff = 0, dfoff = 0, my_exoff = 0, my_dfoff = 0;
-#pragma unroll
-          for (int w = 0; w < WM; ++w) {
-            const int tgt = base + (w < rem ? 1 : 0);
-            exc[w] = w < W ? max(0, cntw[w] - tgt) : 0;
-            dfc[w] = w < W ? max(0, tgt - cntw[w]) : 0;
-            if (w == wg) { my_exoff = exoff; my_dfoff = dfoff; }
-            exoff += exc[w];
-            dfoff += dfc[w];
-          }
-          (void)my_exoff;
-          const int my_exc = exc[wg], my_dfc = dfc[wg], my_cnt = cntw[wg];
-          int *dead = my_ulist + (size_t)cur * n;   // this round's list: no longer read
-          for (int i = t; i < my_exc; i += kEmdThreads) {
-            const int pos = my_cnt - my_exc + i;
-            st_i32(dead + i, s_ri[nxt][pos].x);
-          }
-          if (!emd_cluster_gather_n<WM>(slots, W, wg, ++epoch, &s_nchg, &s_nchg, s_gout, &s_abort, same_xcd)) {
-            aborted = true;
-            break;
-          }
-          for (int i = t; i < my_dfc; i += kEmdThreads) {
-            int p = my_dfoff + i, jj = -1;   // p-th entry of the pool = donors' surpluses in order
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-              if (p >= 0 && p < exc[w])
-                jj = __hip_atomic_load(sc.ulist + (size_t)w * 2 * n + (size_t)cur * n + p, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-              p -= exc[w];
-            }
-            const int pos = my_cnt + i;
-            const float4 pa = ld_person(jj, 0);
-            const float4 pb = ld_person(jj, 1);
-            s_rq[nxt][pos] = pa;
-            s_ri[nxt][pos] = make_int4(jj, __float_as_int(pb.y), __float_as_int(pb.z), 0);
-          }
-          if (t == 0) s_cnt[nxt] = my_cnt - my_exc + my_dfc;
-          __syncthreads();
-#pragma unroll
-          for (int w = 0; w < WM; ++w) cntw[w] = w < W ? base + (w < rem ? 1 : 0) : 0;   // (every list is at its even share now)
-#ifdef MVP_EMD_PROFILE
-          n_rebal += 1;
-#endif
-        }
-      }
-#ifdef MVP_EMD_PROFILE
-      const long long tpb = __builtin_readcyclecounter();
-      prof_pg1 += tpb - tpg2;
-#endif
-      if constexpr (GM) {
-        // gathered-bid round: the cell of every object won this round is re-scanned (this member stored all of
-        // the round's prices itself and has drained them)
-        const int pw = (int)(eg & 1u);
-        const int nw = min(s_nwon[pw], kGCap);
-        const int idx = kEmdThreads - 1 - t;
-        if (idx < nw) {
-          const int cell = s_won[pw][idx];
-          const int e0 = c_start[cell], e1 = c_start[cell + 1];
-          float pv[16], pm = __builtin_inff();
-#pragma unroll
-          for (int k = 0; k < 16; ++k) pv[k] = e0 + k < e1 ? ld_price(e0 + k) : __builtin_inff();
-#pragma unroll
-          for (int k = 0; k < 16; ++k) pm = __builtin_fminf(pm, pv[k]);
-          for (int s2 = e0 + 16; s2 < e1; ++s2) pm = __builtin_fminf(pm, ld_price(s2));
-          c_lo[cell].w = pm;
-        }
-      } else {
-        // Exact price bounds: every cell a winner of the cluster reported is re-scanned by every
-        // member, from the prices in memory (all of this round's stores were drained before the
-        // barrier opened).  The highest waves take the entries: they start bidding a little later,
-        // the searches that run meanwhile may still see the old (lower, valid) bound.
-        const int own_cnt = min(chgw[wg], kLeanBid);
-        int idx = kEmdThreads - 1 - t, total = own_cnt;
-        int cell = idx < own_cnt ? s_own_chg[idx] : -1;
-        idx -= own_cnt;
-        // (also in the round the cluster collapses to member 0: the others' last reports count)
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          if (w == wg) continue;
-          const int cnt = min(chgw[w], kChgCap);
-          if (cell < 0 && idx >= 0 && idx < cnt)
-            cell = (int)(__hip_atomic_load(sc.chg + (size_t)w * kChgCap + idx, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT) >> 32);
-          idx -= cnt;
-          total += cnt;
-        }
-        if (__builtin_expect(overflow || total > kEmdThreads || chgw[wg] > kLeanBid, 0)) {
-          // (cannot happen with <= kLeanCap bidders per cloud) recompute every bound
-          for (int c = t; c < ncell; c += kEmdThreads) {
-            float pm = __builtin_inff();
-            for (int s2 = c_start[c]; s2 < c_start[c + 1]; ++s2) pm = __builtin_fminf(pm, ld_price(s2));
-            if (c_start[c + 1] > c_start[c]) c_lo[c].w = pm;
-          }
-        } else if (cell >= 0) {
-          const int e0 = c_start[cell], e1 = c_start[cell + 1];
-          float pv[16], pm = __builtin_inff();
-#pragma unroll
-          for (int k = 0; k < 16; ++k) pv[k] = e0 + k < e1 ? ld_price(e0 + k) : __builtin_inff();
-#pragma unroll
-          for (int k = 0; k < 16; ++k) pm = __builtin_fminf(pm, pv[k]);
-          for (int s2 = e0 + 16; s2 < e1; ++s2) pm = __builtin_fminf(pm, ld_price(s2));
-          c_lo[cell].w = pm;
-        }
-      }
-      if (t == 0) s_nchg = 0;
-      // ---- at most kGCap persons left (and never more again): the rounds go on with gathered bids.  Every member's
-      // view starts from the memory all of them agree on after the barrier above.
-      if constexpr (WB != 1) {
-        if (!GM && clustered && gm_ok && Utot <= kGCap && it + 1 < iters) {
-          sw = 2;
-          for (int s2 = t; s2 < n; s2 += kEmdThreads)
-            s_owner[s2] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b32(rs, ((unsigned)n + (unsigned)s2) * 16u + 8u, 0, 16);
-#pragma unroll
-          for (int w = 0; w < WM; ++w)
-            if (t == w) {
-              s_gc[0][w] = cntw[w];
-              s_gc[1][w] = 0;
-              s_gc[2][w] = 0;
-            }
-          gi = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)   // (the four counter areas: 1024 words each)
-            reinterpret_cast<unsigned *>(&s_rq[0][0])[1024 + 2048 * q + t] = 0u;
-          if (t == 0) {
-            s_nwon[0] = 0;
-            s_nwon[1] = 0;
-            s_pub = 0;
-          }
-          __syncthreads();
-        }
-      }
-    } else {
-      __syncthreads();
-      Utot = s_cnt[nxt];
-      if (__builtin_expect((it + 1 == it_stop && it + 1 < iters && Utot > 0) ||
-                           (Utot <= u_stop && Utot > 0 && iters - (it + 1) >= kResMinRounds), 0)) {   // (member 0 alone)
-        stop_cnt = Utot;
-        stop_for_res = !(it + 1 == it_stop);
-        break;
-      }
-      {
-        const int own_cnt = min(s_nchg, kLeanBid);
-        __syncthreads();
-        if (t == 0) s_nchg = 0;
-        const int idx = kEmdThreads - 1 - t;
-        if (idx < own_cnt) {
-          const int cell = s_own_chg[idx];
-          float pm = __builtin_inff();
-          for (int s2 = c_start[cell]; s2 < c_start[cell + 1]; ++s2) pm = __builtin_fminf(pm, ld_price(s2));
-          c_lo[cell].w = pm;
-        }
-      }
-    }
-#ifdef MVP_EMD_PROFILE
-    const long long tp4 = __builtin_readcyclecounter();
-    prof_prev4 = tp4;
-    cyc_bid += tp1 - tp0; cyc_sync1 += tp2 - tp1; cyc_assign += tp3 - tp2; cyc_sync2 += tp4 - tp3;
-    if (t == 0 && it >= 100) {
-      int mx = 0, sm = 0;
-      for (int w = 0; w < kEmdWaves; ++w) { mx = max(mx, s_wbusy[w]); sm += s_wbusy[w]; }
-      s_hist[13] += mx; s_hist[14] += sm / kEmdWaves; s_hist[15] += 1; prof_u += U;
-    }
-#endif
+#include "emd_lean_round_end.inc"
     if constexpr (GM) { GMT(10) }   // [10] counts, stop checks, price bounds
     cur ^= 1;
     if constexpr (GM) gi = gnxt;
