@@ -30,7 +30,7 @@ for name in sys.argv[1:] or ("vrcnet", "ecg"):
         args = train.load_config(os.path.join(ROOT, "completion", "cfgs", name + ".yaml"))
         args.load_model = None
         net = importlib.import_module("models." + name).Model(args).to(dev).train()
-        opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=True)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=True, fused=True)
         gt = torch.rand(32, 2048, 3, generator=g).to(dev)
         partial = gt.transpose(2, 1).contiguous()
 
