@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 15
+#define MVP_ABI_VERSION 16
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -443,6 +443,17 @@ int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float *x,
                        const float *xmask, const float *w, int ldw, int w_kmajor,
                        const float *bias, const float *residual, int relu,
                        int group, float *y, void *stream);
+
+/* ABI 16.  (W x + bias) [then ReLU], reduced with max over ALL positions of a cloud inside the GEMM's epilogue
+ * -- the PointNet stage of the completion networks: `x = self.conv4(x); global_feature, _ = torch.max(x, 2)`
+ * (completion/models/pcn.py:29-30; vrcnet.py:281-282 conv5; ecg.py:137-138 gf_conv) -- without writing the
+ * (b, cout, len) tensor: val (b, cout) = the maxima, idx (b, cout) int32 = the first position that attains each
+ * (what torch.max reports; the sparse backward pass mvp_pointwise_max_backward takes it).  Arithmetic as
+ * mvp_pointwise_mfma: val equals its output reduced with max, bit for bit.  keys: b * cout * 8 bytes of caller
+ * scratch, 8-byte aligned, contents irrelevant.  w (cout, cin) row-major with row stride ldw (0 = cin). */
+int mvp_pointwise_mfma_max(int b, int cin, int cout, int len, const float *x, const float *w, int ldw,
+                           const float *bias, int relu, float *val, int *idx, void *keys, long long keys_bytes,
+                           void *stream);
 
 /* Weight (and bias) gradient of the same map on the matrix cores:
  *   gw[co,ci] = sum_b sum_l g[b,co,l] x[b,ci,l],  gb[co] = sum_b sum_l g[b,co,l]

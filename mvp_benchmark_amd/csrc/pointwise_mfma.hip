@@ -168,6 +168,24 @@ __device__ __forceinline__ void pw_mma(f32x16 (&acc)[TM][TN], const float (&a)[T
       for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
 }
 
+// Unsigned max with one DPP-modified operand (lanes a row mask leaves unwritten combine with 0, the identity).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned pw_dpp_umax(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+  return o > v ? o : v;
+}
+
+// keys (see pointwise_mfma_kernel, ROWMAX) -> val[i] = the row's maximum, idx[i] = the first position that attains it
+__global__ void pointwise_rowmax_unpack_kernel(long long total, const unsigned long long *__restrict__ keys,
+                                               float *__restrict__ val, int *__restrict__ idx) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const unsigned long long k = keys[i];
+  const unsigned o = (unsigned)(k >> 32);
+  val[i] = __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+  idx[i] = (int)~(unsigned)k;
+}
+
 // Workgroup number -> work item so that consecutive items run on ONE XCD (workgroups are dealt to the 8 XCDs
 // round-robin by their linear id): XCD x takes items [x per, (x + 1) per).
 __device__ __forceinline__ long long pw_work_item(long long total) {
@@ -178,7 +196,13 @@ __device__ __forceinline__ long long pw_work_item(long long total) {
 // ------------------------------------------------------------------- forward / data gradient
 // Per cloud  Y (M x N) = A (M x K) X (K x N): A = the weight, (M, K) row-major [AMODE kKC: forward] or (K, M)
 // row-major [kXC: the data gradient multiplies by W^T]; X, xmask (K x N), Y per cloud.
-template <int TM, int TN, int BK, int AMODE, bool MASKED>
+// ROWMAX (round 5): the epilogue keeps only the maximum of every output row over ALL positions of its cloud, and where it
+// was attained -- the PointNet stage of the completion networks (conv -> max over the points: pcn.py:25-31 conv4, the
+// relational encoder's conv5) writes a (B, Cout, N) tensor only to reduce it in the next kernel (0.5 GB each way at
+// 64 x 1024 x 2048).  `y` then is a (nb, M) array of 64-bit keys {order-preserving bits of the value | ~column}, zeroed by the
+// caller; a tile's rows join by one 64-bit atomic max per row and half-wave (the lanes that hold the half-wave's maximum
+// issue it: ties go to the smallest column), pointwise_rowmax_unpack_kernel turns the keys into values and positions.
+template <int TM, int TN, int BK, int AMODE, bool MASKED, bool ROWMAX = false>
 __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
     int M, int N, int K, int nb, const float *__restrict__ a, int a_ld, int a_vec, const float *__restrict__ x,
     const float *__restrict__ xmask, const float *__restrict__ bias, const float *__restrict__ residual, int relu,
@@ -247,6 +271,40 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
   }
 
   // ---- epilogue.  C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  if constexpr (ROWMAX) {
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(y) + (size_t)cloud * M;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const float bi = sbias[lr];
+        unsigned hi = 0u, lo = 0u;            // this lane's best of its TN columns: value bits (0: none), ~column
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + wn * 32 * TN + j * 32 + lrow;
+          float v = acc[i][j][r] + bi;
+          if (relu) v = __builtin_fmaxf(v, 0.f);
+          const unsigned b = __float_as_uint(v);
+          const unsigned o = col < N ? ((b & 0x80000000u) ? ~b : (b | 0x80000000u)) : 0u;   // order-preserving, > 0
+          if (o > hi) { hi = o; lo = ~(unsigned)col; }                                         // (strict: the smaller column stays)
+        }
+        // maximum over the 32 lanes that share this row (lanes 0..31 / 32..63): DPP inside the rows of 16, row_bcast15
+        // into rows 1 and 3, whose last lanes then hold it
+        unsigned m = hi;
+        m = pw_dpp_umax<0xB1, 0xF>(m);    // quad_perm [1,0,3,2]
+        m = pw_dpp_umax<0x4E, 0xF>(m);    // quad_perm [2,3,0,1]
+        m = pw_dpp_umax<0x141, 0xF>(m);   // row_half_mirror
+        m = pw_dpp_umax<0x140, 0xF>(m);   // row_mirror
+        m = pw_dpp_umax<0x142, 0xA>(m);   // row_bcast15 -> rows 1, 3
+        const unsigned m0h = (unsigned)__builtin_amdgcn_readlane((int)m, 31), m1h = (unsigned)__builtin_amdgcn_readlane((int)m, 63);
+        const unsigned mh = lk ? m1h : m0h;
+        if (hi != 0u && hi == mh && m0 + lr < M)
+          atomicMax(keys + (m0 + lr), ((unsigned long long)hi << 32) | (unsigned long long)lo);
+      }
+    }
+    return;
+  }
   const int len_out = N / group;
   float *yb = y + (size_t)cloud * M * len_out;
   const float *rbse = residual ? residual + (size_t)cloud * M * len_out : nullptr;
@@ -552,4 +610,42 @@ extern "C" int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float
 #undef MVP_MM
 #undef MVP_MM_
   return check_launch("mvp_pointwise_mfma");
+}
+
+// (W x + bias).max over the positions of every cloud, fused: val (b, cout), idx (b, cout) = the first position that
+// attains it; keys: b * cout * 8 bytes of scratch (contents irrelevant).  Same arithmetic as mvp_pointwise_mfma (the same
+// k-ordered fmaf chain per output), so val == mvp_pointwise_mfma's output reduced with max, bit for bit.
+extern "C" int mvp_pointwise_mfma_max(int b, int cin, int cout, int len, const float *x, const float *w, int ldw,
+                                      const float *bias, int relu, float *val, int *idx, void *keys, long long keys_bytes,
+                                      void *stream) {
+  if (b < 0 || cin <= 0 || cout <= 0 || len <= 0) return MVP_EBADSHAPE;
+  if ((len & 3) != 0 || b > 65535) return MVP_EBADSHAPE;
+  if (b == 0) return MVP_OK;
+  if (!x || !w || !val || !idx || !keys) return MVP_EBADARG;
+  if (keys_bytes < (long long)b * cout * 8 || (reinterpret_cast<uintptr_t>(keys) & 7) != 0) return MVP_EBADARG;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return MVP_EBADARG;
+  if (ldw == 0) ldw = cin;
+  if (ldw < cin) return MVP_EBADARG;
+  if ((ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) != 0) return MVP_EBADARG;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(keys, 0, (size_t)b * cout * 8, st) != hipSuccess) return MVP_ELAUNCH;
+  const bool big = cout > 64;
+  const int bm = big ? 128 : 64;
+  const long long total = (long long)((cout + bm - 1) / bm) * ((len + 127) / 128) * b;
+  const long long nwg = (total + 7) / 8 * 8;
+  if (nwg > 2147483647LL) return MVP_EBADSHAPE;
+  const int a_vec = (ldw & 3) == 0;
+  const float *none = nullptr;
+  float *y = reinterpret_cast<float *>(keys);
+  const int group = 1;
+  if (big)
+    hipLaunchKernelGGL((pointwise_mfma_kernel<2, 2, 16, kKC, false, true>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, cout, len,
+                       cin, b, w, ldw, a_vec, x, none, bias, none, relu, group, y);
+  else
+    hipLaunchKernelGGL((pointwise_mfma_kernel<1, 2, 16, kKC, false, true>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, cout, len,
+                       cin, b, w, ldw, a_vec, x, none, bias, none, relu, group, y);
+  const long long rows = (long long)b * cout;
+  hipLaunchKernelGGL(pointwise_rowmax_unpack_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows,
+                     reinterpret_cast<const unsigned long long *>(keys), val, idx);
+  return check_launch("mvp_pointwise_mfma_max");
 }

@@ -244,8 +244,12 @@ class _PointwiseConvMax(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         with torch.no_grad():
-            y = pointwise_conv(x, weight, bias)
-            val, idx = y.flatten(2).max(dim=2)
+            fused = mfma_conv_max(x, weight, bias)
+            if fused is not None:
+                val, idx = fused
+            else:
+                y = pointwise_conv(x, weight, bias)
+                val, idx = y.flatten(2).max(dim=2)
         ctx.save_for_backward(x, weight, idx)
         ctx.has_bias = bias is not None
         return val
@@ -284,6 +288,27 @@ class _PointwiseConvMax(Function):
         return gx, gw, gb
 
 
+def mfma_conv_max(x, weight, bias=None):
+    """(values (B, Cout), positions (B, Cout) int32) of (W x + bias).max over the positions inside the GEMM's epilogue
+    (mvp_pointwise_mfma_max: the (B, Cout, L) tensor is never written), or None where the forward GEMM is not routed to
+    the MFMA kernel.  No autograd."""
+    cout, cin = weight.size(0), weight.size(1)
+    if not (x.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous() and x.numel() > 0
+            and _mfma_fwd(x, cin, cout, weight)):
+        return None
+    B, length = x.size(0), x[0, 0].numel()
+    w2d = weight.reshape(cout, cin)
+    ldw = 0
+    if cin % 4 != 0:
+        w2d = F.pad(w2d, (0, -cin % 4))
+        ldw = w2d.size(1)
+    val = torch.empty(B, cout, dtype=torch.float32, device=x.device)
+    idx = torch.empty(B, cout, dtype=torch.int32, device=x.device)
+    keys = torch.empty(B * cout, dtype=torch.int64, device=x.device)
+    call("mvp_pointwise_mfma_max", x.device, B, cin, cout, length, x, w2d, ldw, bias, 0, val, idx, keys, keys.numel() * 8)
+    return val, idx
+
+
 def _conv_max_kernel_covers(x, weight):
     """Shapes mvp_pointwise_max_backward takes: its per-cloud sort of the winners lives in LDS ((3 Cout + L) * 4 <= 30000
     bytes: L <= 4428 positions at Cout = 1024)."""
@@ -307,6 +332,10 @@ def pointwise_conv_max(x, weight, bias=None):
             import logging
             logging.getLogger(__name__).info("conv -> max over %d positions x %d channels: outside the sparse backward kernel's "
                                              "LDS budget, dense autograd route", shape[1], shape[0])
+        return pointwise_conv(x, weight, bias).flatten(2).max(dim=2)[0]      # (plain autograd)
+    fused = mfma_conv_max(x, weight, bias)                                     # no gradient wanted: the fused forward alone
+    if fused is not None:
+        return fused[0]
     return pointwise_conv(x, weight, bias).flatten(2).max(dim=2)[0]
 
 

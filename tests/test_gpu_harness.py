@@ -743,3 +743,54 @@ def test_conv_interp_concat_equals_interpolate_then_convolve(first, four_d, relu
         out.append((y,) + torch.autograd.grad(y.square().sum(), params))
     for a, b in zip(*out):
         assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("B,cin,cout,L,relu", [(3, 512, 1024, 2048, 0), (2, 64, 48, 384, 0), (2, 130, 200, 1000, 1), (5, 32, 1024, 132, 0),
+                                               (1, 256, 64, 4, 0)])
+def test_pointwise_mfma_max_equals_gemm_then_max(B, cin, cout, L, relu):
+    """mvp_pointwise_mfma_max (round 5: the max over a cloud's positions inside the GEMM's epilogue, pcn.py:29-30 /
+    vrcnet.py:281-282) through the C ABI: values BIT-identical to mvp_pointwise_mfma's output reduced with max, positions =
+    the FIRST position that attains each maximum -- also where the maximum is attained several times (duplicated
+    columns) and in rows of the last, partial tiles."""
+    from mvp_benchmark_amd import _lib
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = torch.randn(B, cin, L, generator=g)
+    x[:, :, L // 2:] = x[:, :, :L - L // 2]                 # every column occurs twice: every maximum is attained twice
+    x = x.to(DEV)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(DEV)
+    ldw = 0
+    if cin % 4:
+        w = torch.nn.functional.pad(w, (0, -cin % 4)).contiguous()
+        ldw = w.size(1)
+    bias = torch.randn(cout, generator=g).to(DEV)
+    y = torch.empty(B, cout, L, device=DEV)
+    _lib.call("mvp_pointwise_mfma", DEV, B, cin, cout, L, x, None, w, ldw, 0, bias, None, relu, 1, y)
+    val = torch.empty(B, cout, device=DEV)
+    idx = torch.empty(B, cout, dtype=torch.int32, device=DEV)
+    keys = torch.full((B * cout,), -1, dtype=torch.int64, device=DEV)     # (contents irrelevant)
+    _lib.call("mvp_pointwise_mfma_max", DEV, B, cin, cout, L, x, w, ldw, bias, relu, val, idx, keys, keys.numel() * 8)
+    torch.cuda.synchronize()
+    want = y.max(dim=2)[0]
+    assert torch.equal(val, want)
+    first = (y == want.unsqueeze(2)).int().argmax(dim=2).int()
+    assert torch.equal(idx, first)
+    assert int(idx.max()) < L - L // 2 or relu                            # the first of the two copies (ReLU zeros may tie earlier still)
+
+
+def test_conv_max_layer_uses_the_fused_forward_and_matches_autograd():
+    """PointwiseConv1d.max_over_positions on an MFMA-routed shape: forward through mvp_pointwise_mfma_max, backward through
+    mvp_pointwise_max_backward -- values equal conv(x).max, gradients equal autograd's of the unfused formulation."""
+    from mvp_benchmark_amd import pointwise
+    torch.manual_seed(3)
+    layer = pointwise.PointwiseConv1d(256, 512).to(DEV)
+    x = torch.randn(4, 256, 768, device=DEV, requires_grad=True)
+    assert pointwise.mfma_conv_max(x.detach(), layer.weight.detach(), layer.bias.detach()) is not None
+    got = layer.max_over_positions(x)
+    ref = layer(x).max(dim=2)[0]
+    assert torch.equal(got, ref)
+    go = torch.randn_like(ref)
+    params = (x,) + tuple(layer.parameters())
+    for a, b in zip(torch.autograd.grad(got, params, go), torch.autograd.grad(ref, params, go)):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    with torch.no_grad():
+        assert torch.equal(layer.max_over_positions(x), ref)
