@@ -1,6 +1,6 @@
 """Runs tests/test_model_golden.py and prints, for every comparison with the reference-generated fixtures, the error
 actually measured next to the tolerance, and for every replayed pass the index rows that differed from the reference
-run (all of them verified ties).  Usage: python tools/model_golden_report.py [gpu]  ->  stdout (profiles/r5_model_golden_*.txt)."""
+run (all of them verified ties).  Usage: python tests/report_model_golden.py [gpu]   (lives under tests/: it drives tests that use the CPU oracle)  ->  stdout (profiles/r5_model_golden_*.txt)."""
 import os
 import sys
 
@@ -9,7 +9,7 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import test_model_golden as tm  # noqa: E402
 
 _close, _close_l2, _flips = tm.close, tm.close_l2, tm._check_flips

@@ -32,7 +32,7 @@ timeout 300 python tools/bench_knn.py > $out/bench_knn.txt 2>&1
   MVP_BENCH_REPS=5 timeout 300 python tools/bench_emd_one.py 32 16384 0.004 3000
   MVP_BENCH_REPS=5 timeout 300 python tools/bench_emd_one.py 64 16384 0.005 50
   MVP_BENCH_REPS=5 timeout 300 python tools/bench_emd_one.py 64 2048 0.005 50; } > $out/bench_emd_sweep.txt 2>&1
-timeout 900 python tools/model_golden_report.py gpu > $out/model_golden_gpu.txt 2>&1
+timeout 900 python tests/report_model_golden.py gpu > $out/model_golden_gpu.txt 2>&1
 timeout 600 python tools/bench_models.py > $out/bench_models.txt 2>&1
 timeout 900 python tools/emd_surfaces.py 64 16384 > $out/emd_surfaces_16384.txt 2>&1
 timeout 600 python tools/emd_surfaces.py 64 2048 > $out/emd_surfaces_2048.txt 2>&1
