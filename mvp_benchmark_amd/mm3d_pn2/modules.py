@@ -66,8 +66,10 @@ class QueryAndGroup(nn.Module):
             for p in range(idx.shape[1]):
                 uniq = torch.unique(idx[b, p])
                 counts[b, p] = uniq.numel()
-                extra = torch.randint(0, uniq.numel(), (self.sample_num - uniq.numel(),), device=uniq.device)
-                idx[b, p] = torch.cat((uniq, uniq[extra]))
+                # (drawn on the HOST generator, as the reference does -- group_points.py:86-90 calls torch.randint without a
+                # device --, so that a seed reproduces the reference's draws on any device)
+                extra = torch.randint(0, uniq.numel(), (self.sample_num - uniq.numel(),), dtype=torch.long)
+                idx[b, p] = torch.cat((uniq, uniq[extra.to(uniq.device)]))
         return counts
 
     def forward(self, points_xyz, center_xyz, features=None):
