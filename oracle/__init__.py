@@ -45,6 +45,11 @@ def lib():
     return _lib
 
 
+def set_contraction(on):
+    """True (default): the canonical fma chain; False: every product and sum rounded on its own (mvp_oracle.c)."""
+    lib().orc_set_contraction(1 if on else 0)
+
+
 def num_threads():
     return int(lib().orc_num_threads())
 
