@@ -174,12 +174,47 @@ def main():
         print(f"  knn k=16 (64,2048) q 2048:     {timed(lambda: ref.knn(16, x2, x2, v)):9.2f} | {timed(lambda: pn2.knn(16, x2, x2)):8.2f}")
         print(f"  ball_query s=32 (64,2048,512): {timed(lambda: ref.ball_query(0., .2, 32, x2, c2, v)):9.2f} | {timed(lambda: pn2.ball_query(0., .2, 32, x2, c2)):8.2f}")
         print(f"  three_nn (64,2048<-512):       {timed(lambda: ref.three_nn(x2, c2, v)):9.2f} | {timed(lambda: pn2.three_nn(x2, c2)):8.2f}")
+        f1 = dev(rnd(8, 64, 128, 2048))
+        gi = dev(np.random.default_rng(9).integers(0, 2048, (64, 512, 32)).astype(np.int32))
+        print(f"  group (64,128,2048) idx (512,32): {timed(lambda: ref.grouping_operation(f1, gi, v)):7.2f} | {timed(lambda: pn2.grouping_operation(f1, gi)):8.2f}")
+        ti = dev(np.random.default_rng(10).integers(0, 512, (64, 2048, 3)).astype(np.int32))
+        tw = dev(rnd(11, 64, 2048, 3))
+        f2 = dev(rnd(12, 64, 256, 512))
+        print(f"  three_interpolate (64,256,512->2048): {timed(lambda: ref.three_interpolate(f2, ti, tw, v)):5.2f} | {timed(lambda: pn2.three_interpolate(f2, ti, tw)):8.2f}")
+        # the reference's own harness shape for CD (unit_test.py / SURVEY 6): forward + backward at (32,2000,3)/(32,1000,3)
+        ha, hc = dev(rnd(13, 32, 2000, 3)), dev(rnd(14, 32, 1000, 3))
+        g1, g2 = dev(rnd(15, 32, 2000)), dev(rnd(16, 32, 1000))
+
+        def ref_cd_fb():
+            d1, d2, i1, i2 = ref.chamfer_forward(ha, hc, v)
+            ref.chamfer_backward(ha, hc, g1, g2, i1, i2, v)
+
+        def our_cd_fb():
+            pa, pc = ha.clone().requires_grad_(True), hc.clone().requires_grad_(True)
+            d1, d2, _, _ = cdm(pa, pc)
+            ((d1 * g1).sum() + (d2 * g2).sum()).backward()
+
+        print(f"  chamfer fwd+bwd (32,2000)/(32,1000): {timed(ref_cd_fb, 20):6.3f} | {timed(our_cd_fb, 20):8.3f}")
         em = metrics.emd()
-        for (b, n, eps, it, reps) in [(20, 8192, 0.05, 100, 2), (64, 2048, 0.004, 3000, 1), (64, 16384, 0.004, 3000, 1)]:
+        step_ref = step_our = None
+        for (b, n, eps, it, reps) in [(20, 8192, 0.05, 100, 2), (64, 2048, 0.005, 50, 3), (64, 1024, 0.004, 3000, 1),
+                                      (64, 2048, 0.004, 3000, 1), (64, 4096, 0.004, 3000, 1), (64, 8192, 0.004, 3000, 1),
+                                      (64, 16384, 0.004, 3000, 1)]:
             p, q = dev(rnd(6, b, n, 3)), dev(rnd(7, b, n, 3))
             tr = timed(lambda: ref.emd_forward(p, q, eps, it, v), reps)
             to = timed(lambda: em(p, q, eps, it), reps)
             print(f"  emd ({b},{n}) eps {eps} iters {it}: {tr:9.1f} | {to:8.2f}   ({tr / to:.0f}x)", flush=True)
+            step_ref, step_our = tr, to
+        tcr, tco = timed(lambda: ref.chamfer_forward(a, c, v)), timed(lambda: cdm(a, c))
+        print(f"  headline step (CD + EMD at (64,16384,3), eps 0.004, 3000 rounds): {tcr + step_ref:9.1f} | {tco + step_our:8.2f}   ({(tcr + step_ref) / (tco + step_our):.0f}x)")
+        from mvp_benchmark_amd import synthetic
+        for shape, modev in [("chair", 0.03), ("chair", "indep"), ("sphere", 0.03)]:
+            g = torch.Generator().manual_seed(5)
+            pr, gt = synthetic.prediction_pair(shape, modev, g, 64, 16384)
+            pr, gt = pr.cuda(), gt.cuda()
+            tr = timed(lambda: ref.emd_forward(pr, gt, 0.004, 3000, v), 1)
+            to = timed(lambda: em(pr, gt, 0.004, 3000), 1)
+            print(f"  emd surface {shape} / {modev} (64,16384): {tr:9.1f} | {to:8.2f}   ({tr / to:.0f}x)", flush=True)
 
 
 if __name__ == "__main__":
