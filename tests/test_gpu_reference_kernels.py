@@ -215,6 +215,9 @@ def test_reference_chamfer_kernel_exact_ties(oracle, mode):
 
 
 EMD_CASES = [(2, 1024, 0.005, 50), (2, 1024, 0.002, 10000), (4, 2048, 0.004, 3000), (2, 2048, 0.05, 100), (3, 1024, 0.004, 3000),
+             # the forced last round with most persons still unassigned (emd_cuda.cu:200); three blocks per cloud; eps extremes
+             (2, 1024, 0.005, 1), (2, 1024, 0.005, 2), (2, 1024, 0.005, 5), (2, 3072, 0.01, 300), (3, 2048, 0.05, 3000),
+             (2, 1024, 1e-4, 500),
              (2, 4096, 0.004, 3000), (2, 8192, 0.004, 3000)]
 
 
