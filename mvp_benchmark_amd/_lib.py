@@ -126,10 +126,21 @@ def _ptr(t):
     return t.data_ptr()
 
 
+_FN = {}   # name -> (ctypes function, signature): one attribute lookup per entry point, not per call
+
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream   # the current stream's handle without building a Stream object
+except AttributeError:   # pragma: no cover
+    _raw_stream = None
+
+
 def call(name, device, *args):
-    """Invoke one C-ABI entry point on `device`'s current stream."""
-    lib = load()
-    sig = SIGNATURES[name]
+    """Invoke one C-ABI entry point on `device`'s current stream.  (Host cost matters for the small ops: a completion
+    network issues ~600 of these per step; everything that can be looked up once is.)"""
+    ent = _FN.get(name)
+    if ent is None:
+        ent = _FN[name] = (getattr(load(), name), SIGNATURES[name])
+    fn, sig = ent
     assert len(sig) == len(args), (name, len(sig), len(args))
     cargs = []
     for kind, a in zip(sig, args):
@@ -139,13 +150,20 @@ def call(name, device, *args):
             cargs.append(float(a))
         else:
             cargs.append(int(a))
-    with torch.cuda.device(device):
-        stream = torch.cuda.current_stream(device).cuda_stream
-        rc = getattr(lib, name)(*cargs, stream)
+    idx = device.index
+    cur = torch.cuda.current_device()
+    if idx is None:
+        idx = cur
+    if idx == cur:
+        stream = _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(idx).cuda_stream
+        rc = fn(*cargs, stream)
+    else:
+        with torch.cuda.device(idx):
+            rc = fn(*cargs, torch.cuda.current_stream(idx).cuda_stream)
     if rc != MVP_OK:
         detail = _ERR.get(rc, "code %d" % rc)
         if rc == -3:
-            detail += ": " + lib.mvp_last_hip_error().decode()
+            detail += ": " + load().mvp_last_hip_error().decode()
         raise MvpOpsError("%s failed: %s" % (name, detail))
 
 

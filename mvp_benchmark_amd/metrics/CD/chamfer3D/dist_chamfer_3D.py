@@ -34,8 +34,14 @@ class chamfer_3DFunction(Function):
         xyz1, xyz2 = _as_cloud(xyz1), _as_cloud(xyz2)
         B, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
         dev = xyz1.device
-        dist = [torch.zeros(B, k, device=dev) for k in (n, m)]
-        idx = [torch.zeros(B, k, dtype=torch.int32, device=dev) for k in (n, m)]
+        # one buffer per dtype, no memset: with n, m > 0 the kernels write every element (tests poison the buffers);
+        # empty sides keep the reference's zeros (:33-37)
+        alloc = torch.empty if (n > 0 and m > 0) else torch.zeros
+        off = (B * n + 63) & ~63                     # the second side starts 256-byte aligned
+        dbuf = alloc(off + B * m, device=dev)
+        ibuf = alloc(off + B * m, dtype=torch.int32, device=dev)
+        dist = [dbuf[:B * n].view(B, n), dbuf[off:].view(B, m)]
+        idx = [ibuf[:B * n].view(B, n), ibuf[off:].view(B, m)]
         if n >= SORTED_MIN_POINTS and m >= SORTED_MIN_POINTS and n * m >= SORTED_MIN_PAIRS:
             # large clouds: Morton-sorted sides + tile skipping (same bits, a fraction of the pairs)
             nbytes = chamfer_scratch_bytes(B, n, m)
@@ -52,7 +58,10 @@ class chamfer_3DFunction(Function):
     def backward(ctx, graddist1, graddist2, gradidx1, gradidx2):
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
         dev = graddist1.device
-        grads = [torch.zeros(x.shape, device=dev) for x in (xyz1, xyz2)]
+        k1 = xyz1.numel()
+        off = (k1 + 63) & ~63
+        gbuf = torch.zeros(off + xyz2.numel(), device=dev)       # one memset for both gradients
+        grads = [gbuf[:k1].view(xyz1.shape), gbuf[off:].view(xyz2.shape)]
         call("mvp_chamfer_backward", dev, xyz1.shape[0], xyz1.shape[1], xyz2.shape[1], xyz1, xyz2,
              grads[0], grads[1], graddist1.contiguous(), graddist2.contiguous(), idx1, idx2)
         return grads[0], grads[1]

@@ -1326,3 +1326,28 @@ def test_emd_surface_shaped_clouds_match_oracle(oracle, emd_split, n, split):
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
     rec = _lib.emd_records(scratch, nbytes, b)
     assert (rec["next_round"] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,m", [(3, 77, 130), (2, 2048, 4100), (1, 1, 5)])
+def test_chamfer_forward_writes_every_output_element(oracle, b, n, m):
+    """chamfer_3DFunction allocates its outputs with torch.empty: the kernels must overwrite all of them (both launch
+    paths), whatever the buffers held."""
+    import torch
+    from mvp_benchmark_amd._lib import call, chamfer_scratch_bytes
+    a, c = rand_clouds(n, b, n, 3), rand_clouds(m + 1, b, m, 3)
+    xa, xc = torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda()
+    want = oracle.chamfer_forward(a, c)
+    for sorted_path in (False, True):
+        d1 = torch.full((b, n), float("nan"), device="cuda")
+        d2 = torch.full((b, m), float("nan"), device="cuda")
+        i1 = torch.full((b, n), -7, dtype=torch.int32, device="cuda")
+        i2 = torch.full((b, m), -7, dtype=torch.int32, device="cuda")
+        if sorted_path:
+            nb = chamfer_scratch_bytes(b, n, m)
+            scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+            call("mvp_chamfer_forward_sorted", xa.device, b, n, m, xa, xc, d1, d2, i1, i2, scratch, nb)
+        else:
+            call("mvp_chamfer_forward", xa.device, b, n, m, xa, xc, d1, d2, i1, i2)
+        for got, w in zip((d1, d2, i1, i2), want):
+            np.testing.assert_array_equal(got.cpu().numpy(), w)
