@@ -197,7 +197,7 @@ def main():
         print(f"  chamfer fwd+bwd (32,2000)/(32,1000): {timed(ref_cd_fb, 20):6.3f} | {timed(our_cd_fb, 20):8.3f}")
         em = metrics.emd()
         step_ref = step_our = None
-        for (b, n, eps, it, reps) in [(20, 8192, 0.05, 100, 2), (64, 2048, 0.005, 50, 3), (64, 1024, 0.004, 3000, 1),
+        for (b, n, eps, it, reps) in [(20, 8192, 0.05, 3000, 1), (64, 2048, 0.005, 50, 3), (64, 1024, 0.004, 3000, 1),
                                       (64, 2048, 0.004, 3000, 1), (64, 4096, 0.004, 3000, 1), (64, 8192, 0.004, 3000, 1),
                                       (64, 16384, 0.004, 3000, 1)]:
             p, q = dev(rnd(6, b, n, 3)), dev(rnd(7, b, n, 3))
