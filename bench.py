@@ -34,6 +34,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) including
   roofline     -- for the dominant kernel (the persistent EMD auction kernel)
   cpu_baseline -- the CPU oracle timed on a bounded sample of the same workload
   cpu_baseline_reference_path -- the reference's own CPU path for CD
+  gpu_reference_baseline -- the reference's own CD / EMD kernels (oracle/_ref, compiled for gfx950 as written) on the timed batch
                   (distChamfer, restated in metrics/CD/chamfer_python.py) timed
                   with all torch threads
   extra        -- per-op times, FPS throughput, CD figures.
@@ -177,6 +178,37 @@ def cpu_baseline(args, n):
                       bs, n, args.eps, args.iters, t1 - t0, t2 - t1,
                       int(stats[:, 0].max()), float(stats[:, 1].mean())),
     }
+
+
+def gpu_reference_baseline(args, pred, gt, our_cd_ms, our_emd_ms):
+    """The REFERENCE's own Chamfer and EMD kernels on the SAME resident batch of this GPU: utils/metrics/CD/chamfer3D and
+    utils/metrics/EMD compiled for gfx950 AS WRITTEN by oracle/build_ref_gpu.sh (oracle/_ref: test infrastructure, built
+    where the reference tree is present and shipped as .so files).  A baseline beside `cpu_baseline`, measured after the
+    timed region; the product never loads it.  None when oracle/_ref is not there."""
+    try:
+        from oracle import ref_gpu
+        if not ref_gpu.available(""):
+            return None
+        ref_gpu.chamfer_forward(gt, pred)                       # warm-up: module load, first launch
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ref_gpu.chamfer_forward(gt, pred)                   # (each call allocates its outputs and synchronises)
+        cd_ms = (time.perf_counter() - t0) / 3 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(2):
+            d, _, _ = ref_gpu.emd_forward(pred, gt, args.eps, args.iters)
+        emd_ms = (time.perf_counter() - t0) / 2 * 1e3
+    except Exception as e:   # a baseline must not break the bench line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    B, n = pred.shape[0], pred.shape[1]
+    return {"value": float(B) * n * n / ((cd_ms + emd_ms) * 1e-3), "unit": "point-pairs/s", "kind": "reference kernels on this GPU",
+            "cd_ms": cd_ms, "emd_ms": emd_ms, "ms_per_step": cd_ms + emd_ms,
+            "this_repo_ms": {"cd_f1_ms": our_cd_ms, "emd_ms": our_emd_ms},
+            "speedup_of_this_repo": (cd_ms + emd_ms) / (our_cd_ms + our_emd_ms),
+            "emd_mean_sqrt_dist": float(d.sqrt().mean()),
+            "sample": "the timed batch itself: chamfer_cuda_forward + emd_cuda_forward (eps=%g, iters=%d) on (%d,%d,3), wrapper "
+                      "allocations included, F-score (Python on both sides) not; chamfer3D.cu / emd_cuda.cu through hipify-perl + "
+                      "hipcc --offload-arch=gfx950 with default flags (DESIGN 2.2)" % (args.eps, args.iters, B, n)}
 
 
 def cpu_reference_path(n):
@@ -437,6 +469,7 @@ def run_eval(args, rank, world, dev):
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, n)
         line["cpu_baseline_reference_path"] = cpu_reference_path(n)
+        line["gpu_reference_baseline"] = gpu_reference_baseline(args, pred, gt, cd_ms, emd_ms)
     return line
 
 
