@@ -41,6 +41,8 @@ fi
 TMP=$(mktemp -d)
 trap 'rm -rf "$TMP"' EXIT
 
+# (every translation + compilation below is independent of the others: run them side by side, link at the end)
+pids=()
 # --- PointNet++ kernels: no CUDA header is included by these files; hipcc needs nothing but the renamed runtime calls
 objs=()
 for f in furthest_point_sample/src/furthest_point_sample_cuda.cu knn/src/knn_cuda.cu ball_query/src/ball_query_cuda.cu \
@@ -48,22 +50,23 @@ for f in furthest_point_sample/src/furthest_point_sample_cuda.cu knn/src/knn_cud
          group_points/src/group_points_cuda.cu; do
   n=$(basename "$f" .cu)
   "$HIPIFY" "$REF/utils/mm3d_pn2/ops/$f" > "$TMP/$n.hip" 2>/dev/null
-  "$HIPCC" --offload-arch=$ARCH -O2 -fPIC -w $CONTRACT -c "$TMP/$n.hip" -o "$TMP/$n.o"
+  "$HIPCC" --offload-arch=$ARCH -O2 -fPIC -w $CONTRACT -c "$TMP/$n.hip" -o "$TMP/$n.o" & pids+=($!)
   objs+=("$TMP/$n.o")
 done
-"$HIPCC" -shared -fPIC "${objs[@]}" -L/opt/rocm/lib -lamdhip64 -o "$OUT/libref_pn2$SUFFIX.so"
 
 # --- EMD and Chamfer: kernels + the reference's own pybind shims (at::Tensor in, raw pointers out)
 "$HIPIFY" "$REF/utils/metrics/EMD/emd_cuda.cu" 2>/dev/null | sed 's/\batomicMax\b/ref_atomicMax/g' > "$TMP/emd_cuda.hip"
-"$HIPCC" --offload-arch=$ARCH $INC $DEFS -std=c++17 -O2 -fPIC -w $CONTRACT -c "$TMP/emd_cuda.hip" -o "$TMP/emd_cuda.o"
+"$HIPCC" --offload-arch=$ARCH $INC $DEFS -std=c++17 -O2 -fPIC -w $CONTRACT -c "$TMP/emd_cuda.hip" -o "$TMP/emd_cuda.o" & pids+=($!)
 g++ $INC $DEFS -std=c++17 -O2 -fPIC -w -DTORCH_EXTENSION_NAME=ref_emd$SUFFIX -DTORCH_API_INCLUDE_EXTENSION_H \
-    -c "$REF/utils/metrics/EMD/emd.cpp" -o "$TMP/emd_bind.o"
-"$HIPCC" -shared -fPIC "$TMP/emd_cuda.o" "$TMP/emd_bind.o" $LIBS -o "$OUT/ref_emd$SUFFIX.so"
-
+    -c "$REF/utils/metrics/EMD/emd.cpp" -o "$TMP/emd_bind.o" & pids+=($!)
 "$HIPIFY" "$REF/utils/metrics/CD/chamfer3D/chamfer3D.cu" > "$TMP/chamfer3D.hip" 2>/dev/null
-"$HIPCC" --offload-arch=$ARCH $INC $DEFS -std=c++17 -O2 -fPIC -w $CONTRACT -c "$TMP/chamfer3D.hip" -o "$TMP/chamfer3D.o"
+"$HIPCC" --offload-arch=$ARCH $INC $DEFS -std=c++17 -O2 -fPIC -w $CONTRACT -c "$TMP/chamfer3D.hip" -o "$TMP/chamfer3D.o" & pids+=($!)
 g++ $INC $DEFS -std=c++17 -O2 -fPIC -w -DTORCH_EXTENSION_NAME=ref_chamfer_3D$SUFFIX -DTORCH_API_INCLUDE_EXTENSION_H \
-    -c "$REF/utils/metrics/CD/chamfer3D/chamfer_cuda.cpp" -o "$TMP/chamfer_bind.o"
+    -c "$REF/utils/metrics/CD/chamfer3D/chamfer_cuda.cpp" -o "$TMP/chamfer_bind.o" & pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+
+"$HIPCC" -shared -fPIC "${objs[@]}" -L/opt/rocm/lib -lamdhip64 -o "$OUT/libref_pn2$SUFFIX.so"
+"$HIPCC" -shared -fPIC "$TMP/emd_cuda.o" "$TMP/emd_bind.o" $LIBS -o "$OUT/ref_emd$SUFFIX.so"
 "$HIPCC" -shared -fPIC "$TMP/chamfer3D.o" "$TMP/chamfer_bind.o" $LIBS -o "$OUT/ref_chamfer_3D$SUFFIX.so"
 
 echo "$want$CONTRACT" > "$stamp"
