@@ -60,7 +60,7 @@ def run(kind, arg, x, v):
     if kind == "emd":
         runs = [ref.emd_forward(dev(x["a"]), dev(x["c"]), arg["eps"], arg["iters"], v) for _ in range(3)]
         assert all(torch.equal(runs[0][1], r[1]) for r in runs[1:]), "a fixture case must be deterministic on the reference"
-        d, a, p = runs[0]
+        d, a, _ = runs[0]
         res = {"dist": host(d), "assignment": host(a)}
         if arg.get("grad"):
             res["gradxyz1"] = host(ref.emd_backward(dev(x["a"]), dev(x["c"]), dev(x["g"]), a, v)[0])

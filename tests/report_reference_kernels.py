@@ -20,7 +20,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as orc  # noqa: E402
 import ref_kernels as ref  # noqa: E402
 from mvp_benchmark_amd import metrics, mm3d_pn2 as pn2  # noqa: E402
-from mvp_benchmark_amd.mm3d_pn2 import functional as F  # noqa: E402
 
 
 def rnd(seed, *shape):
