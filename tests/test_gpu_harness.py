@@ -794,3 +794,35 @@ def test_conv_max_layer_uses_the_fused_forward_and_matches_autograd():
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
     with torch.no_grad():
         assert torch.equal(layer.max_over_positions(x), ref)
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields(tmp_path):
+    """`python bench.py` on a small shape: ONE JSON line with the driver's contract keys, `roofline`, `cpu_baseline`, and
+    (where oracle/_ref travelled) `gpu_reference_baseline` -- the reference's own kernels on the timed batch."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "4", "--points", "2048", "--iters", "200",
+                          "--steps", "2", "--warmup", "1", "--cpu-sample", "2", "--no-side"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 4 * 2048 * 2048 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    from oracle import ref_gpu
+    g = d.get("gpu_reference_baseline")
+    if ref_gpu.available(""):
+        assert g and "error" not in g, g
+        assert g["ms_per_step"] > 0 and g["speedup_of_this_repo"] > 1.0
+    else:
+        assert g is None
