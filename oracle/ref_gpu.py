@@ -31,6 +31,14 @@ _SYMS = {
 
 _cache = {}
 
+SYNC = True   # tests compare results right away; a timing of many calls in a row sets this to False (the reference's own
+              # wrappers do not synchronise either)
+
+
+def _sync():
+    if SYNC:
+        torch.cuda.synchronize()
+
 
 def available(variant=""):
     return all(os.path.exists(os.path.join(REF_DIR, f)) for f in
@@ -69,7 +77,7 @@ def _call(variant, name, *args):
             conv.append(ctypes.c_int(int(a)))
     conv.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     fn(*conv)
-    torch.cuda.synchronize()
+    _sync()
 
 
 def fps(xyz, m, variant=""):
@@ -180,7 +188,7 @@ def chamfer_forward(xyz1, xyz2, variant=""):
     i1 = torch.zeros(b, n, device=dev, dtype=torch.int32)
     i2 = torch.zeros(b, m, device=dev, dtype=torch.int32)
     _module("ref_chamfer_3D", variant).forward(xyz1, xyz2, d1, d2, i1, i2)
-    torch.cuda.synchronize()
+    _sync()
     return d1, d2, i1, i2
 
 
@@ -189,7 +197,7 @@ def chamfer_backward(xyz1, xyz2, g1, g2, i1, i2, variant=""):
     gx1 = torch.zeros_like(xyz1)
     gx2 = torch.zeros_like(xyz2)
     _module("ref_chamfer_3D", variant).backward(xyz1, xyz2, gx1, gx2, g1, g2, i1, i2)
-    torch.cuda.synchronize()
+    _sync()
     return gx1, gx2
 
 
@@ -213,7 +221,7 @@ def emd_forward(xyz1, xyz2, eps, iters, variant=""):
     cnt_tmp = z(512, dt=torch.int32)
     _module("ref_emd", variant).forward(xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments,
                                         max_increments, unass_idx, unass_cnt, unass_cnt_sum, cnt_tmp, max_idx, eps, iters)
-    torch.cuda.synchronize()
+    _sync()
     return dist, assignment, price
 
 
@@ -222,5 +230,5 @@ def emd_backward(xyz1, xyz2, graddist, assignment, variant=""):
     gx1 = torch.zeros_like(xyz1)
     gx2 = torch.zeros_like(xyz2)
     _module("ref_emd", variant).backward(xyz1, xyz2, gx1, graddist, assignment)
-    torch.cuda.synchronize()
+    _sync()
     return gx1, gx2
