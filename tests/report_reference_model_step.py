@@ -47,17 +47,23 @@ def step_ms(name, fused):
     g = torch.Generator().manual_seed(0)
     args = train.load_config(os.path.join(ROOT, "completion", "cfgs", name + ".yaml"))
     args.load_model = None
+    torch.manual_seed(0)                 # the same initial weights in every mode
     net = importlib.import_module("models." + name).Model(args).to(dev).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=fused)
     gt = torch.rand(32, 2048, 3, generator=g).to(dev)
     partial = gt.transpose(2, 1).contiguous()
 
+    losses = []
+
     def step():
         opt.zero_grad()
+        torch.manual_seed(1)             # (VRCNet's reparameterisation noise / dropout: the same draw in every mode)
         _, _, loss = net(partial, gt, alpha=0.5)
+        if len(losses) < 1:
+            losses.append(float(loss.mean()))
         loss.backward()
         opt.step()
-    return timed(step)
+    return timed(step), losses[0]
 
 
 def main():
@@ -66,20 +72,20 @@ def main():
     for name in names:
         op_config.OPS.reset()
         pw.MFMA_TRAIN = True
-        a = step_ms(name, True)
+        a, la = step_ms(name, True)
         op_config.configure(gather_sum=0, gather_max=0, side_lanes=0, stacked_projections=0, skip_full_fps_of_gt=0,
                             conv_before_interp=0, folded_conv=0)
         pw.MFMA_TRAIN = False
-        b = step_ms(name, False)
+        b, lb = step_ms(name, False)
         undo = ref_ops.patch_ops(modules())
         ref_ops.ref.SYNC = False            # like the reference's wrappers: no host synchronisation per operator
         try:
-            c = step_ms(name, False)
+            c, lc = step_ms(name, False)
         finally:
             ref_ops.ref.SYNC = True
             undo()
         print("  %-7s as shipped %7.2f | reference formulation, this repo's op kernels %7.2f | reference formulation, the reference's "
-              "op kernels %7.2f   (%.1fx)" % (name, a, b, c, c / a), flush=True)
+              "op kernels %7.2f   (%.1fx)   first-step loss %.7f | %.7f | %.7f" % (name, a, b, c, c / a, la, lb, lc), flush=True)
     op_config.OPS.reset()
     pw.MFMA_TRAIN = True
 
