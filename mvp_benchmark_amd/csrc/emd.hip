@@ -62,6 +62,7 @@
 #include <mutex>
 
 #include "emd_common.h"
+#include "emd_index.h"
 
 namespace mvp {
 
@@ -174,13 +175,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
-  // Per-cell metadata (SoA, conflict-free lane-per-cell reads).
-  // per cell: {box min x, y, z, price lower bound} and {box max x, y, z, -}:
-  // a cell test is two ds_read_b128 per lane
-  __shared__ float4 c_lo[kMaxCells], c_hi[kMaxCells];
-  __shared__ int c_start[kMaxCells + 1];
-  __shared__ int s_tmp[kMaxCells];  // counts / fill cursors during the build
-  __shared__ unsigned short w_list[kEmdWaves][4 * kRowListCap];  // surviving cells, per 16-lane row
+  // The index (emd_index.h): per leaf and per node {box min x, y, z, price lower bound} and {box max x, y, z, -}:
+  // a box test is two ds_read_b128 per lane.  (During the build the leaves' 32 KB hold the sort's 512 x 16 counters.)
+  __shared__ float4 l_box[2 * kMaxLeaves];
+  float4 *const l_lo = l_box, *const l_hi = l_box + kMaxLeaves;
+  __shared__ float4 n_lo[kMaxNodes], n_hi[kMaxNodes];
+  __shared__ int s_leafkey[kMaxLeaves];  // build only: first Hilbert key of every leaf (the persons' home chunks)
+  __shared__ unsigned short w_list[kEmdWaves][4 * kRowListCap];  // surviving leaves, per 16-lane row
   __shared__ float s_red[6][kEmdWaves];
   __shared__ int s_wsum[kEmdWaves];
   __shared__ int s_cnt[2];
@@ -207,33 +208,11 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   __shared__ float4 s_rq[2][kRecCap];
   __shared__ int4 s_ri[2][kRecCap];
 
-  // ------------------------------------------------------------ grid build
-  // Every workgroup of the cluster derives the same grid geometry and cell
-  // offsets (deterministic reductions); member 0 alone writes the shared
-  // cell-sorted arrays and the initial state.
-  // (a) bounding box of both clouds
-  float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-  float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-  for (int k = t; k < n; k += kEmdThreads) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float u = xyz1[k * 3 + a], w = xyz2[k * 3 + a];
-      mn[a] = __builtin_fminf(mn[a], __builtin_fminf(u, w));
-      mx[a] = __builtin_fmaxf(mx[a], __builtin_fmaxf(u, w));
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      mn[a] = __builtin_fminf(mn[a], __shfl_xor(mn[a], off, kWave));
-      mx[a] = __builtin_fmaxf(mx[a], __shfl_xor(mx[a], off, kWave));
-    }
-    if (lane == 0) {
-      s_red[a][wave] = mn[a];
-      s_red[3 + a][wave] = mx[a];
-    }
-  }
+  // ------------------------------------------------------------ index build (emd_index.h)
+  // Member 0 alone sorts the objects along the Hilbert curve and writes the shared arrays and the initial state;
+  // after the cluster's barrier every member derives the leaves' and nodes' boxes from the sorted objects itself.
+  const int lshift = emd_leaf_shift(n), nleaf = n >> lshift, nnode = (nleaf + kNodeFan - 1) / kNodeFan;
+  const int kch = 1 << (lshift - 4);   // 16-slot chunks per leaf (1 up to 16384 points)
   if (t == 0) {
     s_err = 0;
     s_abort = 0;
@@ -242,101 +221,87 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     s_next = kEmdWaves;
     s_nchg = 0;
   }
-  __syncthreads();
-  GridGeom gg;
-  {
-    float lo[3], hi[3];
+  if (wg == 0) {
+    // (a) the cube that bounds both clouds
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int k = t; k < n; k += kEmdThreads) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float u = xyz1[k * 3 + a], w = xyz2[k * 3 + a];
+        mn[a] = __builtin_fminf(mn[a], __builtin_fminf(u, w));
+        mx[a] = __builtin_fmaxf(mx[a], __builtin_fmaxf(u, w));
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      lo[a] = s_red[a][0];
-      hi[a] = s_red[3 + a][0];
-      for (int w = 1; w < kEmdWaves; ++w) {
-        lo[a] = __builtin_fminf(lo[a], s_red[a][w]);
-        hi[a] = __builtin_fmaxf(hi[a], s_red[3 + a][w]);
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        mn[a] = __builtin_fminf(mn[a], __shfl_xor(mn[a], off, kWave));
+        mx[a] = __builtin_fmaxf(mx[a], __shfl_xor(mx[a], off, kWave));
+      }
+      if (lane == 0) {
+        s_red[a][wave] = mn[a];
+        s_red[3 + a][wave] = mx[a];
       }
     }
-    float ext = __builtin_fmaxf(hi[0] - lo[0],
-                                __builtin_fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
-    if (!(ext > 0.f) || !(ext < 3.0e38f)) ext = 1.f;
-    // ~12 objects per cell (one 32-lane half-wave), 2 <= G <= 12
-    int g = 2;
-    while (g < kMaxG && (g + 1) * (g + 1) * (g + 1) * 12 <= n) ++g;
-    gg.g = g;
-    gg.lox = lo[0];
-    gg.loy = lo[1];
-    gg.loz = lo[2];
-    gg.invh = (float)g / ext;
-  }
-  const int ncell = gg.g * gg.g * gg.g;
-
-  // (b) histogram
-  for (int c = t; c < kMaxCells; c += kEmdThreads) s_tmp[c] = 0;
-  __syncthreads();
-  for (int k = t; k < n; k += kEmdThreads)
-    atomicAdd(&s_tmp[emd_cell(gg, xyz2[k * 3 + 0], xyz2[k * 3 + 1], xyz2[k * 3 + 2])], 1);
-  __syncthreads();
-  // (c) exclusive prefix sum over <= 1728 cells: 2 cells per thread
-  {
-    const int c0 = 2 * t, c1 = 2 * t + 1;
-    const int v0 = c0 < ncell ? s_tmp[c0] : 0;
-    const int v1 = c1 < ncell ? s_tmp[c1] : 0;
-    int incl = v0 + v1;
+    __syncthreads();
+    HilbertFrame hf;
+    {
+      float lo[3], hi[3];
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const int o = __shfl_up(incl, off, kWave);
-      if (lane >= off) incl += o;
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = s_red[a][0];
+        hi[a] = s_red[3 + a][0];
+        for (int w = 1; w < kEmdWaves; ++w) {
+          lo[a] = __builtin_fminf(lo[a], s_red[a][w]);
+          hi[a] = __builtin_fmaxf(hi[a], s_red[3 + a][w]);
+        }
+      }
+      float ext = __builtin_fmaxf(hi[0] - lo[0], __builtin_fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
+      if (!(ext > 0.f) || !(ext < 3.0e38f)) ext = 1.f;
+      hf.lox = lo[0];
+      hf.loy = lo[1];
+      hf.loz = lo[2];
+      hf.scale = (float)(1 << kHilbertBits) / ext;
     }
-    if (lane == kWave - 1) s_wsum[wave] = incl;
+    // (b) {Hilbert key, object} pairs, sorted by three stable 9-bit passes through the (not yet used) list areas
+    u64 *buf_a = reinterpret_cast<u64 *>(sc.ulist), *buf_b = buf_a + n;   // 16 n of the lists' 64 n bytes
+    for (int k = t; k < n; k += kEmdThreads)
+      buf_a[k] = ((u64)emd_hilbert_key(hf, xyz2[k * 3 + 0], xyz2[k * 3 + 1], xyz2[k * 3 + 2]) << 32) | (u64)(unsigned)k;
     __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
-    const int excl = wbase + incl - (v0 + v1);
-    if (c0 <= ncell) c_start[c0] = excl;
-    if (c1 <= ncell) c_start[c1] = excl + v0;
-    __syncthreads();
-    if (c0 < kMaxCells) s_tmp[c0] = 0;
-    if (c1 < kMaxCells) s_tmp[c1] = 0;
-    __syncthreads();
-  }
-  // (d) member 0: scatter into cell-sorted order; initial state of
-  // emd_module.py:54-65
-  if (wg == 0) {
-    for (int k = t; k < n; k += kEmdThreads) {
-      const float x = xyz2[k * 3 + 0], y = xyz2[k * 3 + 1], z = xyz2[k * 3 + 2];
-      const int c = emd_cell(gg, x, y, z);
-      const int s = c_start[c] + atomicAdd(&s_tmp[c], 1);
-      sc.obj[s] = make_float4(x, y, z, 0.f);
+    int *hist = reinterpret_cast<int *>(l_box);
+    static_assert(sizeof(float4) * 2 * kMaxLeaves >= sizeof(int) * kSortDigits * kEmdWaves, "the counters fit the leaves' LDS");
+    emd_sort_pass(buf_a, buf_b, n, 0, hist, s_wsum);
+    emd_sort_pass(buf_b, buf_a, n, kHilbertBits, hist, s_wsum);
+    emd_sort_pass(buf_a, buf_b, n, 2 * kHilbertBits, hist, s_wsum);
+    // (c) the sorted objects; initial state of emd_module.py:54-65
+    for (int s = t; s < n; s += kEmdThreads) {
+      const u64 e = buf_b[s];
+      const int k = (int)(unsigned)e;
+      sc.obj[s] = make_float4(xyz2[k * 3 + 0], xyz2[k * 3 + 1], xyz2[k * 3 + 2], 0.f);
       sc.perm[s] = k;
-      ass[k] = -1;
-      sc.ostate[k] = make_int4(0, 0, -1, 0);
-      sc.person[2 * k] = make_float4(xyz1[k * 3 + 0], xyz1[k * 3 + 1], xyz1[k * 3 + 2], 0.f);
+      ass[s] = -1;
+      sc.ostate[s] = make_int4(0, 0, -1, 0);
+      if ((s & ((1 << lshift) - 1)) == 0) s_leafkey[s >> lshift] = (int)(unsigned)(e >> 32);
+    }
+    __syncthreads();
+    // (d) the persons' records: point + home chunk (the leaf whose key range holds the person's own key)
+    for (int k = t; k < n; k += kEmdThreads) {
+      const float x = xyz1[k * 3 + 0], y = xyz1[k * 3 + 1], z = xyz1[k * 3 + 2];
+      const int key = (int)emd_hilbert_key(hf, x, y, z);
+      int lo = 0, hi = nleaf;   // last leaf whose first key is <= key (leaf 0 if none)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_leafkey[mid] <= key) lo = mid; else hi = mid;
+      }
+      sc.person[2 * k] = make_float4(x, y, z, __int_as_float(lo << (lshift - 4)));
       sc.person[2 * k + 1] = make_float4(__int_as_float(-1), __int_as_float(-1), __int_as_float(-1), 0.f);
     }
-    if (lean) {  // what the second kernel needs to rebuild the cell index
-      for (int c = t; c <= ncell; c += kEmdThreads) sc.cstart[c] = c_start[c];
-      if (t == 0) {
-        resume->g = gg.g;
-        resume->lox = gg.lox;
-        resume->loy = gg.loy;
-        resume->loz = gg.loz;
-        resume->invh = gg.invh;
-      }
-    }
   }
-  // every member: its own share of the persons is its first unassigned list
   int share = n / W;  // n % 1024 == 0
   int first = wg * share;
   int *my_ulist = sc.ulist + (size_t)wg * 2 * n;
-  for (int k = t; k < share; k += kEmdThreads) my_ulist[k] = first + k;
-  if (t < kRecCap && t < share) {  // round 0: list position u holds person first + u
-    const int k = first + t;
-    s_rq[0][t] = make_float4(xyz1[k * 3 + 0], xyz1[k * 3 + 1], xyz1[k * 3 + 2], 0.f);
-    s_ri[0][t] = make_int4(k, -1, -1, 0);
-  }
-  if (t == 0) {
-    s_cnt[0] = share;
-    s_cnt[1] = 0;
-  }
   unsigned epoch = 0;
   if constexpr (W > 1) {
     // hand the shared arrays to the other members: release (write back this
@@ -368,22 +333,18 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
   } else {
     __syncthreads();
   }
-  // (e) exact bounding box per cell; price lower bound 0
-  for (int c = t; c < ncell; c += kEmdThreads) {
-    float bx0 = __builtin_inff(), by0 = __builtin_inff(), bz0 = __builtin_inff();
-    float bx1 = -__builtin_inff(), by1 = -__builtin_inff(), bz1 = -__builtin_inff();
-    for (int s = c_start[c]; s < c_start[c + 1]; ++s) {
-      const float4 o = sc.obj[s];
-      bx0 = __builtin_fminf(bx0, o.x);
-      by0 = __builtin_fminf(by0, o.y);
-      bz0 = __builtin_fminf(bz0, o.z);
-      bx1 = __builtin_fmaxf(bx1, o.x);
-      by1 = __builtin_fmaxf(by1, o.y);
-      bz1 = __builtin_fmaxf(bz1, o.z);
-    }
-    c_lo[c] = make_float4(bx0, by0, bz0, 0.f);
-    // (.w: the cell's members in chunks of 16, minus one, at most 31 -- a search lists a cell once per chunk, see there)
-    c_hi[c] = make_float4(bx1, by1, bz1, (float)min(31, max(0, c_start[c + 1] - c_start[c] - 1) >> 4));
+  // (e) every member: exact box per leaf and node, price lower bounds 0 (emd_index.h; ends with a barrier) ...
+  emd_index_boxes(l_lo, l_hi, n_lo, n_hi, sc.obj, n, lshift);
+  // ... and its own share of the persons as its first unassigned list (the list areas were the sort's buffers)
+  for (int k = t; k < share; k += kEmdThreads) my_ulist[k] = first + k;
+  if (t < kRecCap && t < share) {  // round 0: list position u holds person first + u
+    const int k = first + t;
+    s_rq[0][t] = sc.person[2 * k];
+    s_ri[0][t] = make_int4(k, -1, -1, 0);
+  }
+  if (t == 0) {
+    s_cnt[0] = share;
+    s_cnt[1] = 0;
   }
   __syncthreads();
 
@@ -465,39 +426,25 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         const int j = rb.x;
         const float qx = ra.x, qy = ra.y, qz = ra.z;
         const int p1 = rb.y, p2 = rb.z;
-        const int c0 = emd_cell(gg, qx, qy, qz);
+        const int hc = act ? __float_as_int(ra.w) : 0;   // home chunk (emd_index.h)
 
-        // (1) seed: second-largest exact value among DISTINCT real objects --
-        // the home cell's members plus the previous best / second best when
-        // they live elsewhere (a valid lower bound of the final second best).
+        // (1) seed: second-largest exact value among DISTINCT real objects -- the
+        // home chunk's 16 members, the previous best / second best when they live
+        // elsewhere and, before the first bid, the home chunk's sibling (a valid
+        // lower bound of the final second best).
         float tm;
         {
           float a1 = -1e9f, a2 = -1e9f;
-          const int s0 = c_start[c0], s1 = act ? c_start[c0 + 1] : s0;
-          // (the hint objects' load is issued first: it shares the round trip of the home cell's)
-          const bool hint = act && ((l16 == 0 && p1 >= 0) || (l16 == 1 && p2 >= 0));
-          float4 oh = make_float4(0.f, 0.f, 0.f, 0.f);
+          // (the hint objects' load is issued first: it shares the round trip of the home chunk's)
+          const bool hint = act && ((l16 == 0 && p1 >= 0 && (p1 >> 4) != hc) || (l16 == 1 && p2 >= 0 && (p2 >> 4) != hc));
+          const bool two = act && p1 < 0 && p2 < 0;   // row-uniform
+          float4 oh = make_float4(0.f, 0.f, 0.f, 0.f), o0 = oh, o1 = oh;
           if (hint) oh = ld_obj(l16 == 0 ? p1 : p2);
-          for (int s = s0 + l16; __any(s < s1); s += 16) {
-            if (s < s1) {
-              const float4 o = ld_obj(s);
-              top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
-            }
-          }
-          bool extra = false;
-          if (hint) {
-            const float4 o = oh;
-            if (emd_cell(gg, o.x, o.y, o.z) != c0) {
-              extra = true;
-              top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
-            }
-          }
-          const int have = (s1 - s0) + __builtin_popcountll((__ballot(extra) >> rsh) & 0xFFFFull);
-          if (__builtin_expect(act && have < 2, 0)) {  // row-uniform; rare: the first 16 slots (distinct objects)
-            const float4 o = ld_obj(l16);
-            a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
-            a2 = -1e9f;
-          }
+          if (act) o0 = ld_obj(hc * 16 + l16);
+          if (two) o1 = ld_obj((hc ^ 1) * 16 + l16);
+          if (act) top2_insert(a1, a2, emd_value(sqdist3(o0.x - qx, o0.y - qy, o0.z - qz), o0.w));
+          if (two) top2_insert(a1, a2, emd_value(sqdist3(o1.x - qx, o1.y - qy, o1.z - qz), o1.w));
+          if (hint) top2_insert(a1, a2, emd_value(sqdist3(oh.x - qx, oh.y - qy, oh.z - qz), oh.w));
           top2_dpp_step<0xB1, 0xF>(a1, a2);   // butterfly inside the row:
           top2_dpp_step<0x4E, 0xF>(a1, a2);   // every lane ends with the row's
           top2_dpp_step<0x141, 0xF>(a1, a2);  // (largest, second largest)
@@ -531,29 +478,16 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           }
         };
 
-        // (2) cells intersecting the cube |o - q|_inf <= tm (prices >= 0)
-        int ix0, iy0, iz0, nx, ny, nz;
-        {
-          const float r = tm * gg.invh + 1e-3f;  // slack covers index rounding
-          const float fx = (qx - gg.lox) * gg.invh;
-          const float fy = (qy - gg.loy) * gg.invh;
-          const float fz = (qz - gg.loz) * gg.invh;
-          const float gm = (float)(gg.g - 1);
-          ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
-          iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
-          iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
-          nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
-          ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
-          nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
+        // (2) the nodes, 16 per step: this row's passing nodes as a bit mask
+        unsigned long long nm = 0ull;
+        for (int nb = 0; nb < nnode; nb += 16) {
+          const bool np = act && emd_box_pass(n_lo[nb + l16], n_hi[nb + l16], qx, qy, qz, tm);
+          nm |= ((__ballot(np) >> rsh) & 0xFFFFull) << nb;
         }
-        const int nxy = nx * ny;
-        const int nsub_all = act ? nxy * nz : 0;
-        // approximate reciprocals suffice: (i + 0.5) / m is >= 0.5/144 away
-        // from an integer, far above the 1 ulp error of v_rcp_f32
-        const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
-        // search cube covers most of the grid (clustered prediction against a
-        // spread target): scan the cell-sorted objects linearly instead
-        const bool linear = act && 2 * nsub_all > ncell;
+        // most of the cloud within reach (clustered prediction against a spread
+        // target): scan the sorted objects linearly instead
+        const int npass = __builtin_popcountll(nm);
+        const bool linear = act && 2 * npass > nnode && npass > 8;
         if (__builtin_expect(__any(linear), 0)) {
           for (int base = 0; base < n; base += 64) {   // n % 1024 == 0
             float4 o[4];
@@ -564,92 +498,43 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             for (int r4 = 0; r4 < 4; ++r4) consider(linear, o[r4], base + r4 * 16 + l16);
           }
         }
-        const int nsub = linear ? 0 : nsub_all;
+        if (linear) nm = 0ull;
 
-        // (3) visit the listed cells of this row, 4 per step (16 lanes each)
+        // (4) visit the listed leaves of this row, 4 per step (16 lanes each)
         int nlist = 0;
         auto visit = [&]() {
           for (int k0 = 0; __any(k0 < nlist); k0 += 4) {
-            int s[4], s1[4];
+            int s[4];
+            bool in[4];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-              const int k = k0 + r4;
-              s[r4] = 0;
-              s1[r4] = 0;
-              if (k < nlist) {
-                const int cw = wl[k], cc = cw & 0x7FF, q = cw >> 11;   // cell, chunk of 16 members
-                const int m0 = c_start[cc] + 16 * q, m1 = c_start[cc + 1];
-                s[r4] = m0 + l16;
-                s1[r4] = q == 7 ? m1 : min(m1, m0 + 16);   // (here the eighth chunk stands for everything behind it)
-              }
+              in[r4] = k0 + r4 < nlist;
+              s[r4] = in[r4] ? ((int)wl[k0 + r4] << lshift) + l16 : 0;
             }
-            bool more = true;
-            while (more) {
+            for (int c = 0; c < kch; ++c) {   // (one chunk per leaf up to 16384 points)
               float4 o[4];
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4)
-                o[r4] = s[r4] < s1[r4] ? ld_obj(s[r4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                o[r4] = in[r4] ? ld_obj(s[r4] + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) consider(s[r4] < s1[r4], o[r4], s[r4]);
-              bool mine = false;   // cells with more than 16 members: next 16
-#pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) {
-                s[r4] += 16;
-                mine |= s[r4] < s1[r4];
-              }
-              more = __any(mine);
+              for (int r4 = 0; r4 < 4; ++r4) consider(in[r4], o[r4], s[r4] + 16 * c);
             }
           }
           nlist = 0;
         };
-        for (int cb = 0; __any(cb < nsub); cb += 16) {
-          const int i = cb + l16;
-          bool cpass = false;
-          int extra = 0;   // further chunks of 16 members (this schedule lists at most 8 per cell)
-          int c = 0;
-          if (i < nsub) {
-            // exact small-integer division via float (i < 1728, divisors <= 144)
-            const int kz = (int)(((float)i + 0.5f) * inv_nxy);
-            const int rem = i - kz * nxy;
-            const int ky = (int)(((float)rem + 0.5f) * inv_nx);
-            const int kx = rem - ky * nx;
-            c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
-            const float4 cl = c_lo[c], ch = c_hi[c];
-            extra = min(7, (int)ch.w);
-            const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
-            const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
-            const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
-            const float tq = tm - cl.w;
-            cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
+        // (3) the 16 leaves of every passing node, one node of this row per step
+        while (__any(nm != 0ull)) {
+          bool lp = false;
+          int leaf = 0;
+          if (nm != 0ull) {
+            leaf = (int)__builtin_ctzll(nm) * kNodeFan + l16;
+            nm &= nm - 1ull;
+            lp = emd_box_pass(l_lo[leaf], l_hi[leaf], qx, qy, qz, tm);
           }
-          // (a cell is listed once per chunk of 16 members, see the one-bidder-per-wave path; cells of more than 32
-          // members -- surface-shaped clouds -- get their further entries in the rare branch below)
-          extra = cpass ? extra : 0;
-          const bool big = extra >= 1, huge = extra >= 2;
-          const unsigned rmask = (unsigned)((__ballot(cpass) >> rsh) & 0xFFFFull);
-          const unsigned bmask = (unsigned)((__ballot(big) >> rsh) & 0xFFFFull);
-          if (cpass) {
-            const unsigned lt = (1u << l16) - 1u;
-            const int pos = nlist + __builtin_popcount(rmask & lt) + __builtin_popcount(bmask & lt);
-            wl[pos] = (unsigned short)c;
-            if (big) wl[pos + 1] = (unsigned short)(c | (1 << 11));
-          }
-          nlist += __builtin_popcount(rmask) + __builtin_popcount(bmask);
-          if (__builtin_expect(__any(huge), 0)) {
-            // further chunks 2 .. extra of this row's cells: positions by a prefix sum over the row's 16 lanes
-            const int cntx = huge ? extra - 1 : 0;   // <= 6 each, <= 96 per row
-            int incl = cntx;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-              const int up = __shfl_up(incl, off, 16);
-              if (l16 >= off) incl += up;
-            }
-            const int rowtot = __shfl(incl, 15, 16);
-            if (__any(nlist + rowtot > kRowListCap)) visit();
-            for (int q = 0; q < cntx; ++q) wl[nlist + incl - cntx + q] = (unsigned short)(c | ((q + 2) << 11));
-            nlist += rowtot;
-          }
-          if (__any(nlist > kRowListCap - 32)) visit();  // keep room for the next 16 cells' first two chunks
+          const unsigned rmask = (unsigned)((__ballot(lp) >> rsh) & 0xFFFFull);
+          if (lp) wl[nlist + __builtin_popcount(rmask & ((1u << l16) - 1u))] = (unsigned short)leaf;
+          nlist += __builtin_popcount(rmask);
+          if (__any(nlist > kRowListCap - 16)) visit();  // keep room for the next node's 16 leaves
         }
         visit();
 
@@ -725,211 +610,24 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       const long long tb0 = __builtin_readcyclecounter();
       int prof_cells = 0;
 #endif
-      const int c0 = emd_cell(gg, qx, qy, qz);
-
-      // (1) seed: second-largest exact value among DISTINCT real objects --
-      // the home cell's members plus the previous best / second best when
-      // they live elsewhere.  Two real objects reach it, so it is a valid
-      // lower bound of the final second-best value.
+      const int hc = __float_as_int(ra.w);   // home chunk (emd_index.h)
       BidState st;
-      {
-        float a1 = -1e9f, a2 = -1e9f;
-        const int s0 = c_start[c0], s1 = c_start[c0 + 1];
-        // (the hint objects' load is issued first: it shares the round trip of the home cell's)
-        const bool hint = (lane == 0 && p1 >= 0) || (lane == 1 && p2 >= 0);
-        float4 oh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (hint) oh = ld_obj(lane == 0 ? p1 : p2);
-        for (int s = s0 + lane; s < s1; s += kWave) {
-          const float4 o = ld_obj(s);
-          top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
-        }
-        bool extra = false;
-        if (hint) {
-          const float4 o = oh;
-          if (emd_cell(gg, o.x, o.y, o.z) != c0) {
-            extra = true;
-            top2_insert(a1, a2, emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w));
-          }
-        }
-        const int have = (s1 - s0) + __builtin_popcountll(__ballot(extra));
-        if (__builtin_expect(have < 2, 0)) {  // wave-uniform; rare: fall back to the first 64 slots
-          const float4 o = ld_obj(lane);
-          a1 = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
-          a2 = -1e9f;
-        }
-        st.b1 = -1e9f;
-        st.b2 = -1e9f;
-        st.bk = -1;
-        st.b2k = -1;
-        const float seed_b2 = wave_second_largest(a1, a2);
-        st.tm = (3.0f - seed_b2) + kMargin;
-      }
+      st.b1 = -1e9f;
+      st.b2 = -1e9f;
+      st.bk = -1;
+      st.b2k = -1;
+      unsigned short *wl = w_list[wave];
+      int nsub = 0;          // leaves tested (statistics)
 #ifdef MVP_EMD_PROFILE
-      const long long tb1 = __builtin_readcyclecounter();
+      long long tb1 = tb0;
+      float prof_tm_seed = 0.f;
       long long t_visit = 0;
       int n_visit = 0, prof_fold = 0, prof_more = 0;
 #endif
-
-      // (2) Only cells that intersect the cube |o - q|_inf <= tm can hold a
-      // relevant object (prices are >= 0).  Enumerate that sub-box of the
-      // grid 64 cells at a time and test each cell's exact bounding box and
-      // price lower bound; (3) visit the survivors, 4 cells per step with 16
-      // lanes each.
-      int ix0, iy0, iz0, nx, ny, nz;
-      {
-        const float r = st.tm * gg.invh + 1e-3f;  // slack covers index rounding
-        const float fx = (qx - gg.lox) * gg.invh;
-        const float fy = (qy - gg.loy) * gg.invh;
-        const float fz = (qz - gg.loz) * gg.invh;
-        const float gm = (float)(gg.g - 1);
-        ix0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx - r), 0.f), gm);
-        iy0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy - r), 0.f), gm);
-        iz0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz - r), 0.f), gm);
-        nx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fx + r), 0.f), gm) - ix0 + 1;
-        ny = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fy + r), 0.f), gm) - iy0 + 1;
-        nz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(fz + r), 0.f), gm) - iz0 + 1;
-        ix0 = __builtin_amdgcn_readfirstlane(ix0);
-        iy0 = __builtin_amdgcn_readfirstlane(iy0);
-        iz0 = __builtin_amdgcn_readfirstlane(iz0);
-        nx = __builtin_amdgcn_readfirstlane(nx);
-        ny = __builtin_amdgcn_readfirstlane(ny);
-        nz = __builtin_amdgcn_readfirstlane(nz);
-      }
-      const int nxy = nx * ny;
-      const int nsub = nxy * nz;
-      // approximate reciprocals are enough: (i + 0.5) / m is >= 0.5/144 away
-      // from an integer, far above the 1 ulp error of v_rcp_f32
-      const float inv_nxy = __builtin_amdgcn_rcpf((float)nxy), inv_nx = __builtin_amdgcn_rcpf((float)nx);
-      const int sub = lane >> 4, sl = lane & 15;
-      unsigned short *wl = w_list[wave];
-      int nlist = 0;
-      // (3) visit listed cells, 16 per step: each 16-lane row takes 4 cells
-      // (a cell holds ~10 objects), so 4 independent 16-byte loads per lane are
-      // in flight at once and a typical bid (~10 surviving cells) needs ONE
-      // dependent memory round trip here.
-      auto visit = [&]() {
-#ifdef MVP_EMD_PROFILE
-        const long long tv0 = __builtin_readcyclecounter();
-        n_visit += (nlist + 15) / 16;
-#endif
-        for (int k0 = 0; k0 < nlist; k0 += 16) {
-          int s[4], s1[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int k = k0 + r * 4 + sub;
-            s[r] = 0;
-            s1[r] = 0;
-            if (k < nlist) {
-              const int cw = wl[k], cc = cw & 0x7FF, q = cw >> 11;   // cell, chunk of 16 members
-              const int m0 = c_start[cc] + 16 * q, m1 = c_start[cc + 1];
-              s[r] = m0 + sl;
-              s1[r] = q == 31 ? m1 : min(m1, m0 + 16);   // (chunk 31 stands for everything behind it: cells of > 512 members)
-            }
-          }
-          bool more = true;
-          while (more) {  // (a second pass only for cells of more than 32 members)
-            float4 o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              o[r] = s[r] < s1[r] ? ld_obj(s[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
-              const float tq = st.tm - o[r].w;
-              const bool ps = s[r] < s1[r] && tq >= 0.f && sd <= tq * tq;
-              const unsigned long long m = __ballot(ps);
-#ifdef MVP_EMD_PROFILE
-              prof_fold += __builtin_popcountll(m);
-#endif
-              if (m) emd_fold(st, m, emd_value(sd, o[r].w), s[r], n, tpu, sc.perm);
-            }
-            // cells with more than 16 members (rare): next 16
-            bool mine = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              s[r] += 16;
-              mine |= s[r] < s1[r];
-            }
-            more = __builtin_expect(__any(mine), 0);
-#ifdef MVP_EMD_PROFILE
-            prof_more += more ? 1 : 0;
-#endif
-          }
-        }
-        nlist = 0;
-#ifdef MVP_EMD_PROFILE
-        t_visit += __builtin_readcyclecounter() - tv0;
-#endif
-      };
-      // When the search cube covers most of the grid (high prices everywhere,
-      // e.g. a clustered prediction against a spread target) the cell
-      // machinery only adds overhead: scan the cell-sorted objects linearly,
-      // 4 x 64 per step, with the same lossless filter.
-      const bool linear = 2 * nsub > ncell;
-      if (__builtin_expect(linear, 0)) {
-        for (int base = 0; base < n; base += 4 * kWave) {
-          float4 o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = ld_obj(base + r * kWave + lane);  // n % 1024 == 0
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sd = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
-            const float tq = st.tm - o[r].w;
-            const bool ps = tq >= 0.f && sd <= tq * tq;
-            const unsigned long long m = __ballot(ps);
-            if (m) emd_fold(st, m, emd_value(sd, o[r].w), base + r * kWave + lane, n, tpu, sc.perm);
-          }
-        }
-      }
-      for (int cb = 0; cb < (linear ? 0 : nsub); cb += kWave) {
-        const int i = cb + lane;
-        bool cpass = false;
-        int extra = 0;
-        int c = 0;
-        if (i < nsub) {
-          // exact small-integer division via float (i < 1728, divisors <= 144)
-          const int kz = (int)(((float)i + 0.5f) * inv_nxy);
-          const int rem = i - kz * nxy;
-          const int ky = (int)(((float)rem + 0.5f) * inv_nx);
-          const int kx = rem - ky * nx;
-          c = ((iz0 + kz) * gg.g + (iy0 + ky)) * gg.g + (ix0 + kx);
-          const float4 cl = c_lo[c], ch = c_hi[c];
-          const float dx = __builtin_fmaxf(__builtin_fmaxf(cl.x - qx, qx - ch.x), 0.f);
-          const float dy = __builtin_fmaxf(__builtin_fmaxf(cl.y - qy, qy - ch.y), 0.f);
-          const float dz = __builtin_fmaxf(__builtin_fmaxf(cl.z - qz, qz - ch.z), 0.f);
-          const float tq = st.tm - cl.w;
-          cpass = tq >= 0.f && sqdist3(dx, dy, dz) <= tq * tq;  // empty cell: inf
-          extra = cpass ? (int)ch.w : 0;
-        }
-        // A cell is listed once per chunk of 16 members: they all travel in the round trips of the visit
-        // steps, 16 chunks per step, instead of in dependent passes of 16 members each (cells of 17..32
-        // members: 12 % of the cells of a uniform cloud, i.e. two of three bids; surface-shaped clouds hold
-        // 30-200 objects per occupied cell).  The first two chunks are placed by the lanes themselves, cells
-        // of more than 32 members are taken one by one.
-        const bool big = extra >= 1, huge = extra >= 2;
-        const unsigned long long cmask = __ballot(cpass), bmask = __ballot(big);
-        unsigned long long hmask = __ballot(huge);
-        if (cpass) {
-          const unsigned long long lt = (1ull << lane) - 1ull;
-          const int pos = nlist + __builtin_popcountll(cmask & lt) + __builtin_popcountll(bmask & lt);
-          wl[pos] = (unsigned short)c;
-          if (big) wl[pos + 1] = (unsigned short)(c | (1 << 11));
-        }
-        nlist += __builtin_popcountll(cmask) + __builtin_popcountll(bmask);
-        while (__builtin_expect(hmask != 0ull, 0)) {
-          const int l = (int)__builtin_ctzll(hmask);
-          hmask &= hmask - 1ull;
-          const int cc = __builtin_amdgcn_readlane(c, l), ne = __builtin_amdgcn_readlane(extra, l) - 1;   // chunks 2 .. extra
-          if (nlist + ne > 4 * kRowListCap) visit();
-          if (lane < ne) wl[nlist + lane] = (unsigned short)(cc | ((lane + 2) << 11));
-          nlist += ne;
-        }
-#ifdef MVP_EMD_PROFILE
-        prof_cells += __builtin_popcountll(cmask);
-#endif
-        if (nlist > (4 * kRowListCap) - 2 * kWave) visit();  // keep room for the next 64 cells' first two chunks
-      }
-      visit();
+#define EMD_SEARCH_FOLD(m_, v_, slot_, price_) emd_fold(st, m_, v_, slot_, n, tpu, sc.perm)
+#include "emd_search_wave.inc"
+#undef EMD_SEARCH_FOLD
+      (void)nsub;
 #ifdef MVP_EMD_PROFILE
       if (lane == 0 && it >= 100) {
         const long long d = __builtin_readcyclecounter() - tb0;
@@ -984,7 +682,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       if (chg_have) {
         const int pmb = (int)(unsigned)chg_pend;
         if (pmb >= 0)  // bits of a non-negative float order like ints
-          atomicMax(reinterpret_cast<int *>(&c_lo[(int)(chg_pend >> 32)].w), pmb);
+          atomicMax(reinterpret_cast<int *>(&l_lo[(int)(chg_pend >> 32)].w), pmb);
         chg_have = false;
       }
     }
@@ -1103,23 +801,23 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         st_ostate(o, j);
         st_i32(&ass[j], o);
         st_f32(&sc.obj[o].w, oo.w + bi);
-        // The cell's price lower bound only needs a refresh when the object
-        // that just got dearer was (one of) the cheapest of its cell; then the
+        // The leaf's price lower bound only needs a refresh when the object
+        // that just got dearer was (one of) the cheapest of its leaf; then the
         // members are re-scanned (prices read while other winners raise them
         // are old or new -- either way a valid bound) and the new bound is
         // broadcast to the other workgroups of the cluster.
-        const int c = emd_cell(gg, oo.x, oo.y, oo.z);
-        if (oo.w <= c_lo[c].w) {
+        const int c = o >> lshift;
+        if (oo.w <= l_lo[c].w) {
           float pm = oo.w + bi;
-          const int e0 = c_start[c], e1 = c_start[c + 1];
-          // (the first 16 members in ONE round trip: 88 % of the cells have no more)
+          const int e0 = c << lshift, e1 = e0 + (1 << lshift);
+          // (the first 16 members in ONE round trip: all of them up to 16384 points)
           float pv[16];
 #pragma unroll
-          for (int k = 0; k < 16; ++k) pv[k] = (e0 + k < e1 && e0 + k != o) ? ld_price(e0 + k) : __builtin_inff();
+          for (int k = 0; k < 16; ++k) pv[k] = e0 + k != o ? ld_price(e0 + k) : __builtin_inff();
 #pragma unroll
           for (int k = 0; k < 16; ++k) pm = __builtin_fminf(pm, pv[k]);
           for (int s = e0 + 16; s < e1; ++s) pm = __builtin_fminf(pm, s == o ? pm : ld_price(s));
-          c_lo[c].w = pm;
+          l_lo[c].w = pm;
 #ifdef MVP_EMD_PROFILE
           if (it >= 100) atomicAdd(&s_hist2[0], 1ull << 40);  // refresh count in the high bits
 #endif
@@ -1150,6 +848,8 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       if (t == 0 && it >= 100) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); prof_a3 += __builtin_readcyclecounter() - ta0; }
 #endif
     }
+    // the nodes' price bounds follow their leaves' (LDS only; a bound that lags a round is still a bound)
+    if (t >= kEmdThreads - kMaxNodes) emd_node_price(l_lo, n_lo, t - (kEmdThreads - kMaxNodes), nleaf);
 #ifdef MVP_EMD_PROFILE
     const long long tp3 = __builtin_readcyclecounter();
     if (t == 0 && it >= 100) prof_a4 += tp3 - tp2;
@@ -1308,10 +1008,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
       } else if (__builtin_expect(overflow, 0)) {
         // too many refreshes to broadcast (the first, heavy rounds): recompute
         // every bound from the prices themselves (stable between barriers)
-        for (int c = t; c < ncell; c += kEmdThreads) {
+        for (int c = t; c < nleaf; c += kEmdThreads) {
           float pm = __builtin_inff();
-          for (int s = c_start[c]; s < c_start[c + 1]; ++s) pm = __builtin_fminf(pm, ld_obj(s).w);
-          if (pm >= c_lo[c].w) c_lo[c].w = pm;
+          for (int s = c << lshift; s < ((c + 1) << lshift); ++s) pm = __builtin_fminf(pm, ld_obj(s).w);
+          if (pm >= l_lo[c].w) l_lo[c].w = pm;
         }
       } else {
         // Fetch the other workgroups' refreshed bounds now, fold them in after
@@ -1344,7 +1044,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
               const u64 e = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               const int pmb = (int)(unsigned)e;
               if (pmb >= 0)  // bits of a non-negative float order like ints
-                atomicMax(reinterpret_cast<int *>(&c_lo[(int)(e >> 32)].w), pmb);
+                atomicMax(reinterpret_cast<int *>(&l_lo[(int)(e >> 32)].w), pmb);
             }
           }
           chg_have = false;

@@ -12,15 +12,14 @@ namespace mvp {
 
 constexpr int kEmdThreads = 1024;
 constexpr int kEmdWaves = kEmdThreads / kWave;
-constexpr int kMaxG = 12;
-constexpr int kMaxCells = kMaxG * kMaxG * kMaxG;  // 1728
+constexpr int kIndexReserve = 1728;  // ints of per-cloud scratch the grid of rounds 1-5 kept its cell offsets in (the size formula of the scratch stays)
 constexpr int kBidCache = 1024;  // list positions whose bid is cached in LDS
 constexpr int kRecCap = 512;     // list positions whose person record is cached in LDS
 #ifndef MVP_EMD_ROWMIN
 #define MVP_EMD_ROWMIN 96
 #endif
 constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 bidders share a wave
-constexpr int kRowListCap = 128; // per-row (bidder) surviving-cell list, flushed when full
+constexpr int kRowListCap = 128; // per-row (bidder) list of surviving leaves, flushed when full
 constexpr int kMaxCluster = 8;   // workgroups per cloud (W)
 constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broadcast per round
 #ifndef MVP_EMD_SOLO
@@ -65,20 +64,21 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 // Per-person record (32 B): two 16-byte halves.
-//   lo = {qx, qy, qz, -}                         the person's point (xyz1)
+//   lo = {qx, qy, qz, bits(home chunk)}          the person's point (xyz1); the 16-slot chunk of the sorted objects
+//                                                its Hilbert key falls into (emd_index.h: a seed of every search)
 //   hi = {bid, prev1, prev2, bits(bidinc)}       slot it last bid on, best /
 //        second-best slot of that bid (seed hints), increment of that bid
 // Per-object auction state (16 B), next to the object's float4 {x,y,z,price}:
 //   {key lo, key hi, owner (-1 = free), -}
 //   key = ord(max bid increment this round) << 32 | (winning bidder + 1); 0 = no bid
 struct EmdScratch {
-  float4 *obj;     // (n) cell-sorted x, y, z, price of xyz2
+  float4 *obj;     // (n) Hilbert-sorted x, y, z, price of xyz2
   int4 *ostate;    // (n) per slot
   float4 *person;  // (2n) per person: lo, hi
   int *perm;       // (n) slot -> original object index
   int *ulist;      // (W x 2n) ping-pong unassigned lists, one pair per workgroup
-  u64 *chg;        // (W x kChgCap) {cell, bits(price bound)} broadcast per round
-  int *cstart;     // (kMaxCells + 4) cell offsets of the cell-sorted order (for the lean kernel)
+  u64 *chg;        // (W x kChgCap) {leaf, bits(price bound)} broadcast per round
+  int *reserved;   // (kIndexReserve + 4 ints: unused since the leaf index, emd_index.h)
 };
 
 // Hand-over record of a cloud (first kernel -> lean kernel), after the barrier granules.
@@ -87,8 +87,7 @@ struct EmdScratch {
 struct EmdHandover {
   int next_it;     // first round the lean kernel runs
   int utot;        // persons still unassigned
-  int g;           // grid geometry (same arithmetic in both kernels)
-  float lox, loy, loz, invh;
+  int unused_[5];  // (the grid geometry of rounds 1-5; the leaf index is a function of n alone: emd_index.h)
   int err;         // the first kernel's internal-error flag
   int cnt[kMaxCluster];   // entries of each member's list
   int nlists;      // members that left a list (the cluster width of the kernel that wrote the record)
@@ -101,8 +100,8 @@ struct EmdHandover {
 static_assert(sizeof(EmdHandover) % 16 == 0, "the scratch tail stays 16-byte granular");
 
 __host__ __device__ inline size_t emd_scratch_per_cloud(int n) {
-  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg + cstart
-  return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8 + (size_t)(kMaxCells + 4) * 4;
+  // obj 16 + ostate 16 + person 32 + perm 4 + lists 8 x kMaxCluster, + chg + reserve
+  return (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8 + (size_t)(kIndexReserve + 4) * 4;
 }
 // After the per-cloud areas ("tail" of the scratch buffer, zeroed by the host
 // before the launch): 256 B of barrier granules per cloud for the first
@@ -132,7 +131,7 @@ __device__ __forceinline__ EmdScratch emd_carve(char *base, int n) {
   s.perm = reinterpret_cast<int *>(base + (size_t)n * 64);
   s.ulist = reinterpret_cast<int *>(base + (size_t)n * 68);
   s.chg = reinterpret_cast<u64 *>(base + (size_t)n * (68 + 8 * kMaxCluster));
-  s.cstart = reinterpret_cast<int *>(base + (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8);
+  s.reserved = reinterpret_cast<int *>(base + (size_t)n * (68 + 8 * kMaxCluster) + (size_t)kMaxCluster * kChgCap * 8);
   return s;
 }
 
@@ -210,16 +209,15 @@ struct BidState {
   int bk, b2k;   // their slots (b2k is only a seed hint)
   float tm;      // filter threshold: <= fl(fl(3 - b2) + kMargin)
   float bp;      // (emd_fold<true> only) price of the best object as the search read it
-  int bc;        // (emd_fold<true> only) the list word of the cell it was found in
 };
 
 // Fold the candidates flagged in `mask` (exact value v and slot k per lane)
 // into the uniform state, lowest lane first.
-// PC: the best object's price `pw` and cell word `cw` (per lane, like v and k) are carried along (st.bp, st.bc).
+// PC: the best object's price `pw` (per lane, like v and k) is carried along (st.bp).
 template <bool PC = false>
 __device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
                                          float v, int k, int n, int tpu,
-                                         const int *__restrict__ perm, float pw = 0.f, int cw = 0) {
+                                         const int *__restrict__ perm, float pw = 0.f) {
   while (mask) {
     const int l = __builtin_ctzll(mask);
     mask &= mask - 1;
@@ -231,19 +229,13 @@ __device__ __forceinline__ void emd_fold(BidState &st, unsigned long long mask,
       st.b2k = st.bk;
       st.b1 = vl;
       st.bk = kl;
-      if constexpr (PC) {
-        st.bp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw), l));
-        st.bc = __builtin_amdgcn_readlane(cw, l);
-      }
+      if constexpr (PC) st.bp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw), l));
     } else if (__builtin_expect(vl == st.b1, 0)) {
       st.b2 = st.b1;
       if (emd_precedes(perm[kl], perm[st.bk], n, tpu)) {
         st.b2k = st.bk;
         st.bk = kl;
-        if constexpr (PC) {
-          st.bp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw), l));
-          st.bc = __builtin_amdgcn_readlane(cw, l);
-        }
+        if constexpr (PC) st.bp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw), l));
       } else {
         st.b2k = kl;
       }
@@ -335,19 +327,6 @@ __device__ __forceinline__ float emd_wave_second(float v) {
   const float t1 = emd_wave_max(v);
   const int l1 = (int)__builtin_ctzll(__ballot(v == t1));
   return emd_wave_max((int)(threadIdx.x & 63) == l1 ? -1e9f : v);
-}
-
-struct GridGeom {
-  float lox, loy, loz, invh;
-  int g;
-};
-
-__device__ __forceinline__ int emd_cell(const GridGeom &gg, float x, float y,
-                                        float z) {
-  const int ix = min(gg.g - 1, max(0, (int)((x - gg.lox) * gg.invh)));
-  const int iy = min(gg.g - 1, max(0, (int)((y - gg.loy) * gg.invh)));
-  const int iz = min(gg.g - 1, max(0, (int)((z - gg.loz) * gg.invh)));
-  return (iz * gg.g + iy) * gg.g + ix;
 }
 
 // All-gather of two 32-bit payloads among the W workgroups of a cluster; also

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "emd_common.h"
+#include "emd_index.h"
 #include "emd_resident.h"
 
 namespace mvp {
@@ -40,13 +41,13 @@ hipError_t emd_resident_launch(int b, int n, float *dist, int *assignment, float
 struct LeanShared {
   // (order: what the round loop addresses with an immediate offset comes first -- a DS instruction's
   // offset field covers 64 KB)
-  float4 c_lo[kMaxCells], c_hi[kMaxCells];
+  float4 l_lo[kMaxLeaves], l_hi[kMaxLeaves];   // the leaves' boxes + price bounds (emd_index.h)
+  float4 n_lo[kMaxNodes], n_hi[kMaxNodes];     // the nodes'
   int s_cnt[2];
   int s_next;
   int s_err, s_abort, s_nchg, s_xcc;
   int s_alarm[2];
   unsigned s_gout[2 * kMaxCluster];
-  int c_start[kMaxCells + 1];
   int s_bj[kLeanBid], s_bo[kLeanBid], s_b2k[kLeanBid];
   float s_binc[kLeanBid];
   int s_own_chg[kLeanBid];
@@ -60,7 +61,7 @@ struct LeanShared {
   unsigned short s_owner[kGMaxN];     // object slot -> person (0xFFFF: free)
   unsigned short s_go[kGCap], s_gj[kGCap];   // the round's bids by position in the cloud-wide order: object, bidder
   float s_ginc[kGCap];                //   ... increment
-  unsigned short s_won[2][kGCap];     // cells of the objects won this round (their price bound is re-scanned)
+  unsigned short s_won[2][kGCap];     // leaves of the objects won this round (their price bound is re-scanned)
   int s_nwon[2];
   int s_pub;                          // bids this member has published this round
   int s_gc[3][kMaxCluster];           // every member's list length: current round / next / (being zeroed)
@@ -183,9 +184,8 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   };
 
 
-  auto &c_lo = sh.c_lo; auto &c_hi = sh.c_hi;
-  auto &c_start = sh.c_start;
-  auto &w_list = sh.w_list;  // surviving cells of a wave's search
+  auto &l_lo = sh.l_lo; auto &l_hi = sh.l_hi; auto &n_lo = sh.n_lo; auto &n_hi = sh.n_hi;
+  auto &w_list = sh.w_list;  // surviving leaves of a wave's search
   auto &s_cnt = sh.s_cnt;
   auto &s_next = sh.s_next;             // next undrawn list position of the round
   auto &s_err = sh.s_err; auto &s_abort = sh.s_abort; auto &s_nchg = sh.s_nchg; auto &s_xcc = sh.s_xcc;
@@ -205,7 +205,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   // this round's bids, by list position
   auto &s_bj = sh.s_bj; auto &s_bo = sh.s_bo; auto &s_b2k = sh.s_b2k;
   auto &s_binc = sh.s_binc;
-  auto &s_own_chg = sh.s_own_chg;   // cells whose cheapest member this workgroup's winners made dearer this round
+  auto &s_own_chg = sh.s_own_chg;   // leaves whose cheapest member this workgroup's winners made dearer this round
   // person records {qx,qy,qz,-} / {j, prev1, prev2, -} of the current / next unassigned list
   auto &s_rq = sh.s_rq;
   auto &s_ri = sh.s_ri;
@@ -223,14 +223,8 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   u64 *const bid_area = emd_bid_area(tail, b, cloud);
 
   // ------------------------------------------------------------ resume
-  GridGeom gg;
-  gg.g = resume->g;
-  gg.lox = resume->lox;
-  gg.loy = resume->loy;
-  gg.loz = resume->loz;
-  gg.invh = resume->invh;
-  const int ncell = gg.g * gg.g * gg.g;
-  for (int c = t; c <= ncell; c += kEmdThreads) c_start[c] = sc.cstart[c];
+  const int lshift = emd_leaf_shift(n), nleaf = n >> lshift, nnode = (nleaf + kNodeFan - 1) / kNodeFan;
+  const int kch = 1 << (lshift - 4);   // 16-slot chunks per leaf
   if (t == 0) {
     s_err = resume->err;
     s_abort = 0;
@@ -239,25 +233,8 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     s_next = kEmdWaves;
     s_nchg = 0;
   }
-  __syncthreads();
-  // exact bounding box and exact price lower bound per cell
-  for (int c = t; c < ncell; c += kEmdThreads) {
-    float bx0 = __builtin_inff(), by0 = __builtin_inff(), bz0 = __builtin_inff(), pm = __builtin_inff();
-    float bx1 = -__builtin_inff(), by1 = -__builtin_inff(), bz1 = -__builtin_inff();
-    for (int s = c_start[c]; s < c_start[c + 1]; ++s) {
-      const float4 o = sc.obj[s];
-      bx0 = __builtin_fminf(bx0, o.x);
-      by0 = __builtin_fminf(by0, o.y);
-      bz0 = __builtin_fminf(bz0, o.z);
-      bx1 = __builtin_fmaxf(bx1, o.x);
-      by1 = __builtin_fmaxf(by1, o.y);
-      bz1 = __builtin_fmaxf(bz1, o.z);
-      pm = __builtin_fminf(pm, o.w);
-    }
-    c_lo[c] = make_float4(bx0, by0, bz0, c_start[c + 1] > c_start[c] ? pm : 0.f);
-    // .w: the cell's members in chunks of 16, minus one, at most 31 (a search lists a cell once per chunk)
-    c_hi[c] = make_float4(bx1, by1, bz1, (float)min(31, max(0, c_start[c + 1] - c_start[c] - 1) >> 4));
-  }
+  // exact bounding box and exact price lower bound per leaf and node (ends with a barrier)
+  emd_index_boxes(l_lo, l_hi, n_lo, n_hi, sc.obj, n, lshift);
   // this member's unassigned list, as the first kernel left it
   int *my_ulist = sc.ulist + (size_t)wg * 2 * n;
   {
