@@ -484,21 +484,10 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
           const bool np = act && emd_box_pass(n_lo[nb + l16], n_hi[nb + l16], qx, qy, qz, tm);
           nm |= ((__ballot(np) >> rsh) & 0xFFFFull) << nb;
         }
-        // most of the cloud within reach (clustered prediction against a spread
-        // target): scan the sorted objects linearly instead
-        const int npass = __builtin_popcountll(nm);
-        const bool linear = act && 2 * npass > nnode && npass > 8;
-        if (__builtin_expect(__any(linear), 0)) {
-          for (int base = 0; base < n; base += 64) {   // n % 1024 == 0
-            float4 o[4];
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-              o[r4] = linear ? ld_obj(base + r4 * 16 + l16) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) consider(linear, o[r4], base + r4 * 16 + l16);
-          }
-        }
-        if (linear) nm = 0ull;
+        // the whole cloud within reach (clustered prediction against a spread target): every node passes AND so do
+        // all 16 leaves of the row's first step -> the sorted objects are scanned linearly instead (below)
+        bool all_near = act && __builtin_popcountll(nm) >= nnode;
+        bool linear = false;
 
         // (4) visit the listed leaves of this row, 4 per step (16 lanes each)
         int nlist = 0;
@@ -532,11 +521,28 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
             lp = emd_box_pass(l_lo[leaf], l_hi[leaf], qx, qy, qz, tm);
           }
           const unsigned rmask = (unsigned)((__ballot(lp) >> rsh) & 0xFFFFull);
-          if (lp) wl[nlist + __builtin_popcount(rmask & ((1u << l16) - 1u))] = (unsigned short)leaf;
-          nlist += __builtin_popcount(rmask);
+          if (__builtin_expect(all_near && rmask == 0xFFFFu, 0)) {   // (row-uniform; only ever in the first step)
+            linear = true;
+            nm = 0ull;
+            lp = false;
+          }
+          all_near = false;
+          const unsigned amask = linear ? 0u : rmask;
+          if (lp) wl[nlist + __builtin_popcount(amask & ((1u << l16) - 1u))] = (unsigned short)leaf;
+          nlist += __builtin_popcount(amask);
           if (__any(nlist > kRowListCap - 16)) visit();  // keep room for the next node's 16 leaves
         }
         visit();
+        if (__builtin_expect(__any(linear), 0)) {
+          for (int base = 0; base < n; base += 64) {   // n % 1024 == 0
+            float4 o[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              o[r4] = linear ? ld_obj(base + r4 * 16 + l16) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) consider(linear, o[r4], base + r4 * 16 + l16);
+          }
+        }
 
         // (4) merge the 16 lanes of the row: exact best / second best with the
         // reference's tie order (original object indices ride along)
