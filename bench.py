@@ -341,6 +341,101 @@ def side_measurements(args, dev, g, emd_mod, furthest_point_sample, gather_point
     return out
 
 
+def model_level_measurements(args, dev, with_reference):
+    """BASELINE cfgs 3 and 2 in front of the driver, rank 0, AFTER the timed region, 5 timed steps each:
+      vrcnet_train_ms  cfg 3's per-rank step (completion/train.py:122-142: forward, CD losses + KLD, backward, fused Adam),
+                       32 clouds of 2048 points, cfgs/vrcnet.yaml, random weights;
+      pcn_eval_ms      cfg 2's eval step (completion/models/pcn.py:105-112 + model_utils.calc_emd): PCN forward 2048 ->
+                       16384 + CD / F1 of its output + EMD (eps 0.004, 3000 rounds) -- the EMD on gt + noise 0.03 of a
+                       chair-like surface, what a TRAINED network's output looks like next to its target (a random-init PCN
+                       emits one blob: bench.py --workload pcn_eval).
+    with_reference (oracle/_ref travelled; the baseline leg, tests/report_reference_model_step.py's method): the same steps in
+    the reference's formulation on the reference's own operator kernels compiled for this GPU."""
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, "completion"))
+    import model_utils as mu
+    import op_config
+    import train
+    import mvp_benchmark_amd.pointwise as pw
+    from mvp_benchmark_amd.synthetic import prediction_pair
+    out = {}
+
+    def timed(fn, warm, reps=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    g = torch.Generator().manual_seed(4242)
+    gt2k = torch.rand(32, 2048, 3, generator=g).to(dev)
+    part2k = torch.rand(32, 2048, 3, generator=g).to(dev).transpose(2, 1).contiguous()
+    surf_pred, surf_gt = [t.to(dev) for t in prediction_pair("chair", "0.03", g, 32, args.points)]
+    part16 = torch.rand(32, 3, 2048, generator=g).to(dev)
+
+    def vrcnet_step_fn(fused, switches=None):
+        cfg = train.load_config(os.path.join(ROOT, "completion", "cfgs", "vrcnet.yaml"))   # (sets the op-layer switches)
+        cfg.load_model = None
+        if switches:
+            op_config.configure(**switches)
+        torch.manual_seed(0)
+        net = importlib.import_module("models.vrcnet").Model(cfg).to(dev).train()
+        opt = torch.optim.Adam(net.parameters(), lr=cfg.lr, betas=(0.9, 0.999), fused=fused)
+
+        def step():
+            opt.zero_grad()
+            _, _, loss = net(part2k, gt2k, alpha=0.5)
+            loss.mean().backward()
+            opt.step()
+        return step
+
+    def pcn_step_fn(switches=None):
+        cfg = train.load_config(os.path.join(ROOT, "completion", "cfgs", "pcn_eval16k.yaml"))
+        cfg.eval_emd = False
+        if switches:
+            op_config.configure(**switches)
+        torch.manual_seed(1)
+        net = importlib.import_module("models.pcn").Model(cfg).to(dev).eval()
+
+        def step():
+            with torch.no_grad():
+                net(part16, surf_gt, prefix="val")                                      # forward + calc_cd(out2, gt, calc_f1=True)
+                mu.calc_emd(surf_pred, surf_gt, eps=args.eps, iterations=args.iters)
+        return step
+
+    out["vrcnet_train_ms"] = timed(vrcnet_step_fn(True), 2)
+    out["vrcnet_train_samples_per_s"] = 32e3 / out["vrcnet_train_ms"]
+    out["pcn_eval_ms"] = timed(pcn_step_fn(), 1)
+    out["pcn_eval_clouds_per_s"] = 32e3 / out["pcn_eval_ms"]
+    mu.check_emd_status()
+    out["model_level_note"] = ("5 timed steps each after the timed region; vrcnet: 32 x 2048 points per rank, fused Adam; pcn_eval: 32 clouds, "
+                               "forward 2048 -> %d + CD/F1 of the output + EMD eps %g x %d on chair gt + noise 0.03" % (args.points, args.eps, args.iters))
+    if with_reference:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import ref_ops                      # the reference's own kernels behind the operator API (test infrastructure)
+            from models import _common, ecg, edge_unet, pcn, relational, vrcnet
+            off = dict(gather_sum=0, gather_max=0, side_lanes=0, stacked_projections=0, skip_full_fps_of_gt=0,
+                       conv_before_interp=0, folded_conv=0)
+            pw.MFMA_TRAIN = pw.USE_MFMA = False
+            undo = ref_ops.patch_ops([mu, _common, relational, edge_unet, ecg, vrcnet, pcn])
+            ref_ops.ref.SYNC = False            # like the reference's wrappers: no host synchronisation per operator
+            try:
+                out["vrcnet_train_reference_kernels_ms"] = timed(vrcnet_step_fn(False, off), 1, reps=3)
+                out["pcn_eval_reference_kernels_ms"] = timed(pcn_step_fn(off), 1, reps=2)
+            finally:
+                ref_ops.ref.SYNC = True
+                undo()
+                op_config.OPS.reset()
+                pw.MFMA_TRAIN = pw.USE_MFMA = True
+        except Exception as exc:   # (the baseline must never cost the measurement)
+            out["model_level_reference_error"] = repr(exc)[:200]
+    return out
+
+
 def run_eval(args, rank, world, dev):
     from mvp_benchmark_amd.metrics import cd, emd, fscore
     from mvp_benchmark_amd.mm3d_pn2 import furthest_point_sample, gather_points
@@ -470,6 +565,16 @@ def run_eval(args, rank, world, dev):
         line["cpu_baseline"] = cpu_baseline(args, n)
         line["cpu_baseline_reference_path"] = cpu_reference_path(n)
         line["gpu_reference_baseline"] = gpu_reference_baseline(args, pred, gt, cd_ms, emd_ms)
+    if world == 1 and not args.no_side:
+        # cfg 3's per-rank train step and cfg 2's eval step (after everything timed above; the reference-kernel leg only
+        # with the baselines)
+        ref_ok = not args.no_cpu_baseline and isinstance(line.get("gpu_reference_baseline"), dict) and "error" not in line["gpu_reference_baseline"]
+        del pred, gt
+        torch.cuda.empty_cache()
+        try:
+            line["extra"].update(model_level_measurements(args, dev, ref_ok))
+        except Exception as exc:
+            line["extra"]["model_level_error"] = repr(exc)[:300]
     return line
 
 

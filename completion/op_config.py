@@ -50,5 +50,6 @@ def configure(**switches):
 def configure_from_cfg(args):
     """cfg key `op_layer: {switch: value, ...}` (optional; absent = defaults)."""
     section = args.get("op_layer") if hasattr(args, "get") else None
+    OPS.reset()   # a cfg without the section (or with fewer keys) gets the defaults, not the previous cfg's switches
     if section:
         configure(**dict(section))

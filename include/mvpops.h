@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 16
+#define MVP_ABI_VERSION 17
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -142,9 +142,10 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
                     float *dist, int *assignment, float eps, int iters,
                     void *scratch, long long scratch_bytes, void *stream);
 
-/* Tuning / A-B knobs of mvp_emd_forward, process-wide (defaults: environment
- * variables MVP_EMD_CLUSTER / _SAME_XCD / _SPLIT read once at first use).  A
- * negative argument leaves that knob unchanged.
+/* Tuning / A-B knobs of mvp_emd_forward, process-wide (compiled-in defaults; the release
+ * library reads NOTHING from the environment -- the MVP_EMD_* variables of rounds 1-4 exist
+ * only in libmvpops_hooks.so, the same sources built with -DMVP_TEST_HOOKS for the tests and
+ * A/B tools).  A negative argument leaves that knob unchanged.
  *   cluster     0 = automatic, or 1|2|4|8: cap of the workgroups per cloud
  *   same_xcd    0: keep write-through stores even when a cluster shares an XCD
  *   split       5 (default): as 4, with gathered-bid rounds once <= 256 persons are unassigned;
@@ -153,16 +154,26 @@ int mvp_emd_forward(int b, int n, const float *xyz1, const float *xyz2,
  *               3: the same in a launch of its own (every cloud waits for the last to get there); 2: the tail rounds run in the second kernel, from
  *               round 300 on with cluster widths by load (8 .. 2 workgroups);
  *               1: second kernel, fixed widths; 0: the first kernel runs every round
- *               (environment, read once: MVP_EMD_PLAN_ROUND = 300; MVP_EMD_PLAN_WIDTHS, e.g.
- *               8,5,4,4,3,3,3,2, fixes the widths of an XCD's eight clouds, heaviest first, sum
- *               32, instead of deriving them from the loads; MVP_EMD_PLAN_EVERY rounds between
- *               re-plans, default: never again)
  *   resident_cap  1..64 (default 16: one wave of the workgroup per unassigned person; more: several per wave): unassigned persons at which a cloud of <= 4096
- *               points moves into LDS (split = 3)
+ *               points moves into LDS (split >= 3)
  * This is the library's only process-wide state (kept under a mutex; a call of
  * mvp_emd_forward reads one consistent copy).  Results never depend on it
- * (every setting is bit-identical: tests/test_gpu_ops.py). */
+ * (every setting is bit-identical: tests/test_gpu_ops.py).  A caller that must not
+ * share state (several devices / threads with different plans) passes the plan on
+ * the call instead: mvp_emd_forward_plan below. */
 int mvp_emd_configure(int cluster, int same_xcd, int split, int resident_cap);
+
+/* mvp_emd_forward with its launch plan on the call (ABI 17): the fields mean what
+ * mvp_emd_configure's arguments mean; a NULL plan or a negative field selects the
+ * compiled-in default.  Neither reads nor writes the process-wide knobs.  Same
+ * results bit for bit. */
+typedef struct MvpEmdPlan {
+  int cluster, same_xcd, split, resident_cap;
+} MvpEmdPlan;
+int mvp_emd_forward_plan(int b, int n, const float *xyz1, const float *xyz2,
+                         float *dist, int *assignment, float eps, int iters,
+                         void *scratch, long long scratch_bytes,
+                         const MvpEmdPlan *plan, void *stream);
 
 /* Replaces emd.backward = emd_backward (emd.cpp:22-25,30) ->
  * emd_cuda_backward (emd_cuda.cu:302-316) -> NmDistanceGradKernel (:284-300).

@@ -23,6 +23,7 @@ SIGNATURES = {
     "mvp_chamfer_forward_sorted": "iiipppppppq",
     "mvp_chamfer_backward": "iiipppppppp",
     "mvp_emd_forward": "iippppfipq",
+    "mvp_emd_forward_plan": "iippppfipqp",
     "mvp_emd_backward": "iippppp",
     "mvp_furthest_point_sampling": "iiippp",
     "mvp_furthest_point_sampling_sorted": "iiippppq",
@@ -59,7 +60,7 @@ SIGNATURES = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 16  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 17  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
 EMD_DEFAULT_SPLIT = 5
@@ -145,11 +146,13 @@ def call(name, device, *args):
     cargs = []
     for kind, a in zip(sig, args):
         if kind == "p":
-            cargs.append(_ptr(a) if isinstance(a, torch.Tensor) else a)
+            cargs.append(_ptr(a) if isinstance(a, torch.Tensor) else ctypes.addressof(a) if isinstance(a, ctypes.Structure) else a)
         elif kind == "f":
             cargs.append(float(a))
         else:
             cargs.append(int(a))
+    if not isinstance(device, torch.device):   # "cuda:1", 1: accepted like torch does
+        device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
     idx = device.index
     cur = torch.cuda.current_device()
     if idx is None:
@@ -170,6 +173,15 @@ def call(name, device, *args):
 def emd_scratch_bytes(b, n, iters=None):
     """Scratch of mvp_emd_forward (the same for any number of rounds)."""
     return int(load().mvp_emd_scratch_bytes(int(b), int(n)))
+
+
+class EmdPlan(ctypes.Structure):
+    """MvpEmdPlan of include/mvpops.h: the launch plan of ONE mvp_emd_forward_plan call (negative field = compiled-in
+    default; nothing process-wide is read or written).  call("mvp_emd_forward_plan", dev, ..., nbytes, EmdPlan(split=2))."""
+    _fields_ = [("cluster", ctypes.c_int), ("same_xcd", ctypes.c_int), ("split", ctypes.c_int), ("resident_cap", ctypes.c_int)]
+
+    def __init__(self, cluster=-1, same_xcd=-1, split=-1, resident_cap=-1):
+        super().__init__(int(cluster), int(same_xcd), int(split), int(resident_cap))
 
 
 def emd_configure(cluster=-1, same_xcd=-1, split=-1, resident_cap=-1):

@@ -23,18 +23,22 @@
 //   * the unassigned lists are maintained incrementally (losers stay, an
 //     evicted owner joins the list of the workgroup that evicted it) instead
 //     of a count / prefix-sum / compaction pass over all n points per round;
-//   * objects (xyz2) are bucketed once into a uniform grid (<= 12^3 cells) and
-//     stored cell-sorted as float4 {x, y, z, price}.  Per cell every workgroup
-//     keeps in LDS the exact bounding box of its members and a lower bound of
-//     their prices (prices only rise, so a stale bound stays valid; refreshed
-//     bounds are broadcast to the other workgroups of the cluster each round);
+//   * objects (xyz2) are sorted once along a Hilbert curve and stored in that
+//     order as float4 {x, y, z, price}; 16 consecutive slots are a LEAF, 16
+//     consecutive leaves a NODE (emd_index.h: the index follows the cloud --
+//     16 objects per leaf on a volume and on a 2-manifold alike; rounds 1-5 used
+//     a uniform 12^3 grid).  Per leaf and node every workgroup keeps in LDS the
+//     exact bounding box of the members and a lower bound of their prices
+//     (prices only rise, so a stale bound stays valid; refreshed bounds are
+//     broadcast to the other workgroups of the cluster each round);
 //   * Bid.  A bid needs the best and second-best of
 //         v_k = float(3.0 - (double)sqrtf(|q-o_k|^2) - price_k)     (emd_cuda.cu:146)
 //     over all k.  Instead of evaluating all n objects the bidder (1) seeds a
-//     lower bound B2 of the second-best value from its home cell and its
-//     previous two best objects, (2) tests only the cells intersecting the
-//     cube |o-q|_inf <= 3-B2 against  dist(q, box) + price_lb <= 3 - B2  and
-//     (3) visits only surviving cells, where each object first passes the same
+//     lower bound B2 of the second-best value from its home chunk and the
+//     chunks of its previous two best objects, (2) tests the <= 64 nodes and
+//     the leaves of the passing nodes against
+//     dist(q, box) + price_lb <= 3 - B2  and
+//     (3) visits only surviving leaves, where each object first passes the same
 //     conservative test on its squared distance (no sqrt, no double); only
 //     objects that can still change {best, second best, best index} get the
 //     exact double-precision value.  Every skip is provably lossless (kMargin
@@ -42,9 +46,9 @@
 //     schedules share that logic: rounds with many bidders run FOUR bidders
 //     per wave (one per 16-lane DPP row; lane-local exact top-2, merged per
 //     row with DPP) for throughput; rounds with few bidders run one bidder
-//     per wave (wave-uniform state, scalar folds) for the shortest dependent
-//     chain.  A search cube that covers most of the grid falls back to a
-//     linear scan of the cell-sorted objects;
+//     per wave (wave-uniform state, scalar folds; emd_search_wave.inc) for the
+//     shortest dependent chain.  A search that finds the whole cloud within
+//     reach falls back to a linear scan of the sorted objects;
 //   * ties are resolved by the reference's own order, reconstructed from its
 //     thread partition (emd_cuda.cu:108-118,139-142,163-171): candidates are
 //     ordered by (chunk thread, 2048-tile, index in tile) of their ORIGINAL
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
     // few bidders -> one bidder per wave (shortest dependent chain).
     if (U > kRowModeMin) {
     // ---------------- Bid (emd_cuda.cu:95-179): one 16-lane ROW per bidder
-    // A bid touches ~16 cells and ~60 objects, so a 64-lane wave per bidder
+    // A bid touches ~10 leaves and ~160 objects, so a 64-lane wave per bidder
     // mostly waits on its own dependent instruction stream.  Four bidders per
     // wave (one per 16-lane DPP row) run those streams side by side: row-wide
     // reductions are 4 DPP steps, every lane keeps the exact top-2 of the
@@ -1196,7 +1200,7 @@ struct EmdKnobs {
 static std::mutex g_knob_mutex;
 static EmdKnobs &emd_knobs_locked() {   // (callers hold g_knob_mutex)
   static EmdKnobs k = [] {
-    EmdKnobs v{kMaxCluster, 1, 5, 300, 4096, 0ull, 16};   // widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
+    EmdKnobs v{kMaxCluster, 1, 5, 300, 4096, 0ull, 16};   // (mvp_emd_forward_plan builds the same defaults) widths from the loads (MVP_EMD_PLAN_WIDTHS=8,5,4,4,3,3,3,2 fixes them)
 #ifdef MVP_TEST_HOOKS
     if (const char *e = getenv("MVP_EMD_CLUSTER")) v.cluster = atoi(e);
     if (const char *e = getenv("MVP_EMD_SAME_XCD")) v.same_xcd = atoi(e) != 0;
@@ -1277,10 +1281,10 @@ extern "C" int mvp_emd_configure(int cluster, int same_xcd, int split, int resid
   return MVP_OK;
 }
 
-extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
-                               const float *xyz2, float *dist, int *assignment,
-                               float eps, int iters, void *scratch,
-                               long long scratch_bytes, void *stream) {
+static int emd_forward_with(const EmdKnobs &knobs, int b, int n, const float *xyz1,
+                            const float *xyz2, float *dist, int *assignment,
+                            float eps, int iters, void *scratch,
+                            long long scratch_bytes, void *stream) {
   if (b < 0 || n <= 0 || iters < 1) return MVP_EBADSHAPE;
   if (b > 512 || n % 1024 != 0) return MVP_EBADSHAPE;  // emd_cuda.cu:236-249
   // the pruning bounds rely on prices that never fall, i.e. on positive bid increments
@@ -1297,7 +1301,6 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
   // barrier granules, hand-over records and statistics start from zero on every call
   if (hipMemsetAsync(sbase + (size_t)b * emd_scratch_per_cloud(n), 0, (size_t)b * kEmdTailPerCloud, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
-  const EmdKnobs knobs = emd_knobs();
   int w = emd_cluster_width(b, knobs.cluster);
   // Two launches when the auction is long enough to have a tail: the first kernel hands a cloud
   // over when at least `lean` rounds are left (0: never); the second exits at once for clouds
@@ -1317,6 +1320,33 @@ extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
                               knobs.split >= 4 ? knobs.res_cap : knobs.split == 3 ? -knobs.res_cap : 0, st) != hipSuccess)
     return check_launch("mvp_emd_forward");
   return check_launch("mvp_emd_forward");
+}
+
+extern "C" int mvp_emd_forward(int b, int n, const float *xyz1,
+                               const float *xyz2, float *dist, int *assignment,
+                               float eps, int iters, void *scratch,
+                               long long scratch_bytes, void *stream) {
+  return emd_forward_with(emd_knobs(), b, n, xyz1, xyz2, dist, assignment, eps, iters, scratch, scratch_bytes, stream);
+}
+
+// The same call with its launch plan on the call instead of in the process (ABI 17): nothing of the library's state is
+// read or written -- a NULL plan or a negative field means the compiled-in default (NOT what mvp_emd_configure set).
+extern "C" int mvp_emd_forward_plan(int b, int n, const float *xyz1,
+                                    const float *xyz2, float *dist, int *assignment,
+                                    float eps, int iters, void *scratch,
+                                    long long scratch_bytes, const MvpEmdPlan *plan, void *stream) {
+  EmdKnobs k{kMaxCluster, 1, 5, 300, 4096, 0ull, 16};
+  if (plan) {
+    if (plan->cluster >= 0) {
+      if (plan->cluster != 0 && plan->cluster != 1 && plan->cluster != 2 && plan->cluster != 4 && plan->cluster != 8) return MVP_EBADARG;
+      k.cluster = plan->cluster == 0 ? kMaxCluster : plan->cluster;
+    }
+    if (plan->same_xcd >= 0) k.same_xcd = plan->same_xcd != 0;
+    if (plan->split >= 0) k.split = plan->split > 5 ? 5 : plan->split;
+    if (plan->resident_cap == 0 || plan->resident_cap > kResList) return MVP_EBADARG;
+    if (plan->resident_cap > 0) k.res_cap = plan->resident_cap;
+  }
+  return emd_forward_with(k, b, n, xyz1, xyz2, dist, assignment, eps, iters, scratch, scratch_bytes, stream);
 }
 
 extern "C" int mvp_emd_backward(int b, int n, const float *xyz1,

@@ -285,8 +285,10 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
           const int col = n0 + wn * 32 * TN + j * 32 + lrow;
           float v = acc[i][j][r] + bi;
           if (relu) v = __builtin_fmaxf(v, 0.f);
-          const unsigned b = __float_as_uint(v);
-          const unsigned o = col < N ? ((b & 0x80000000u) ? ~b : (b | 0x80000000u)) : 0u;   // order-preserving, > 0
+          // order-preserving key, > 0; -0 counts as +0 (the first position of a tie wins, as torch.max reports) and a NaN
+          // of either sign takes the top key (torch.max propagates NaN; unpacked as a NaN again)
+          const unsigned b = __float_as_uint(v + 0.f);
+          const unsigned o = col < N ? (v != v ? 0xFFFFFFFFu : (b & 0x80000000u) ? ~b : (b | 0x80000000u)) : 0u;
           if (o > hi) { hi = o; lo = ~(unsigned)col; }                                         // (strict: the smaller column stays)
         }
         // maximum over the 32 lanes that share this row (lanes 0..31 / 32..63): DPP inside the rows of 16, row_bcast15

@@ -30,18 +30,17 @@ MAX_CIN = 64
 # (profiles/r4_conv_passes_vrcnet_skinny.txt: 3.60 -> 1.97 ms per step over the 16 shapes).
 MFMA_MIN_CH = 1
 MFMA_SKINNY_FWD_MAX_CIN = 136   # forward with < 32 output channels: the library's GEMV-like kernel wins from ~256 input channels
-USE_MFMA = True   # A-B switch (tools/bench_models.py)
 # Round 4 (tools/bench_conv_passes.py, profiles/r4_conv_passes_*.txt): on the 20 routed shapes of a VRCNet step the
 # three passes cost 3.99 / 3.93 / 5.38 ms on these kernels against 5.34 / 5.54 / 6.29 ms on the library (whose
-# weight gradient is an NHWC implicit GEMM wrapped in layout transposes), every shape at least a tie.  Rounds 2-3 had
-# kept training on the library (MFMA_TRAIN off): the round-2 kernels won the forward only.  The switches stay for A/B:
+# weight gradient is an NHWC implicit GEMM wrapped in layout transposes), every shape at least a tie: every routed layer
+# trains and infers on the MFMA kernels.  What is left below are ROUTE SELECTORS, not experiments: the parity tests drive
+# every branch of the backward pass through them (tests/test_gpu_harness.py) and the reference-formulation report and the
+# per-pass bench record the library route beside ours (tests/report_reference_model_step.py, tools/bench_conv_passes.py).
+# (Round 6 removed the superseded ones: MFMA_WGRAD_TRAIN / _MIN_CIN -- weight gradients only --, MFMA_FWD_MAX_CIN.)
+USE_MFMA = True            # False: nothing is routed to the MFMA kernels (the library's convolution everywhere)
 MFMA_TRAIN = True          # under autograd the routed layers go through _PointwiseConv
 MFMA_DGRAD = True          # data gradient on mvp_pointwise_mfma (W^T, ReLU' on load)
 MFMA_WGRAD_MIN_CIN = 1     # weight gradient on mvp_pointwise_wgrad_mfma from this many input channels
-MFMA_FWD_MAX_CIN = 1 << 30
-# Only the weight gradients leave the library (forward and data gradient stay library calls); superseded by MFMA_TRAIN
-MFMA_WGRAD_TRAIN = False
-MFMA_WGRAD_TRAIN_MIN_CIN = 65
 
 _WGRAD_SCRATCH = {}   # (device, stream) -> one growing workspace for the partial tiles (no allocator churn)
 
@@ -74,7 +73,7 @@ def _gemm_fits(batch, m, k, length):
 
 def _mfma_fwd(x, cin, cout, weight=None):
     """Forward GEMM through mvp_pointwise_mfma?"""
-    return cin <= MFMA_FWD_MAX_CIN and _mfma_ok(x, cin, cout, weight) \
+    return _mfma_ok(x, cin, cout, weight) \
         and _gemm_fits(x.size(0), cout, cin, x[0, 0].numel()) and (cout >= 32 or cin <= MFMA_SKINNY_FWD_MAX_CIN)
 
 
@@ -170,8 +169,7 @@ class _PointwiseConv(Function):
         gx_small = need_x and _covered(x, weight)          # <= 64 x 64 channels: mvp_pointwise_dgrad (11-26 us, at or below the MFMA kernel)
         gx_mfma = MFMA_DGRAD and need_x and not gx_small and _mfma_ok(gy, cout, cin, weight) and cin % 4 == 0 \
             and _gemm_fits(x.size(0), cin, cout, x[0, 0].numel())
-        wgrad_min = min(MFMA_WGRAD_MIN_CIN, MFMA_WGRAD_TRAIN_MIN_CIN) if MFMA_WGRAD_TRAIN else MFMA_WGRAD_MIN_CIN
-        gw_mfma = (need_w or need_b) and cin >= wgrad_min and _mfma_ok(x, cin, cout, weight) and not _covered(x, weight) \
+        gw_mfma = (need_w or need_b) and cin >= MFMA_WGRAD_MIN_CIN and _mfma_ok(x, cin, cout, weight) and not _covered(x, weight) \
             and x.size(0) * x[0, 0].numel() >= MFMA_WGRAD_MIN_POSITIONS \
             and pointwise_wgrad_mfma_scratch_bytes(x.size(0), cin, cout, x[0, 0].numel(), ctx.has_bias) > 0
         # ReLU'(.): the MFMA kernels mask grad_out by the saved output on load; the other routes get
@@ -221,8 +219,7 @@ def pointwise_conv(x, weight, bias=None, relu=False):
     routed = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() \
         and weight.is_contiguous() and x.numel() > 0 and (_mfma_ok(x, cin, cout, weight) or _covered(x, weight))
     if routed and (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
-        if MFMA_TRAIN or _covered(x, weight) or (MFMA_WGRAD_TRAIN and cin >= MFMA_WGRAD_TRAIN_MIN_CIN
-                                                 and _mfma_ok(x, cin, cout, weight)):
+        if MFMA_TRAIN or _covered(x, weight):
             return _PointwiseConv.apply(x, weight, bias, relu)
         y = conv(x, weight, bias)
         return torch.relu(y) if relu else y

@@ -43,10 +43,12 @@ def timed(fn, reps=10):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def step_ms(name, fused):
+def step_ms(name, fused, switches=None):
     g = torch.Generator().manual_seed(0)
     args = train.load_config(os.path.join(ROOT, "completion", "cfgs", name + ".yaml"))
     args.load_model = None
+    if switches:                         # (load_config applies the cfg's switches, else the defaults: override afterwards)
+        op_config.configure(**switches)
     torch.manual_seed(0)                 # the same initial weights in every mode
     net = importlib.import_module("models." + name).Model(args).to(dev).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=fused)
@@ -73,14 +75,14 @@ def main():
         op_config.OPS.reset()
         pw.MFMA_TRAIN = True
         a, la = step_ms(name, True)
-        op_config.configure(gather_sum=0, gather_max=0, side_lanes=0, stacked_projections=0, skip_full_fps_of_gt=0,
-                            conv_before_interp=0, folded_conv=0)
+        off = dict(gather_sum=0, gather_max=0, side_lanes=0, stacked_projections=0, skip_full_fps_of_gt=0,
+                   conv_before_interp=0, folded_conv=0)
         pw.MFMA_TRAIN = False
-        b, lb = step_ms(name, False)
+        b, lb = step_ms(name, False, off)
         undo = ref_ops.patch_ops(modules())
         ref_ops.ref.SYNC = False            # like the reference's wrappers: no host synchronisation per operator
         try:
-            c, lc = step_ms(name, False)
+            c, lc = step_ms(name, False, off)
         finally:
             ref_ops.ref.SYNC = True
             undo()

@@ -70,10 +70,10 @@ def record_abi_calls(names):
 
 def test_cfg3_per_rank_step_ops_match_oracle(oracle, monkeypatch):
     import op_config
-    monkeypatch.setattr(op_config.OPS, "skip_full_fps_of_gt", False)   # the reference's launch sequence, incl. the FPS of all of gt's points
     import importlib
     import train
-    args = train.load_config(os.path.join(COMPLETION, "cfgs", "vrcnet.yaml"))
+    args = train.load_config(os.path.join(COMPLETION, "cfgs", "vrcnet.yaml"))   # (sets the op-layer switches: the cfg's, else the defaults)
+    monkeypatch.setattr(op_config.OPS, "skip_full_fps_of_gt", False)   # the reference's launch sequence, incl. the FPS of all of gt's points
     args.load_model = None
     torch.manual_seed(0)
     net = importlib.import_module("models.vrcnet").Model(args).to(DEV).train()

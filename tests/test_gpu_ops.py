@@ -292,6 +292,40 @@ def test_emd_second_kernel_really_runs(emd_split):
     assert (r1["next_round"] == 0).all() and (r1["final_width"] == 8).all() and (r1["final_launch"] == 1).all()   # finished, by the clusters of 8 a batch of 2 gets
 
 
+def test_emd_plan_on_the_call_is_stateless_and_bit_identical(emd_split):
+    """mvp_emd_forward_plan (ABI 17): the launch plan travels with the call -- the process-wide knobs of
+    mvp_emd_configure are neither read (a plan-less call runs the compiled-in defaults whatever was configured) nor
+    written (the next mvp_emd_forward still sees the configured split), results are the same bits for every plan, and
+    the hand-over record says which plan ran."""
+    from mvp_benchmark_amd import _lib
+    b, n = 2, 4096
+    x1, x2 = dev(rand_clouds(83, b, n, 3)), dev(rand_clouds(84, b, n, 3))
+    nbytes = _lib.emd_scratch_bytes(b, n)
+
+    def run(entry, *plan):
+        scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        dist = torch.zeros(b, n, device=DEV)
+        ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+        _lib.call(entry, "cuda:0", b, n, x1, x2, dist, ass, 0.004, 3000, scratch, nbytes, *plan)   # (a str device: _lib normalises it)
+        torch.cuda.synchronize()
+        return dist.cpu().numpy(), ass.cpu().numpy(), _lib.emd_records(scratch, nbytes, b)
+
+    emd_split(0)                                             # process-wide: the first kernel runs every round
+    ref = run("mvp_emd_forward")
+    assert (ref[2]["first_handover"] == 0).all()
+    outs = [run("mvp_emd_forward_plan", None), run("mvp_emd_forward_plan", _lib.EmdPlan()),
+            run("mvp_emd_forward_plan", _lib.EmdPlan(split=1, cluster=2)), run("mvp_emd_forward_plan", _lib.EmdPlan(split=3, resident_cap=8))]
+    for o in outs:
+        np.testing.assert_array_equal(o[0], ref[0])
+        np.testing.assert_array_equal(o[1], ref[1])
+        assert (o[2]["first_handover"] > 0).all()             # the plan's split, not the configured 0
+    assert (outs[0][2]["final_launch"] == 3).all() and (outs[1][2]["final_launch"] == 3).all()   # defaults: split 5 -> resident tail
+    assert (outs[2][2]["final_width"] == 2).all() and (outs[2][2]["final_launch"] == 1).all()
+    assert (run("mvp_emd_forward")[2]["first_handover"] == 0).all()   # the process-wide knob is untouched
+    with pytest.raises(_lib.MvpOpsError):
+        run("mvp_emd_forward_plan", _lib.EmdPlan(cluster=3))
+
+
 def test_emd_headline_cloud_matches_oracle(oracle, emd_split):
     """Two cloud pairs of the headline shape (16384 points, eps 0.004, 3000
     rounds) against the exhaustive oracle, bit for bit -- with the split into two

@@ -253,6 +253,44 @@ def test_reference_emd_kernels(oracle, mode, b, n, eps, iters):
         np.testing.assert_allclose(host(rd), want, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "chair gt + noise 0.03"])
+def test_reference_emd_kernels_at_the_headline_size(mode, kind):
+    """the headline size (16384 points, eps 0.004, 3000 rounds) against the reference's own emd_cuda.cu inside
+    the suite, on a uniform pair and on a surface-shaped one (what the eval loop sees).  GetMax's race (emd_cuda.cu:188-191)
+    makes the reference differ from itself here, so the yardstick is measured, not assumed: TWO runs of the reference on the
+    same input give its own per-cloud spread of the matching cost, and the product has to sit within three times that (plus
+    the north star's 1e-5, plus a floor of 2e-4 where the runs differ at all: two samples underestimate a spread; the fixed
+    tolerance of the smaller cases is 5e-3) of their mean.  Where the two runs happen to agree bit for bit the product must equal them."""
+    from mvp_benchmark_amd import metrics
+    from mvp_benchmark_amd.synthetic import prediction_pair
+    v, exact = mode
+    b, n, eps, iters = 2, 16384, 0.004, 3000
+    if kind == "uniform":
+        a, c = dev(rand_clouds(7001, b, n, 3)), dev(rand_clouds(7002, b, n, 3))
+    else:
+        pred, gt = prediction_pair("chair", "0.03", torch.Generator().manual_seed(7003), b, n)
+        a, c = pred.cuda(), gt.cuda()
+    r1d, r1a, _ = ref.emd_forward(a, c, eps, iters, v)
+    r2d, r2a, _ = ref.emd_forward(a, c, eps, iters, v)
+    md, ma = metrics.emd()(a, c, eps, iters)
+    cost = lambda d: np.sqrt(host(d).astype(np.float64)).mean(axis=1)            # per cloud
+    c1, c2, cm = cost(r1d), cost(r2d), cost(md)
+    differ = int((host(r1a) != host(r2a)).sum())
+    if differ == 0 and not exact:
+        same_index(ma, r1a)
+    spread = np.abs(c1 - c2)
+    tol = 3 * spread + 1e-5 * cm
+    print("headline-size EMD vs the reference (%s, %s build): reference runs differ in %d of %d assignments, cost spread %s, "
+          "product - reference mean %s (relative %s)" % (kind, v or "default", differ, b * n, spread, cm - (c1 + c2) / 2,
+                                                         (cm - (c1 + c2) / 2) / cm))
+    assert (np.abs(cm - (c1 + c2) / 2) <= tol + 2e-4 * cm * (differ > 0)).all(), (cm, c1, c2)
+    # and the product's dist is the distance of the assignment it returns
+    mh = host(ma).astype(np.int64)
+    assert mh.min() >= 0 and mh.max() < n
+    want = ((host(a) - np.take_along_axis(host(c), mh[..., None], 1)) ** 2).sum(-1)
+    np.testing.assert_allclose(host(md), want, rtol=1e-5, atol=1e-9)
+
+
 def test_reference_emd_backward_kernel(oracle, mode):
     from mvp_benchmark_amd import metrics
     v, _ = mode
@@ -268,6 +306,52 @@ def test_reference_emd_backward_kernel(oracle, mode):
     same_index(asg, ra)
     (d * dev(g)).sum().backward()
     np.testing.assert_array_equal(host(pa.grad), host(gx1))
+
+
+def test_reference_kernels_behind_ref_gpu_reproduce_the_reference_wrappers_fixtures():
+    """The two pins joined (parity seam b): tests/golden/ops_wrapper_golden.npz holds what the reference's own
+    PYTHON WRAPPERS return (generated with their compiled extensions replaced by the oracle); here the same inputs go
+    through oracle/ref_gpu.py -- the hand-made initial buffers (1e10 temp, zeroed idx, -1 assignments ...) in front of the
+    reference's own KERNELS -- and must give the wrappers' outputs: every index identical, values within one ulp (the
+    default-contraction build against fixtures computed in the canonical arithmetic).  A wrong initial value or argument
+    order in ref_gpu.py would show here, independently of the oracle."""
+    import os
+    v = ""
+    if not ref.available(v):
+        pytest.skip("oracle/_ref is not built")
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ops_wrapper_golden.npz"))
+    xyz, ctr, feat = dev(G["in/xyz"]), dev(G["in/ctr"]), dev(G["in/feat"])
+    same_index(ref.ball_query(0.0, 0.2, 8, xyz, ctr, v), G["ball_query/full"])              # ball_query.py:35-38
+    same_index(ref.ball_query(0.1, 0.25, 5, xyz, ctr, v), G["ball_query/ring"])
+    idx, _ = ref.knn(5, xyz, ctr, v)                                                          # knn.py:55-72: (B, M, k) -> (B, k, M)
+    same_index(idx.transpose(1, 2), G["knn/centres"])
+    idx, _ = ref.knn(5, xyz, xyz, v)
+    same_index(idx.transpose(1, 2), G["knn/self5"])
+    d2, idx = ref.three_nn(xyz, ctr, v)                                                       # three_nn.py:31-45 (+ the wrapper's sqrt)
+    same_index(idx, G["three/idx"])
+    np.testing.assert_allclose(np.sqrt(host(d2)), G["three/dist"], rtol=2 * ULP, atol=0)
+    np.testing.assert_allclose(host(ref.three_interpolate(dev(G["three/cfeat"]), dev(G["three/idx"]), dev(G["three/weight"]), v)),
+                               G["three/out"], rtol=2 * ULP, atol=1e-9)
+    np.testing.assert_allclose(host(ref.three_interpolate_grad(dev(G["three/gy"]), dev(G["three/idx"]), dev(G["three/weight"]), 40, v)),
+                               G["three/grad"], rtol=1e-5, atol=1e-6)
+    same_index(ref.fps(xyz, 33, v), G["fps/idx"])                                             # furthest_point_sample.py:29-33
+    same_index(ref.fps_with_dist(dev(G["fps/dmat"]), 20, v), G["fps/with_dist"])
+    same_value(ref.gather_points(feat, dev(G["gather/idx"]), v), G["gather/out"], True)       # gather_points.py:27-31
+    same_value(ref.grouping_operation(feat, dev(G["group/idx"]), v), G["group/out"], True)    # group_points.py:184-188
+    np.testing.assert_allclose(host(ref.gather_points_grad(dev(G["gather/gy"]), dev(G["gather/idx"]), 300, v)), G["gather/grad"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(ref.grouping_operation_grad(dev(G["group/gy"]), dev(G["group/idx"]), 300, v)), G["group/grad"], rtol=1e-5, atol=1e-6)
+    d1, d2c, i1, i2 = ref.chamfer_forward(dev(G["cd/a"]), dev(G["cd/b"]), v)                  # dist_chamfer_3D.py:30-50
+    same_index(i1, G["cd/idx1"])
+    same_index(i2, G["cd/idx2"])
+    same_value(d1, G["cd/dist1"], False)
+    same_value(d2c, G["cd/dist2"], False)
+    p, q = dev(G["emd_in/p"]), dev(G["emd_in/q"])                                             # emd_module.py:49-65
+    for tag, eps, iters in (("train", 0.005, 50), ("smoke", 0.05, 3000)):
+        dist, ass, _ = ref.emd_forward(p, q, eps, iters, v)
+        same_index(ass, G["emd_%s/assignment" % tag])
+        same_value(dist, G["emd_%s/dist" % tag], False)
+        gx1, _ = ref.emd_backward(p, q, dev(G["emd_%s/gd" % tag]), ass, v)
+        np.testing.assert_allclose(host(gx1), G["emd_%s/grad_p" % tag], rtol=1e-5, atol=1e-6)
 
 
 def test_hip_path_matches_committed_reference_kernel_outputs():

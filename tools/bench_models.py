@@ -12,10 +12,17 @@ if "MVP_MFMA_TRAIN" in os.environ:                       # A/B of the training-p
     pw.MFMA_TRAIN = os.environ["MVP_MFMA_TRAIN"] == "1"
 import op_config
 # A/B of the networks' formulations: MVP_OPS="gather_sum=0,side_lanes=1" (completion/op_config.py)
-if os.environ.get("MVP_OPS"):
-    op_config.configure(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["MVP_OPS"].split(","))})
-if "MVP_MFMA_WGRAD_TRAIN" in os.environ:                 # A/B: only the weight gradients leave the library
-    pw.MFMA_WGRAD_TRAIN = os.environ["MVP_MFMA_WGRAD_TRAIN"] == "1"
+OPS_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ["MVP_OPS"].split(","))} if os.environ.get("MVP_OPS") else {}
+
+
+def load_cfg(path):
+    """train.load_config sets the op-layer switches from the cfg (else the defaults); the A/B override goes on top."""
+    args = train.load_config(path)
+    if OPS_OVERRIDE:
+        op_config.configure(**OPS_OVERRIDE)
+    return args
+
+
 REPS = int(os.environ.get("MVP_BENCH_REPS", "10"))
 if os.environ.get("MVP_CUDNN_BENCHMARK") == "1":          # A/B: MIOpen picks its convolution solvers by measuring them
     torch.backends.cudnn.benchmark = True
@@ -34,7 +41,7 @@ def timed(fn, reps=REPS):
 # cfg 2 (the randomly initialised PCN emits one tight blob: the degenerate EMD input, seconds per step;
 # pass "cfg2" to include it)
 if "cfg2" in sys.argv:
-    args = train.load_config(os.path.join(ROOT, "completion", "cfgs", "pcn_eval16k.yaml"))
+    args = load_cfg(os.path.join(ROOT, "completion", "cfgs", "pcn_eval16k.yaml"))
     net = importlib.import_module("models.pcn").Model(args).to(dev).eval()
     partial = torch.rand(32, 3, 2048, generator=g).to(dev); gt = torch.rand(32, 16384, 3, generator=g).to(dev)
     with torch.no_grad():
@@ -44,7 +51,7 @@ if "cfg2" in sys.argv:
     print("cfg2 PCN eval (32, 2048->16384) CD+F1+EMD: %.1f ms/step (%.1f clouds/s); without EMD %.1f ms" % (ms, 32e3 / ms, ms_noemd), flush=True)
 
 for name in ("vrcnet", "ecg", "pcn"):
-    args = train.load_config(os.path.join(ROOT, "completion", "cfgs", name + ".yaml"))
+    args = load_cfg(os.path.join(ROOT, "completion", "cfgs", name + ".yaml"))
     args.load_model = None
     net = importlib.import_module("models." + name).Model(args).to(dev).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=os.environ.get("MVP_FOREACH_ADAM") != "1")   # (fused: as completion/train.py builds it)
@@ -58,5 +65,5 @@ for name in ("vrcnet", "ecg", "pcn"):
     if torch.backends.cudnn.benchmark:
         for _ in range(3): step()       # the solver search happens in the first steps
     ms = timed(step)
-    print("%s train step (batch 32, 2048 pts, MFMA_TRAIN=%s, MFMA_WGRAD_TRAIN=%s%s): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
-        name, pw.MFMA_TRAIN, pw.MFMA_WGRAD_TRAIN, ", solver search on" if torch.backends.cudnn.benchmark else "", ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
+    print("%s train step (batch 32, 2048 pts, MFMA_TRAIN=%s%s): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
+        name, pw.MFMA_TRAIN, ", solver search on" if torch.backends.cudnn.benchmark else "", ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)

@@ -16,6 +16,12 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
 x1, x2 = torch.rand(b, n, 3, generator=g).to(dev), torch.rand(b, n, 3, generator=g).to(dev)
+shape = os.environ.get("MVP_BENCH_SHAPE")   # e.g. "chair:0.03" (gt + noise), "chair:indep": tools/emd_surfaces.py's clouds
+if shape:
+    from mvp_benchmark_amd.synthetic import prediction_pair
+    name, _, mode = shape.partition(":")
+    pred, gt = prediction_pair(name, mode or "indep", g, b, n)
+    x1, x2 = pred.to(dev), gt.to(dev)
 nbytes = _lib.emd_scratch_bytes(b, n)
 scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
 dist = torch.zeros(b, n, device=dev)
