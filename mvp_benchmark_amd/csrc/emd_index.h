@@ -84,9 +84,15 @@ __device__ __forceinline__ void emd_sort_pass(const u64 *__restrict__ src, u64 *
   const int seg = n / kEmdWaves;   // a multiple of 64
   for (int e = t; e < kSortDigits * kEmdWaves; e += kEmdThreads) hist[e] = 0;
   __syncthreads();
-  for (int i = lane; i < seg; i += kWave) {
-    const unsigned d = (unsigned)(src[(size_t)wave * seg + i] >> (32 + shift)) & (kSortDigits - 1);
-    atomicAdd(&hist[d * kEmdWaves + wave], 1);
+  // (eight entries per lane are loaded before the first is used: the passes are chains of dependent memory round trips
+  // otherwise -- 16 per wave and phase at 16384 points)
+  for (int i0 = 0; i0 < seg; i0 += 8 * kWave) {
+    u64 e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = i0 + k * kWave + lane < seg ? src[(size_t)wave * seg + i0 + k * kWave + lane] : 0ull;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k * kWave < seg) atomicAdd(&hist[((unsigned)(e[k] >> (32 + shift)) & (kSortDigits - 1)) * kEmdWaves + wave], 1);
   }
   __syncthreads();
   {  // exclusive prefix sum over the 8192 counters in (digit, wave) order: 8 consecutive ones per thread
@@ -113,21 +119,28 @@ __device__ __forceinline__ void emd_sort_pass(const u64 *__restrict__ src, u64 *
     }
   }
   __syncthreads();
-  for (int i = lane; i < seg; i += kWave) {
-    const u64 e = src[(size_t)wave * seg + i];
-    const unsigned d = (unsigned)(e >> (32 + shift)) & (kSortDigits - 1);
-    unsigned long long peers = ~0ull;
+  for (int i0 = 0; i0 < seg; i0 += 8 * kWave) {
+    u64 ev[8];
 #pragma unroll
-    for (int bit = 0; bit < kHilbertBits; ++bit) {
-      const unsigned long long bm = __ballot((d >> bit) & 1u);
-      peers &= ((d >> bit) & 1u) ? bm : ~bm;
+    for (int k = 0; k < 8; ++k) ev[k] = i0 + k * kWave + lane < seg ? src[(size_t)wave * seg + i0 + k * kWave + lane] : 0ull;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (i0 + k * kWave >= seg) break;   // (seg is a multiple of 64: whole batches)
+      const u64 e = ev[k];
+      const unsigned d = (unsigned)(e >> (32 + shift)) & (kSortDigits - 1);
+      unsigned long long peers = ~0ull;
+#pragma unroll
+      for (int bit = 0; bit < kHilbertBits; ++bit) {
+        const unsigned long long bm = __ballot((d >> bit) & 1u);
+        peers &= ((d >> bit) & 1u) ? bm : ~bm;
+      }
+      const int rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
+      int *cnt = &hist[d * kEmdWaves + wave];
+      const int base = *cnt;
+      dst[base + rank] = e;
+      // (every peer has read the counter -- LDS operations of a wave are in order --; the last of them moves it on)
+      if (lane == 63 - (int)__builtin_clzll(peers)) *cnt = base + __builtin_popcountll(peers);
     }
-    const int rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
-    int *cnt = &hist[d * kEmdWaves + wave];
-    const int base = *cnt;
-    dst[base + rank] = e;
-    // (every peer has read the counter -- LDS operations of a wave are in order --; the last of them moves it on)
-    if (lane == 63 - (int)__builtin_clzll(peers)) *cnt = base + __builtin_popcountll(peers);
   }
   __syncthreads();
 }
@@ -152,21 +165,42 @@ __device__ __forceinline__ void emd_index_boxes(float4 *l_lo, float4 *l_hi, floa
   const int t = threadIdx.x, sl = t & 15;
   const int nleaf = n >> lshift;
   const float inf = __builtin_inff();
-  for (int leaf = t >> 4; leaf < kMaxLeaves; leaf += kEmdThreads / 16) {
-    float lx = inf, ly = inf, lz = inf, pm = inf, hx = -inf, hy = -inf, hz = -inf;
-    if (leaf < nleaf) {
-      for (int s = (leaf << lshift) + sl; s < ((leaf + 1) << lshift); s += 16) {
-        const float4 o = obj[s];
-        lx = __builtin_fminf(lx, o.x); ly = __builtin_fminf(ly, o.y); lz = __builtin_fminf(lz, o.z);
-        hx = __builtin_fmaxf(hx, o.x); hy = __builtin_fmaxf(hy, o.y); hz = __builtin_fmaxf(hz, o.z);
-        pm = __builtin_fminf(pm, o.w);
-      }
-    }
+  auto reduce_store = [&](int leaf, float lx, float ly, float lz, float pm, float hx, float hy, float hz) {
     lx = emd_row_min(lx); ly = emd_row_min(ly); lz = emd_row_min(lz); pm = emd_row_min(pm);
     hx = emd_row_max(hx); hy = emd_row_max(hy); hz = emd_row_max(hz);
     if (sl == 0) {
       l_lo[leaf] = make_float4(lx, ly, lz, leaf < nleaf ? pm : 0.f);
       l_hi[leaf] = make_float4(hx, hy, hz, 0.f);
+    }
+  };
+  if (lshift == 4) {
+    // (16 slots per leaf, up to 16384 points: four leaves' loads in flight per row and iteration)
+    for (int l0 = t >> 4; l0 < kMaxLeaves; l0 += 4 * (kEmdThreads / 16)) {
+      float4 o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int leaf = l0 + j * (kEmdThreads / 16);
+        o[j] = leaf < nleaf ? obj[leaf * 16 + sl] : make_float4(inf, inf, inf, inf);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int leaf = l0 + j * (kEmdThreads / 16);
+        const bool in = leaf < nleaf;
+        reduce_store(leaf, o[j].x, o[j].y, o[j].z, o[j].w, in ? o[j].x : -inf, in ? o[j].y : -inf, in ? o[j].z : -inf);
+      }
+    }
+  } else {
+    for (int leaf = t >> 4; leaf < kMaxLeaves; leaf += kEmdThreads / 16) {
+      float lx = inf, ly = inf, lz = inf, pm = inf, hx = -inf, hy = -inf, hz = -inf;
+      if (leaf < nleaf) {
+        for (int s = (leaf << lshift) + sl; s < ((leaf + 1) << lshift); s += 16) {
+          const float4 o = obj[s];
+          lx = __builtin_fminf(lx, o.x); ly = __builtin_fminf(ly, o.y); lz = __builtin_fminf(lz, o.z);
+          hx = __builtin_fmaxf(hx, o.x); hy = __builtin_fmaxf(hy, o.y); hz = __builtin_fmaxf(hz, o.z);
+          pm = __builtin_fminf(pm, o.w);
+        }
+      }
+      reduce_store(leaf, lx, ly, lz, pm, hx, hy, hz);
     }
   }
   __syncthreads();

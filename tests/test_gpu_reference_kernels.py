@@ -257,10 +257,14 @@ def test_reference_emd_kernels(oracle, mode, b, n, eps, iters):
 def test_reference_emd_kernels_at_the_headline_size(mode, kind):
     """the headline size (16384 points, eps 0.004, 3000 rounds) against the reference's own emd_cuda.cu inside
     the suite, on a uniform pair and on a surface-shaped one (what the eval loop sees).  GetMax's race (emd_cuda.cu:188-191)
-    makes the reference differ from itself here, so the yardstick is measured, not assumed: TWO runs of the reference on the
-    same input give its own per-cloud spread of the matching cost, and the product has to sit within three times that (plus
-    the north star's 1e-5, plus a floor of 2e-4 where the runs differ at all: two samples underestimate a spread; the fixed
-    tolerance of the smaller cases is 5e-3) of their mean.  Where the two runs happen to agree bit for bit the product must equal them."""
+    makes the reference one member of an outcome SET here and the product another (the highest-bidder policy the oracle
+    pins).  The reference is run TWICE on the same input to see its own spread -- measured (first run of this test): the
+    two runs differ in 5 584 of 32 768 assignments but only 4.5e-7 in cost, because the same kernels on the same idle GPU
+    replay nearly the same schedule, while the product's policy sits 1.2e-3 (relative) away on one cloud and 6.6e-5 on the
+    other.  Two runs therefore UNDERSTATE the outcome set; its width was measured in round 2 by running the oracle under
+    both extreme policies (profiles/r2_emd_schedule_sensitivity.txt: 1e-3 .. 2.3e-3).  Tolerance: the larger of three times
+    the measured spread and 2.5e-3 of the cost (the smaller cases above use 5e-3); where the two reference runs agree bit
+    for bit the product must equal them exactly."""
     from mvp_benchmark_amd import metrics
     from mvp_benchmark_amd.synthetic import prediction_pair
     v, exact = mode
@@ -279,11 +283,11 @@ def test_reference_emd_kernels_at_the_headline_size(mode, kind):
     if differ == 0 and not exact:
         same_index(ma, r1a)
     spread = np.abs(c1 - c2)
-    tol = 3 * spread + 1e-5 * cm
     print("headline-size EMD vs the reference (%s, %s build): reference runs differ in %d of %d assignments, cost spread %s, "
           "product - reference mean %s (relative %s)" % (kind, v or "default", differ, b * n, spread, cm - (c1 + c2) / 2,
                                                          (cm - (c1 + c2) / 2) / cm))
-    assert (np.abs(cm - (c1 + c2) / 2) <= tol + 2e-4 * cm * (differ > 0)).all(), (cm, c1, c2)
+    tol = np.maximum(3 * spread, 2.5e-3 * cm) if differ else 1e-5 * cm
+    assert (np.abs(cm - (c1 + c2) / 2) <= tol).all(), (cm, c1, c2)
     # and the product's dist is the distance of the assignment it returns
     mh = host(ma).astype(np.int64)
     assert mh.min() >= 0 and mh.max() < n

@@ -72,7 +72,8 @@ typedef struct {
   double b_leaves_np, b_nodes_np;        /* without price bounds */
   double rounds, g_maxsteps, b_maxsteps, g_sumchunks_round, b_sumleaves_round, bidders;
   double g_seedgap, b_seedgap;           /* seed threshold - final threshold, in grid cell widths */
-  double b2_leaves, b2_steps, b2_maxsteps, ideal_n;  /* variant: seed without the home leaf's neighbour */
+  double b2_leaves, b2_steps, b2_maxsteps, ideal_n;
+  double p_rem[2], p_zero[2], p_maxsteps[2], p_pref[2];   /* prefetch variants: leaves still to visit, searches with none, per-round max extra steps, groups prefetched */  /* variant: seed without the home leaf's neighbour */
 } Stats;
 
 int main(int argc, char **argv) {
@@ -159,7 +160,7 @@ int main(int argc, char **argv) {
           }
         }
       }
-      int g_max = 0, b_max = 0, b2_max = 0; double g_sum = 0, b_sum = 0;
+      int g_max = 0, b_max = 0, b2_max = 0, p_max[2] = {0, 0}; double g_sum = 0, b_sum = 0;
       for (int u = 0; u < cnt; ++u) {
         const int j = unass[u];
         const float *q = x1 + j * 3;
@@ -224,11 +225,33 @@ int main(int argc, char **argv) {
             }
           }
         }
+        if (counting) {
+          /* ---- P: ONE round trip over up to four aligned 64-slot groups (home, previous best, previous second best and
+             a sibling group), exact top-2 of those <= 256 objects -> threshold; what is left to visit afterwards? */
+          for (int var = 0; var < 2; ++var) {
+            const int gh = home[j] >> 2, g1 = p1[j] >= 0 ? slot_of[p1[j]] >> 6 : -1, g2 = p2[j] >= 0 ? slot_of[p2[j]] >> 6 : -1;
+            const int cand[4] = {g1, g2, gh, var == 0 ? (gh ^ 1) : (g1 >= 0 ? (g1 ^ 1) : (gh ^ 1))};
+            int gs[4], ng = 0;
+            for (int c = 0; c < 4; ++c) { int dup = cand[c] < 0 || cand[c] >= n / 64; for (int e = 0; e < ng; ++e) dup |= gs[e] == cand[c]; if (!dup) gs[ng++] = cand[c]; }
+            float a1 = -1e9f, a2 = -1e9f;
+            for (int e = 0; e < ng; ++e) for (int s = 64 * gs[e]; s < 64 * gs[e] + 64; ++s) { const int k = kv[s].idx; const float v = value(sqdist3(x2[k * 3] - q[0], x2[k * 3 + 1] - q[1], x2[k * 3 + 2] - q[2]), price[k]); if (v > a1) { a2 = a1; a1 = v; } else if (v > a2) a2 = v; }
+            const float tm = (3.0f - a2) + MARGIN;
+            int rem = 0;
+            for (int m = 0; m < nnode; ++m) if (box_pass(&nbox[m], q, tm, 1))
+              for (int l = 16 * m; l < 16 * m + 16 && l < nleaf; ++l) if (box_pass(&lbox[l], q, tm, 1)) {
+                int pre = 0; for (int e = 0; e < ng; ++e) pre |= (l >> 2) == gs[e];
+                rem += !pre;
+              }
+            st.p_rem[var] += rem; st.p_zero[var] += rem == 0; st.p_pref[var] += ng;
+            const int steps = (rem + 15) / 16;
+            if (steps > p_max[var]) p_max[var] = steps;
+          }
+        }
         p1[j] = bi; p2[j] = b2i;
         bid[j] = bi; binc[j] = best - better + eps;
         if (binc[j] > maxinc[bi]) maxinc[bi] = binc[j];
       }
-      if (counting) { st.rounds += 1; st.g_maxsteps += g_max; st.b_maxsteps += b_max; st.b2_maxsteps += b2_max; st.g_sumchunks_round += g_sum; st.b_sumleaves_round += b_sum; st.bidders += cnt; }
+      if (counting) { st.rounds += 1; st.g_maxsteps += g_max; st.b_maxsteps += b_max; st.b2_maxsteps += b2_max; st.p_maxsteps[0] += p_max[0]; st.p_maxsteps[1] += p_max[1]; st.g_sumchunks_round += g_sum; st.b_sumleaves_round += b_sum; st.bidders += cnt; }
       for (int u = 0; u < cnt; ++u) { const int j = unass[u]; const int o = bid[j]; const float bi = binc[j], mi = maxinc[o]; if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6) maxidx[o] = j; }
       const int last = it == iters - 1;
       for (int u = 0; u < cnt; ++u) {
@@ -256,5 +279,8 @@ int main(int argc, char **argv) {
   printf("  B leaves : seed gap %.3f cells | %.1f of %d nodes pass (%.1f without price), %.0f leaves tested, %.1f pass (%.1f without price) | steps %.2f (>1: %.1f %%) | per round: max steps %.2f, chunks %.0f\n",
          tot.b_seedgap / S, tot.b_nodes / S, (n / 16 + 15) / 16, tot.b_nodes_np / S, tot.b_leaftests / S, tot.b_leaves / S, tot.b_leaves_np / S, tot.b_steps / S, 100 * tot.b_multi / S, tot.b_maxsteps / R, tot.b_sumleaves_round / R);
   printf("  B, seed without the neighbour leaf: %.1f leaves pass, steps %.2f, per-round max %.2f\n", tot.b2_leaves / S, tot.b2_steps / S, tot.b2_maxsteps / R);
+  for (int v = 0; v < 2; ++v)
+    printf("  P%d one round trip over the 64-slot groups of {home, best, second, %s}: %.2f groups, then %.2f leaves left to visit; nothing left in %.1f %% of the searches; per round: max extra steps %.2f\n",
+           v, v ? "best's sibling" : "home's sibling", tot.p_pref[v] / S, tot.p_rem[v] / S, 100 * tot.p_zero[v] / S, tot.p_maxsteps[v] / R);
   return 0;
 }
