@@ -28,6 +28,10 @@ constexpr int kMaxNodes = 64;     // one lane each
 constexpr int kNodeFan = 16;      // leaves per node: one 16-lane row each
 constexpr int kHilbertBits = 9;   // per axis: 27-bit keys, three 9-bit digits
 constexpr int kSortDigits = 1 << kHilbertBits;
+#ifndef MVP_EMD_VISIT_LOADS
+#define MVP_EMD_VISIT_LOADS 4
+#endif
+constexpr int kVisitLoads = MVP_EMD_VISIT_LOADS;   // leaves a 16-lane row loads per visit step of a one-bidder-per-wave search (4 rows: 16 leaves per step)
 static_assert(kMaxNodes * kNodeFan == kMaxLeaves && kMaxNodes == kWave, "a node per lane, a leaf per lane of a row");
 
 // log2 of the slots of a leaf: 4 (16 slots) up to 16384 points, then as many more as keep the leaves at <= 1024.

@@ -167,6 +167,98 @@ def test_emd_matches_oracle_bit_exact(oracle, b, n, eps, iters):
     np.testing.assert_array_equal(dist.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "sheet"])
+@pytest.mark.parametrize("b,n,eps,iters", [(1, 17408, 0.01, 40), (2, 33792, 0.02, 5), (1, 66560, 0.05, 2)])
+def test_emd_above_16384_points_matches_oracle(oracle, emd_split, b, n, eps, iters, kind):
+    """More than 16384 points: a leaf of the index holds 32 / 64 / 128 slots (csrc/emd_index.h keeps the leaves at <= 1024:
+    544 / 528 / 520 of them here, the last node of the third case half empty), a visited leaf is several 16-slot chunks, the
+    re-scan of a winner's leaf loops, the rounds stay plain (gathered bids need <= 16384).  Both launch sequences; a flat
+    sheet as the second cloud kind (every box degenerate in z)."""
+    from mvp_benchmark_amd.metrics import emd
+    x1, x2 = rand_clouds(n + 7, b, n, 3), rand_clouds(n + 8, b, n, 3)
+    if kind == "sheet":
+        x1[..., 2] = 0.5
+        x2[..., 2] = 0.5
+    od, oa = oracle.emd_forward(x1, x2, eps, iters)
+    for split in (0, 5):
+        emd_split(split)
+        dist, ass = emd()(dev(x1), dev(x2), eps, iters)
+        np.testing.assert_array_equal(ass.cpu().numpy(), oa)
+        np.testing.assert_array_equal(dist.cpu().numpy(), od)
+
+
+def _hilbert_keys(pts, lo, scale, bits=9):
+    """NumPy restatement of csrc/emd_index.h: emd_hilbert_key (Skilling's transpose form, three axes)."""
+    top = (1 << bits) - 1
+    c = np.clip(((pts - lo) * scale).astype(np.int32), 0, top).astype(np.uint32)
+    x, y, z = c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy()
+    q = np.uint32(1 << (bits - 1))
+    while q > 1:
+        p_ = np.uint32(q - 1)
+        x = np.where(x & q, x ^ p_, x)
+        t = (x ^ y) & p_
+        x, y = np.where(y & q, x ^ p_, x ^ t), np.where(y & q, y, y ^ t)
+        t = (x ^ z) & p_
+        x, z = np.where(z & q, x ^ p_, x ^ t), np.where(z & q, z, z ^ t)
+        q = np.uint32(q >> 1)
+    y = y ^ x
+    z = z ^ y
+    t = np.zeros_like(x)
+    q = np.uint32(1 << (bits - 1))
+    while q > 1:
+        t = np.where(z & q, t ^ np.uint32(q - 1), t)
+        q = np.uint32(q >> 1)
+    x, y, z = x ^ t, y ^ t, z ^ t
+    h = np.zeros_like(x)
+    for b_ in range(bits - 1, -1, -1):
+        h = (h << np.uint32(3)) | (((x >> np.uint32(b_)) & np.uint32(1)) << np.uint32(2)) | (((y >> np.uint32(b_)) & np.uint32(1)) << np.uint32(1)) | ((z >> np.uint32(b_)) & np.uint32(1))
+    return h
+
+
+@pytest.mark.parametrize("n,kind", [(1024, "uniform"), (4096, "chair"), (16384, "uniform"), (20480, "uniform")])
+def test_emd_index_is_a_hilbert_sort_of_the_objects(n, kind):
+    """The index build of round 6 (csrc/emd_index.h), read back from the call's scratch: the sorted objects are a permutation
+    of xyz2 (perm), they are in non-decreasing order of the 27-bit Hilbert key of the cube that bounds both clouds (the
+    three-pass radix sort), and every person's home chunk is the chunk whose key range holds the person's own key."""
+    from mvp_benchmark_amd import _lib
+    from mvp_benchmark_amd.synthetic import prediction_pair
+    b = 2
+    if kind == "uniform":
+        x1, x2 = rand_clouds(n + 31, b, n, 3), rand_clouds(n + 32, b, n, 3)
+    else:
+        p, g_ = prediction_pair("chair", "0.03", torch.Generator().manual_seed(n), b, n)
+        x1, x2 = p.numpy(), g_.numpy()
+    nbytes = _lib.emd_scratch_bytes(b, n)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    dist = torch.zeros(b, n, device=DEV)
+    ass = torch.zeros(b, n, dtype=torch.int32, device=DEV)
+    _lib.call("mvp_emd_forward", DEV, b, n, dev(x1), dev(x2), dist, ass, 0.004, 3, scratch, nbytes)
+    torch.cuda.synchronize()
+    per_cloud = (nbytes - b * (768 + 2 * (2 * 256 + 8) * 8 + 96 + 16)) // b
+    lshift = 4
+    while (n >> lshift) > 1024:
+        lshift += 1
+    for c in range(b):
+        base = scratch[c * per_cloud: (c + 1) * per_cloud]
+        obj = base[: n * 16].view(torch.float32).view(n, 4).cpu().numpy()
+        person = base[n * 32: n * 64].view(torch.float32).view(n, 8).cpu().numpy()
+        perm = base[n * 64: n * 68].view(torch.int32).cpu().numpy()
+        assert sorted(perm.tolist()) == list(range(n))
+        np.testing.assert_array_equal(obj[:, :3], x2[c][perm])
+        both = np.concatenate([x1[c], x2[c]], 0)
+        lo = both.min(0)
+        ext = np.float32((both.max(0) - lo).max())
+        scale = np.float32(512.0) / ext
+        keys = _hilbert_keys(obj[:, :3], lo, scale)
+        assert (np.diff(keys.astype(np.int64)) >= 0).all()
+        # home chunk of every person: the last leaf whose first key is <= the person's key (leaf 0 if none), as a chunk
+        leaf_first = keys[:: 1 << lshift].astype(np.int64)
+        pk = _hilbert_keys(x1[c], lo, scale).astype(np.int64)
+        want = np.maximum(np.searchsorted(leaf_first, pk, side="right") - 1, 0) << (lshift - 4)
+        np.testing.assert_array_equal(person[:, :3], x1[c])
+        np.testing.assert_array_equal(person[:, 3].view(np.int32), want.astype(np.int32))
+
+
 @pytest.fixture
 def cluster_width():
     """Pins how many workgroups own one cloud (mvp_emd_configure; automatic again afterwards)."""

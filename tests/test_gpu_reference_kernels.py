@@ -335,7 +335,7 @@ def test_reference_kernels_behind_ref_gpu_reproduce_the_reference_wrappers_fixtu
     same_index(idx, G["three/idx"])
     np.testing.assert_allclose(np.sqrt(host(d2)), G["three/dist"], rtol=2 * ULP, atol=0)
     np.testing.assert_allclose(host(ref.three_interpolate(dev(G["three/cfeat"]), dev(G["three/idx"]), dev(G["three/weight"]), v)),
-                               G["three/out"], rtol=2 * ULP, atol=1e-9)
+                               G["three/out"], rtol=2 * ULP, atol=1e-7)       # (a three-term sum, contracted differently: one ulp of its O(1) terms)
     np.testing.assert_allclose(host(ref.three_interpolate_grad(dev(G["three/gy"]), dev(G["three/idx"]), dev(G["three/weight"]), 40, v)),
                                G["three/grad"], rtol=1e-5, atol=1e-6)
     same_index(ref.fps(xyz, 33, v), G["fps/idx"])                                             # furthest_point_sample.py:29-33
