@@ -493,24 +493,24 @@ __global__ __launch_bounds__(kEmdThreads) void emd_auction_kernel(
         bool all_near = act && __builtin_popcountll(nm) >= nnode;
         bool linear = false;
 
-        // (4) visit the listed leaves of this row, 4 per step (16 lanes each)
+        // (4) visit the listed leaves of this row, kRowVisitLoads per step (16 lanes each)
         int nlist = 0;
         auto visit = [&]() {
-          for (int k0 = 0; __any(k0 < nlist); k0 += 4) {
-            int s[4];
-            bool in[4];
+          for (int k0 = 0; __any(k0 < nlist); k0 += kRowVisitLoads) {
+            int s[kRowVisitLoads];
+            bool in[kRowVisitLoads];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
+            for (int r4 = 0; r4 < kRowVisitLoads; ++r4) {
               in[r4] = k0 + r4 < nlist;
               s[r4] = in[r4] ? ((int)wl[k0 + r4] << lshift) + l16 : 0;
             }
             for (int c = 0; c < kch; ++c) {   // (one chunk per leaf up to 16384 points)
-              float4 o[4];
+              float4 o[kRowVisitLoads];
 #pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4)
+              for (int r4 = 0; r4 < kRowVisitLoads; ++r4)
                 o[r4] = in[r4] ? ld_obj(s[r4] + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) consider(in[r4], o[r4], s[r4] + 16 * c);
+              for (int r4 = 0; r4 < kRowVisitLoads; ++r4) consider(in[r4], o[r4], s[r4] + 16 * c);
             }
           }
           nlist = 0;

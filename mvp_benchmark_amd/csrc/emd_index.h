@@ -31,6 +31,10 @@ constexpr int kSortDigits = 1 << kHilbertBits;
 #ifndef MVP_EMD_VISIT_LOADS
 #define MVP_EMD_VISIT_LOADS 4
 #endif
+#ifndef MVP_EMD_ROW_VISIT_LOADS
+#define MVP_EMD_ROW_VISIT_LOADS 4
+#endif
+constexpr int kRowVisitLoads = MVP_EMD_ROW_VISIT_LOADS;   // ... and per step of a four-bidders-per-wave search (emd.hip)
 constexpr int kVisitLoads = MVP_EMD_VISIT_LOADS;   // leaves a 16-lane row loads per visit step of a one-bidder-per-wave search (4 rows: 16 leaves per step)
 static_assert(kMaxNodes * kNodeFan == kMaxLeaves && kMaxNodes == kWave, "a node per lane, a leaf per lane of a row");
 
