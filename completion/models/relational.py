@@ -78,6 +78,19 @@ class SA_module(nn.Module):
         return [out + x, idx]
 
 
+class _ExactZeroGrads(torch.autograd.Function):
+    """fea unchanged; the listed parameters get gradients of exact zeros (not None)."""
+
+    @staticmethod
+    def forward(ctx, fea, *params):
+        ctx.shapes = [(p.shape, p.dtype, p.device) for p in params]
+        return fea.view_as(fea)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + tuple(torch.zeros(s, dtype=d, device=dev) for s, d, dev in ctx.shapes)
+
+
 class SK_SA_module(nn.Module):
     """Selective-kernel fusion of several SA_modules with different k."""
 
@@ -95,6 +108,14 @@ class SK_SA_module(nn.Module):
     def forward(self, input):
         x, idxs = input
         assert self.num_kernels == len(idxs)
+        if self.num_kernels == 1 and OPS.singleton_sk:
+            # ONE kernel (cfgs/vrcnet.yaml: knn_list "16"): the softmax over a stack of one is identically 1 and its
+            # gradient identically 0, so fea_v = feas[0] * 1 bit for bit and fc / fcs receive exact zeros -- the stack,
+            # its two sums, the two means and the product (six passes over a (B, C, N) tensor forward, as many backward,
+            # at every level) compute nothing (vrcnet.py:138-152).  The squeeze-excite parameters keep their exact-zero
+            # gradients (what the reference's autograd hands the optimizer and DDP's reducer).
+            fea = self.af(self.sams[0]([x, idxs[0]])[0])
+            return [_ExactZeroGrads.apply(fea, *self.fc.parameters(), *self.fcs[0].parameters()), idxs]
         # (stacking the projections of BOTH modules into one convolution measured 0.5 % slower than one per module)
         feas = torch.stack([self.af(sam([x, idx])[0]) for sam, idx in zip(self.sams, idxs)], dim=1)
         fea_z = self.fc(feas.sum(dim=1).mean(-1).mean(-1))                       # (B, d)
@@ -123,7 +144,10 @@ class SKN_Res_unit(nn.Module):
             first, res = torch.split(pointwise_conv(feat, torch.cat((self.conv1.weight, self.conv_res.weight), 0)),
                                      (self.conv1.out_channels, self.conv_res.out_channels), dim=1)
         x, _ = self.sam([first.contiguous(), idx])
-        return self.conv2(self.af(x)) + res
+        # a singleton SK module hands out relu(.) already (above): relu(relu(v)) = relu(v) in value AND in gradient (both
+        # masks are v <= 0), so the second pass and its threshold_backward are not issued
+        act = x if (OPS.singleton_sk and all(m.num_kernels == 1 for m in self.sam)) else self.af(x)
+        return self.conv2(act) + res
 
 
 class SA_SKN_Res_encoder(nn.Module):

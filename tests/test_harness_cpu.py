@@ -513,6 +513,38 @@ def test_sa_module_equals_gather_then_map_formulation():
     assert torch.allclose(g1, g2, rtol=1e-9, atol=1e-9)
 
 
+def test_singleton_sk_unit_is_bit_identical_to_the_attention_formulation():
+    """SKN_Res_unit with ONE neighbourhood size (cfgs/vrcnet.yaml: knn_list "16"): the softmax over a stack of one kernel
+    is identically 1, so op_config's `singleton_sk` route (no stack / sums / means / product, no second ReLU) must give
+    the reference formulation's (vrcnet.py:138-173) output, input gradient and every parameter gradient BIT FOR BIT --
+    exact zeros for the squeeze-excite layers included."""
+    import op_config
+    from models.relational import SKN_Res_unit
+    torch.manual_seed(11)
+    B, C, N, k = 2, 32, 48, 5
+    unit = SKN_Res_unit(16, C, k=[k], layers=2)
+    x0 = torch.randn(B, 16, 1, N)
+    idx = [torch.randint(0, N, (B, N, k))]
+    runs = {}
+    for on in (False, True):
+        old = op_config.configure(singleton_sk=on)
+        try:
+            unit.zero_grad()
+            x = x0.clone().requires_grad_()
+            out = unit(x, idx)
+            out.square().sum().backward()
+            runs[on] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in unit.named_parameters()})
+        finally:
+            op_config.configure(**old)
+    assert torch.equal(runs[True][0], runs[False][0])
+    assert torch.equal(runs[True][1], runs[False][1])
+    assert runs[True][2].keys() == runs[False][2].keys()
+    for name, grad in runs[False][2].items():
+        assert torch.equal(runs[True][2][name], grad), name
+        if ".fc." in name or ".fcs." in name:
+            assert not grad.any(), name          # the reference's autograd hands these layers exact zeros
+
+
 @pytest.mark.parametrize("dense_n", [1, 3])
 def test_dense_conv_equals_edge_tensor_formulation(dense_n):
     """Dense_conv applies the centre columns of every layer per point and
