@@ -7,7 +7,7 @@ import torch.nn as nn
 from model_utils import calc_cd, calc_emd
 from op_config import OPS
 from mm3d_pn2 import three_interpolate
-from mvp_benchmark_amd.pointwise import PointwiseConv1d, PointwiseConv2d, pointwise_conv
+from mvp_benchmark_amd.pointwise import PointwiseConv1d, PointwiseConv2d, pointwise_conv, pointwise_conv_fused
 
 
 def pointwise1d(c_in, c_out, bias=True):
@@ -38,6 +38,8 @@ def conv_global_concat(conv, global_vec, feats, relu=False, global_first=True):
     wg, wf = (w[:, :cg], w[:, cg:]) if global_first else (w[:, w.size(1) - cg:], w[:, :w.size(1) - cg])
     per_cloud = nn.functional.linear(global_vec, wg, conv.bias)
     tail = (1,) * (feats.dim() - 2)
+    if OPS.fused_activations and feats.is_cuda:          # the per-cloud vector is the GEMM's bias, the ReLU its epilogue
+        return pointwise_conv_fused(feats, wf.contiguous().view(cout, -1, *tail), None, relu=relu, cloud_bias=per_cloud)
     h = pointwise_conv(feats, wf.contiguous().view(cout, -1, *tail)) + per_cloud.view(per_cloud.shape + tail)
     return torch.relu_(h) if relu else h
 
@@ -61,8 +63,12 @@ def conv_interp_concat(conv, coarse, skip, idx, weight, interp_first=True, relu=
     wc, ws = (w[:, :cc], w[:, cc:]) if interp_first else (w[:, w.size(1) - cc:], w[:, :w.size(1) - cc])
     yc = pointwise_conv(coarse.reshape(coarse.size(0), cc, -1), wc.contiguous().unsqueeze(2))      # (B, Cout, Nc)
     y = three_interpolate(yc.contiguous(), idx, weight)                                              # (B, Cout, N)
-    h = pointwise_conv(skip.reshape(skip.size(0), skip.size(1), -1), ws.contiguous().unsqueeze(2), conv.bias) + y
-    h = torch.relu_(h) if relu else h
+    if OPS.fused_activations and skip.is_cuda:           # + interpolated half, ReLU: the GEMM's epilogue
+        h = pointwise_conv_fused(skip.reshape(skip.size(0), skip.size(1), -1), ws.contiguous().unsqueeze(2), conv.bias,
+                                 residual=y, relu_after=relu)
+    else:
+        h = pointwise_conv(skip.reshape(skip.size(0), skip.size(1), -1), ws.contiguous().unsqueeze(2), conv.bias) + y
+        h = torch.relu_(h) if relu else h
     return h.unsqueeze(2) if four_d else h
 
 

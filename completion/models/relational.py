@@ -20,7 +20,7 @@ from model_utils import (GeometryAhead, aggregate_shared, aggregate_shared_gathe
 from mm3d_pn2 import three_interpolate
 from op_config import OPS
 from models._common import conv_global_concat, conv_interp_concat, dense, pointwise2d
-from mvp_benchmark_amd.pointwise import pointwise_conv
+from mvp_benchmark_amd.pointwise import pointwise_conv, pointwise_conv_dual, pointwise_conv_fused
 
 
 class SA_module(nn.Module):
@@ -50,16 +50,24 @@ class SA_module(nn.Module):
                 torch.cat((self.conv1.bias, self.conv2.bias, self.conv3.bias), 0),
                 (self.conv1.out_channels, self.conv2.out_channels, self.conv3.out_channels))
 
-    def forward(self, input):
+    def forward(self, input, relu_out=False):
+        """[conv_out(...) + x, idx] (vrcnet.py:36-57); relu_out: the ReLU the caller applies to it (SK_SA_module, :139)
+        rides in conv_out's epilogue."""
         x, idx = input                                   # x: (B, C, 1, N), idx: (B, N, k)
         batch_size, _, _, num_points = x.size()
+        # round 6: relu(x), relu(cat), relu(out) are taken on LOAD by the convolutions that consume them and `+ x` (then
+        # the caller's ReLU) is conv_out's epilogue (pointwise_conv_fused; elsewhere the same ops one by one)
+        fused = OPS.fused_activations and x.is_cuda
         # The reference gathers the k neighbours' C-channel features first and maps
         # the (B, C, k, N) tensor with conv2 / conv3.  A per-point linear map commutes
         # with the gather, so map the N points once (k times fewer multiply-adds, no
         # (B, C, k, N) intermediate) and gather the r and the mid mapped channels;
         # same parameters, same result up to fp32 summation order.
         idx_t = neighbour_lists_k_major(idx) if x.is_cuda else None         # one index tensor for both gathers
-        if not OPS.stacked_projections:                   # A/B: conv1 / conv2 / conv3 as three convolutions
+        if fused and OPS.stacked_projections:
+            weight, bias, sizes = self.projection()
+            query, key_pts, val_pts = torch.split(pointwise_conv_fused(x, weight, bias, relu_in=True), sizes, dim=1)
+        elif not OPS.stacked_projections:                 # A/B: conv1 / conv2 / conv3 as three convolutions
             act = self.activation_fn(x)
             query, key_pts, val_pts = self.conv1(act), self.conv2(act), self.conv3(act)
         else:
@@ -68,14 +76,20 @@ class SA_module(nn.Module):
         keys = get_edge_features(key_pts, idx, idx_t).reshape(batch_size, -1, 1, num_points)   # (B, r*k, 1, N), channel = r_i*k + k_i
 
         # conv_w = ReLU, conv, ReLU, conv (vrcnet.py:28-33): the inner ReLU rides in the first convolution's epilogue
-        t = self.conv_w[0](torch.cat([query, keys], 1))
-        w = self.conv_w[3](self.conv_w[1](t, relu=True))  # (B, k*mid/share, 1, N)
+        if fused:
+            hidden = pointwise_conv_fused(torch.cat([query, keys], 1), self.conv_w[1].weight, None, relu_in=True, relu=True)
+        else:
+            hidden = self.conv_w[1](self.conv_w[0](torch.cat([query, keys], 1)), relu=True)
+        w = self.conv_w[3](hidden)                        # (B, k*mid/share, 1, N)
         # weights are shared by the `share_planes` channel groups; the neighbours' values (conv3's output at the k
         # neighbours of every point) are gathered and summed in ONE kernel: no (B, mid, k, N) tensor, no repeat / product
         out = aggregate_shared_gathered(w.view(batch_size, -1, self.k, num_points), val_pts, idx, self.share_planes, idx_t)
         out = out.view(batch_size, -1, 1, num_points)
-        out = self.conv_out(self.activation_fn(out))     # (B, C_out, 1, N)
-        return [out + x, idx]
+        if fused:
+            return [pointwise_conv_fused(out, self.conv_out.weight, self.conv_out.bias, relu_in=True, residual=x,
+                                         relu_after=relu_out), idx]
+        out = self.conv_out(self.activation_fn(out)) + x  # (B, C_out, 1, N)
+        return [self.activation_fn(out) if relu_out else out, idx]
 
 
 class _ExactZeroGrads(torch.autograd.Function):
@@ -114,7 +128,7 @@ class SK_SA_module(nn.Module):
             # its two sums, the two means and the product (six passes over a (B, C, N) tensor forward, as many backward,
             # at every level) compute nothing (vrcnet.py:138-152).  The squeeze-excite parameters keep their exact-zero
             # gradients (what the reference's autograd hands the optimizer and DDP's reducer).
-            fea = self.af(self.sams[0]([x, idxs[0]])[0])
+            fea = self.sams[0]([x, idxs[0]], relu_out=True)[0]
             return [_ExactZeroGrads.apply(fea, *self.fc.parameters(), *self.fcs[0].parameters()), idxs]
         # (stacking the projections of BOTH modules into one convolution measured 0.5 % slower than one per module)
         feas = torch.stack([self.af(sam([x, idx])[0]) for sam, idx in zip(self.sams, idxs)], dim=1)
@@ -137,8 +151,13 @@ class SKN_Res_unit(nn.Module):
         return nn.Sequential(*[SK_SA_module(in_planes, rel_planes, mid_planes, out_planes, share_planes, k)
                                for _ in range(blocks)])
 
-    def forward(self, feat, idx):
-        if not OPS.stacked_projections:
+    def forward(self, feat, idx, relu_out=False):
+        """conv2(relu(sam(conv1(feat)))) + conv_res(feat) (vrcnet.py:169-173); relu_out: the encoder's ReLU of it (:255-270)
+        in conv2's epilogue."""
+        fused = OPS.fused_activations and feat.is_cuda
+        if fused and OPS.stacked_projections:             # one GEMM, two contiguous outputs: no split views, no copy
+            first, res = pointwise_conv_dual(feat, self.conv1.weight, self.conv_res.weight)
+        elif not OPS.stacked_projections:
             first, res = self.conv1(feat), self.conv_res(feat)
         else:                                             # conv1 and conv_res read the same input: one convolution
             first, res = torch.split(pointwise_conv(feat, torch.cat((self.conv1.weight, self.conv_res.weight), 0)),
@@ -147,7 +166,10 @@ class SKN_Res_unit(nn.Module):
         # a singleton SK module hands out relu(.) already (above): relu(relu(v)) = relu(v) in value AND in gradient (both
         # masks are v <= 0), so the second pass and its threshold_backward are not issued
         act = x if (OPS.singleton_sk and all(m.num_kernels == 1 for m in self.sam)) else self.af(x)
-        return self.conv2(act) + res
+        if fused:
+            return pointwise_conv_fused(act, self.conv2.weight, None, residual=res, relu_after=relu_out)
+        out = self.conv2(act) + res
+        return self.af(out) if relu_out else out
 
 
 class SA_SKN_Res_encoder(nn.Module):
@@ -223,11 +245,11 @@ class SA_SKN_Res_encoder(nn.Module):
             geo.run(("up", level), lambda: three_nn_upsampling(pts[level], pts[level + 1]), lane=1,
                     after=[("pts", 0)] + [("centres", l) for l in (level, level + 1) if l > 0])
 
-        skips = [self.af(units[0](features.unsqueeze(2), geo.take(("graph", 0))))]
+        skips = [units[0](features.unsqueeze(2), geo.take(("graph", 0)), relu_out=True)]
         for level in range(1, 4):
             p_idx, pn_idx, _ = geo.take(("pool", level))
             x = edge_preserve_features(skips[-1].squeeze(2).contiguous(), p_idx, pn_idx).unsqueeze(2)
-            skips.append(self.af(units[level](x, geo.take(("graph", level)))))
+            skips.append(units[level](x, geo.take(("graph", level)), relu_out=True))
 
         g = self.conv5.max_over_positions(skips[3])        # conv5(skips[3]).max over the points, sparse backward
         g = self.dropout(self.af(self.fc2(self.dropout(self.af(self.fc1(g))))))

@@ -10,13 +10,15 @@ by tests/test_model_golden.py); the defaults are the measured-faster ones (DESIG
   skip_full_fps_of_gt  VRCNet training: no FPS of ALL of gt's points in front of the order-blind PCN_encoder
   conv_before_interp   the way up of the U-Nets: the interpolated half convolved at the coarse level
   folded_conv          folding layers as three small products instead of tile / repeat / concatenate / convolve
+  fused_activations    pre-activation ReLUs, residual sums + ReLU and per-cloud vectors inside the convolutions' GEMMs
+                       (mvp_pointwise_mfma_ex), a residual unit's conv1 / conv_res as one GEMM with two outputs
   singleton_sk         SK_SA_module with ONE kernel (the shipped cfg): attention == 1 exactly, the fusion passes not issued
 """
 
 
 class OpLayerConfig:
     __slots__ = ("gather_sum", "gather_max", "side_lanes", "stacked_projections", "skip_full_fps_of_gt",
-                 "conv_before_interp", "folded_conv", "singleton_sk")
+                 "conv_before_interp", "folded_conv", "singleton_sk", "fused_activations")
 
     def __init__(self):
         self.reset()
@@ -30,6 +32,7 @@ class OpLayerConfig:
         self.conv_before_interp = True
         self.folded_conv = True
         self.singleton_sk = True
+        self.fused_activations = True
 
     def as_dict(self):
         return {k: getattr(self, k) for k in self.__slots__}

@@ -43,7 +43,7 @@ extern "C" {
 #define MVP_ELAUNCH (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define MVP_ABI_VERSION 17
+#define MVP_ABI_VERSION 18
 int mvp_abi_version(void);
 
 /* hipGetErrorString of the last launch failure seen on the calling thread
@@ -455,6 +455,33 @@ int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float *x,
                        const float *bias, const float *residual, int relu,
                        int group, float *y, void *stream);
 
+/* ABI 18.  The same map with the activation / residual patterns of the relational encoder in the GEMM's
+ * prologue and epilogue, so that `conv(relu(x))`, `relu(conv(a) + x)`, `relu(conv(f) + g[b])` and two
+ * convolutions of one input cost no elementwise pass and no copy (completion/models/vrcnet.py:34-36,54-57
+ * pre-activation ReLUs of SA_module; :151,172 and :255-296 residual sums followed by ReLU; :283-285 conv6 over
+ * cat(global feature tiled, features); :160,172 conv1 / conv_res of one input).  mvp_pointwise_mfma is this call
+ * with bias_per_cloud = 0, flags = relu ? MVP_PW_RELU : 0, m_split = 0.
+ *   flags  MVP_PW_X_RELU       x counts as max(x, 0) (on load; x itself is not written)
+ *          MVP_PW_RELU         t = max(t, 0) before the group maximum and the residual (mvp_pointwise_mfma's relu)
+ *          MVP_PW_RES_IS_MASK  `residual` is a mask: y = residual > 0 ? u : 0 instead of u + residual -- the data
+ *                              gradient of conv(relu(x)): W^T grad_out where x > 0
+ *          MVP_PW_RELU_AFTER   y = max(y, 0) after the residual / mask
+ *   bias_per_cloud != 0: bias is (b, cout) -- the share of a per-cloud vector in a convolution over
+ *          cat(vector tiled over the positions, features) -- instead of (cout)
+ *   m_split (0, or a multiple of 32 below cout; then residual == NULL, group == 1, y2 != NULL): output rows below
+ *          m_split go to y (b, m_split, len), the others to y2 (b, cout - m_split, len).
+ * Arithmetic: the same k-ordered fmaf chain per output as mvp_pointwise_mfma; every fused step is the exact
+ * float operation the separate pass would perform (max, add, select). */
+#define MVP_PW_RELU 1
+#define MVP_PW_RELU_AFTER 2
+#define MVP_PW_RES_IS_MASK 4
+#define MVP_PW_X_RELU 8
+int mvp_pointwise_mfma_ex(int b, int cin, int cout, int len, const float *x,
+                          const float *xmask, const float *w, int ldw, int w_kmajor,
+                          const float *bias, int bias_per_cloud, const float *residual,
+                          int flags, int group, float *y, int m_split, float *y2,
+                          void *stream);
+
 /* ABI 16.  (W x + bias) [then ReLU], reduced with max over ALL positions of a cloud inside the GEMM's epilogue
  * -- the PointNet stage of the completion networks: `x = self.conv4(x); global_feature, _ = torch.max(x, 2)`
  * (completion/models/pcn.py:29-30; vrcnet.py:281-282 conv5; ecg.py:137-138 gf_conv) -- without writing the
@@ -480,6 +507,12 @@ int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const float *x,
                              const float *gy, const float *gymask, float *gw,
                              float *gb, void *scratch, long long scratch_bytes,
                              void *stream);
+/* ABI 18.  x_relu != 0: x counts as max(x, 0) on load -- the weight gradient of conv(relu(x)) from the
+ * tensor the layer was handed, not from a stored relu(x). */
+int mvp_pointwise_wgrad_mfma_ex(int b, int cin, int cout, int len, const float *x, int x_relu,
+                                const float *gy, const float *gymask, float *gw,
+                                float *gb, void *scratch, long long scratch_bytes,
+                                void *stream);
 
 /* Backward pass of a 1x1 convolution followed by a max over the positions,
  * v[b][co] = max_l (W x + bias)[b][co][l] (the PointNet stage: completion/models/pcn.py:25-31,

@@ -53,14 +53,16 @@ SIGNATURES = {
     "mvp_pointwise_dgrad": "iiiippp",
     "mvp_kabsch_svd3": "ipppppp",
     "mvp_pointwise_mfma": "iiiipppiippiip",
+    "mvp_pointwise_mfma_ex": "iiiipppiipipiipip",
     "mvp_pointwise_wgrad_mfma": "iiiippppppq",
+    "mvp_pointwise_wgrad_mfma_ex": "iiiipipppppq",
     "mvp_pointwise_max_backward": "iiiippppppppq",
     "mvp_pointwise_mfma_max": "iiiippipipppq",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "q": ctypes.c_longlong}
 
-ABI_VERSION = 17  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
+ABI_VERSION = 18  # MVP_ABI_VERSION of include/mvpops.h this binding was written against
 
 # default of mvp_emd_configure's `split` knob (csrc/emd.hip: emd_knobs)
 EMD_DEFAULT_SPLIT = 5

@@ -107,8 +107,10 @@ __device__ __forceinline__ void pw_fetch(PwRegs<BX * BK / 4 / kMmThreads> &r,
   }
 }
 
-// registers -> LDS image (16-byte stores); with MASK, a value counts as 0 where its mask is <= 0
-template <int BX, int BK, int MODE, bool MASK>
+// registers -> LDS image (16-byte stores); with MASK, a value counts as 0 where its mask is <= 0; with SELF_RELU
+// (round 6; a template parameter: as a run-time flag it cost the forward kernel 16 %) where it is < 0 itself: the operand is relu(.) of what lies in memory -- a pre-activation
+// ReLU (vrcnet.py:34,54: conv(relu(x))) costs no pass over x and no second tensor
+template <int BX, int BK, int MODE, bool MASK, bool SELF_RELU = false>
 __device__ __forceinline__ void pw_stash(float *img, const PwRegs<BX * BK / 4 / kMmThreads> &r,
                                          const PwRegs<MASK ? BX * BK / 4 / kMmThreads : 1> &rm, int t) {
   constexpr int V = PwImg<BX, BK, MODE>::vecs, LD = PwImg<BX, BK, MODE>::ld;
@@ -116,6 +118,12 @@ __device__ __forceinline__ void pw_stash(float *img, const PwRegs<BX * BK / 4 / 
   for (int i = 0; i < V; ++i) {
     const int q = t + i * kMmThreads;
     float4 v = r.v[i];
+    if constexpr (SELF_RELU) {                 // (a select, not fmaxf: a NaN stays a NaN, as torch.relu leaves it)
+      v.x = v.x < 0.f ? 0.f : v.x;
+      v.y = v.y < 0.f ? 0.f : v.y;
+      v.z = v.z < 0.f ? 0.f : v.z;
+      v.w = v.w < 0.f ? 0.f : v.w;
+    }
     if constexpr (MASK) {
       v.x = rm.v[i].x > 0.f ? v.x : 0.f;
       v.y = rm.v[i].y > 0.f ? v.y : 0.f;
@@ -202,14 +210,20 @@ __device__ __forceinline__ long long pw_work_item(long long total) {
 // 64 x 1024 x 2048).  `y` then is a (nb, M) array of 64-bit keys {order-preserving bits of the value | ~column}, zeroed by the
 // caller; a tile's rows join by one 64-bit atomic max per row and half-wave (the lanes that hold the half-wave's maximum
 // issue it: ties go to the smallest column), pointwise_rowmax_unpack_kernel turns the keys into values and positions.
-template <int TM, int TN, int BK, int AMODE, bool MASKED, bool ROWMAX = false>
-__global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
+// (waves_per_eu: the residual / two-output epilogue of round 6 would otherwise lift the allocation from 168 to 188 VGPRs
+// -- two workgroups per CU instead of three for EVERY call, 0.4 ms of a VRCNet step)
+template <int TM, int TN, int BK, int AMODE, bool MASKED, bool ROWMAX = false, bool XRELU = false>
+__global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(TM == 2 ? 3 : 5))) void pointwise_mfma_kernel(
     int M, int N, int K, int nb, const float *__restrict__ a, int a_ld, int a_vec, const float *__restrict__ x,
-    const float *__restrict__ xmask, const float *__restrict__ bias, const float *__restrict__ residual, int relu,
-    int group, float *__restrict__ y) {
+    const float *__restrict__ xmask, const float *__restrict__ bias, const float *__restrict__ residual, int flags,
+    int group, float *__restrict__ y, int bias_bs = 0, int m_split = 0, float *__restrict__ y2 = nullptr) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   using IA = PwImg<BM, BK, AMODE>;
   using IB = PwImg<BN, BK, kXC>;
+  // flags (mvpops.h MVP_PW_*): ReLU before the residual | ReLU after it | the residual is a MASK (the value counts as 0
+  // where it is <= 0: the data gradient of conv(relu(x))) | ReLU of x on load
+  const bool relu = (flags & 1) != 0, relu_after = (flags & 2) != 0, res_is_mask = (flags & 4) != 0;
+  static_assert(!(XRELU && MASKED), "ReLU of x on load and a mask on x are not combined");
   __shared__ __attribute__((aligned(16))) float As[2][IA::floats];
   __shared__ __attribute__((aligned(16))) float Bs[2][IB::floats];
   __shared__ float sbias[BM];
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
   const float *mb = xmask ? xmask + (size_t)cloud * K * N : nullptr;
   const size_t lda = a_ld;
 
-  if (t < BM) sbias[t] = (bias && m0 + t < M) ? bias[m0 + t] : 0.f;
+  if (t < BM) sbias[t] = (bias && m0 + t < M) ? bias[(size_t)cloud * bias_bs + m0 + t] : 0.f;   // bias_bs = M: a bias per cloud
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
   pw_fetch<BM, BK, AMODE, false>(ra, rnone, a, nullptr, lda, m0, M, 0, K, a_vec != 0, t);
   pw_fetch<BN, BK, kXC, MASKED>(rb, rbm, xb, mb, N, n0, N, 0, K, true, t);
   pw_stash<BM, BK, AMODE, false>(As[0], ra, rnone, t);
-  pw_stash<BN, BK, kXC, MASKED>(Bs[0], rb, rbm, t);
+  pw_stash<BN, BK, kXC, MASKED, XRELU>(Bs[0], rb, rbm, t);
   __syncthreads();
   for (int s = 0; s < nk; ++s) {
     const int buf = s & 1;
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
         // the next slab goes into the other buffer (nobody reads it in this step) while the matrix
         // core works through the instructions issued so far: the stores' latency is covered
         pw_stash<BM, BK, AMODE, false>(As[buf ^ 1], ra, rnone, t);
-        pw_stash<BN, BK, kXC, MASKED>(Bs[buf ^ 1], rb, rbm, t);
+        pw_stash<BN, BK, kXC, MASKED, XRELU>(Bs[buf ^ 1], rb, rbm, t);
       }
     }
     if (s + 1 < nk) __syncthreads();
@@ -308,9 +322,11 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
     return;
   }
   const int len_out = N / group;
-  float *yb = y + (size_t)cloud * M * len_out;
   const float *rbse = residual ? residual + (size_t)cloud * M * len_out : nullptr;
-  if (group == 1 && !rbse) {                             // the common case: straight-line
+  const bool split = m_split > 0 && m_split < M;
+  if (group == 1 && !rbse && !split) {                   // the common case: straight-line
+    float *yb = y + (size_t)cloud * M * N;
+    const bool relu_any = relu || relu_after;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float bv[16];                                      // the rows' biases first: independent LDS reads, one wait
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
             float v = acc[i][j][r] + bv[r];
-            v = relu ? __builtin_fmaxf(v, 0.f) : v;
+            v = relu_any ? __builtin_fmaxf(v, 0.f) : v;
             if (dr < rows_left) yc[(size_t)dr * N] = v;
           }
         }
@@ -334,6 +350,51 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
     }
     return;
   }
+  if (group == 1) {
+    // round 6: + residual (or the residual as a mask) and a second ReLU, or two outputs -- straight-line like the common
+    // case, a block's 16 residual values fetched before the first is used.  Two outputs (convolutions of ONE input stacked
+    // along the output channels -- a residual unit's conv1 / conv_res, vrcnet.py:160-172 -- hand each consumer a contiguous
+    // tensor, no torch.split views and no copy): rows below m_split go to y (m_split rows per cloud), the others to y2
+    // (M - m_split rows); m_split % 32 == 0, so a 32-row MFMA block lies on one side.
+    const int ms = split ? m_split : M;
+    float *y1b = y + (size_t)cloud * ms * N;
+    float *y2b = split ? y2 + ((size_t)cloud * (M - ms) - (size_t)ms) * N : y1b;     // indexed by the global row
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float bv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[r] = sbias[wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk];
+      const int blk = m0 + wm * 32 * TM + i * 32;        // first row of this 32-row block
+      float *yb = blk < ms ? y1b : y2b;
+      const int rows_left = (blk < ms ? ms : M) - (blk + 4 * lk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + j * 32 + lrow;
+        const size_t o0 = (size_t)(blk + 4 * lk) * N + col;
+        if (col < N) {
+          float rv[16];
+          if (rbse) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int dr = (r & 3) + 8 * (r >> 2);
+              rv[r] = dr < rows_left ? rbse[o0 + (size_t)dr * N] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            float v = acc[i][j][r] + bv[r];
+            v = relu ? __builtin_fmaxf(v, 0.f) : v;
+            if (rbse) v = res_is_mask ? (rv[r] > 0.f ? v : 0.f) : v + rv[r];
+            v = relu_after ? __builtin_fmaxf(v, 0.f) : v;
+            if (dr < rows_left) yb[o0 + (size_t)dr * N] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+  float *yb = y + (size_t)cloud * M * len_out;             // groups of columns reduced with max (no split: checked by the host)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -345,13 +406,15 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
         const int row = m0 + lr;
         float v = acc[i][j][r] + sbias[lr];
         if (relu) v = __builtin_fmaxf(v, 0.f);
-        if (group > 1) {
-          if (col >= N) v = -__builtin_inff();            // (N % group == 0: a group is inside or outside)
-          for (int off = 1; off < group; off <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
-        }
+        if (col >= N) v = -__builtin_inff();              // (N % group == 0: a group is inside or outside)
+        for (int off = 1; off < group; off <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
         if (row < M && col < N && (lrow & (group - 1)) == 0) {
           const size_t o = (size_t)row * len_out + col / group;
-          if (rbse) v += rbse[o];
+          if (rbse) {
+            const float rv = rbse[o];
+            v = res_is_mask ? (rv > 0.f ? v : 0.f) : v + rv;
+          }
+          if (relu_after) v = __builtin_fmaxf(v, 0.f);
           yb[o] = v;
         }
       }
@@ -366,11 +429,11 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_mfma_kernel(
 // workgroups, equal work, no tail); each writes its partial tile, a second kernel adds the partials in a fixed
 // order (no float atomics: reproducible).  The bias gradient is the row sum of the staged g tile, taken from
 // LDS by the workgroups of the first column of tiles.  Both operands are k-contiguous.
-template <int TM, int TN, int BK, bool MASKED>
+template <int TM, int TN, int BK, bool MASKED, bool XRELU = false>
 __global__ __launch_bounds__(kMmThreads) void pointwise_wgrad_mfma_kernel(
     int nb, int cin, int cout, int len, int slabs_per_cloud, int slabs_per_split, int splits,
     const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ gmask, int with_bias,
-    float *__restrict__ partial, float *__restrict__ pbias) {
+    float *__restrict__ partial, float *__restrict__ pbias) {   // XRELU: the layer was conv(relu(x)): x counts as relu(x)
   constexpr int BM = 64 * TM, BN = 64 * TN;
   using IA = PwImg<BM, BK, kKC>;
   using IB = PwImg<BN, BK, kKC>;
@@ -413,7 +476,7 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_wgrad_mfma_kernel(
   if (s_begin < s_end) {
     fetch(s_begin);
     pw_stash<BM, BK, kKC, MASKED>(As[0], ra, ram, t);
-    pw_stash<BN, BK, kKC, false>(Bs[0], rb, rnone, t);
+    pw_stash<BN, BK, kKC, false, XRELU>(Bs[0], rb, rnone, t);
   }
   __syncthreads();
   for (int s = s_begin; s < s_end; ++s) {
@@ -427,7 +490,7 @@ __global__ __launch_bounds__(kMmThreads) void pointwise_wgrad_mfma_kernel(
       pw_mma<TM, TN>(acc, av, bv);
       if (kg == kPwStashAt(BK / 8, true) && s + 1 < s_end) {
         pw_stash<BM, BK, kKC, MASKED>(As[buf ^ 1], ra, ram, t);
-        pw_stash<BN, BK, kKC, false>(Bs[buf ^ 1], rb, rnone, t);
+        pw_stash<BN, BK, kKC, false, XRELU>(Bs[buf ^ 1], rb, rnone, t);
       }
     }
     if (do_bias) {
@@ -536,6 +599,12 @@ extern "C" long long mvp_pointwise_wgrad_mfma_scratch_bytes(int b, int cin, int 
 extern "C" int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const float *x, const float *gy,
                                         const float *gymask, float *gw, float *gb, void *scratch,
                                         long long scratch_bytes, void *stream) {
+  return mvp_pointwise_wgrad_mfma_ex(b, cin, cout, len, x, 0, gy, gymask, gw, gb, scratch, scratch_bytes, stream);
+}
+
+extern "C" int mvp_pointwise_wgrad_mfma_ex(int b, int cin, int cout, int len, const float *x, int x_relu, const float *gy,
+                                           const float *gymask, float *gw, float *gb, void *scratch,
+                                           long long scratch_bytes, void *stream) {
   const int with_bias = gb != nullptr;
   const long long need = mvp_pointwise_wgrad_mfma_scratch_bytes(b, cin, cout, len, with_bias);
   if (need == 0) return MVP_EBADSHAPE;
@@ -551,13 +620,15 @@ extern "C" int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const
   const long long total = (long long)((cout + bm - 1) / bm) * ((cin + bn - 1) / bn) * splits;
   const long long nwg = (total + 7) / 8 * 8;
   if (nwg > 2147483647LL) return MVP_EBADSHAPE;
-#define MVP_WG_(TM, TN, MK)                                                                                             \
-  hipLaunchKernelGGL((pointwise_wgrad_mfma_kernel<TM, TN, kWgBK, MK>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, b, \
+#define MVP_WG_(TM, TN, MK, XR)                                                                                             \
+  hipLaunchKernelGGL((pointwise_wgrad_mfma_kernel<TM, TN, kWgBK, MK, XR>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, b, \
                      cin, cout, len, spc, sps, splits, x, gy, gymask, with_bias, partial, pbias)
-#define MVP_WG(TM, TN)              \
-  do {                              \
-    if (gymask) MVP_WG_(TM, TN, true); \
-    else MVP_WG_(TM, TN, false);    \
+#define MVP_WG(TM, TN)                                \
+  do {                                                \
+    if (gymask && x_relu) MVP_WG_(TM, TN, true, true);   \
+    else if (gymask) MVP_WG_(TM, TN, true, false);       \
+    else if (x_relu) MVP_WG_(TM, TN, false, true);       \
+    else MVP_WG_(TM, TN, false, false);                  \
   } while (0)
   if (bm == 128) {
     if (bn == 128) MVP_WG(2, 2);
@@ -574,10 +645,25 @@ extern "C" int mvp_pointwise_wgrad_mfma(int b, int cin, int cout, int len, const
   return check_launch("mvp_pointwise_wgrad_mfma");
 }
 
+
 extern "C" int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float *x, const float *xmask,
                                   const float *w, int ldw, int w_kmajor, const float *bias, const float *residual,
                                   int relu, int group, float *y, void *stream) {
+  return mvp_pointwise_mfma_ex(b, cin, cout, len, x, xmask, w, ldw, w_kmajor, bias, 0, residual, relu ? MVP_PW_RELU : 0,
+                               group, y, 0, nullptr, stream);
+}
+
+extern "C" int mvp_pointwise_mfma_ex(int b, int cin, int cout, int len, const float *x, const float *xmask,
+                                     const float *w, int ldw, int w_kmajor, const float *bias, int bias_per_cloud,
+                                     const float *residual, int flags, int group, float *y, int m_split, float *y2,
+                                     void *stream) {
   if (b < 0 || cin <= 0 || cout <= 0 || len < 0) return MVP_EBADSHAPE;
+  if ((flags & ~(MVP_PW_RELU | MVP_PW_RELU_AFTER | MVP_PW_RES_IS_MASK | MVP_PW_X_RELU)) != 0) return MVP_EBADARG;
+  if ((flags & MVP_PW_RES_IS_MASK) && !residual) return MVP_EBADARG;
+  if ((flags & MVP_PW_X_RELU) && xmask) return MVP_EBADARG;
+  if (m_split != 0 && (m_split < 0 || m_split >= cout || (m_split & 31) != 0 || !y2 || residual || group != 1)) return MVP_EBADARG;
+  if (bias_per_cloud && !bias) return MVP_EBADARG;
+  const int bias_bs = bias_per_cloud ? cout : 0;
   if (group < 1 || group > 32 || (group & (group - 1)) != 0) return MVP_EBADSHAPE;
   if ((len & 3) != 0 || len % group != 0 || b > 65535) return MVP_EBADSHAPE;
   if (b == 0 || len == 0) return MVP_OK;
@@ -594,13 +680,14 @@ extern "C" int mvp_pointwise_mfma(int b, int cin, int cout, int len, const float
   const long long nwg = (total + 7) / 8 * 8;
   if (nwg > 2147483647LL) return MVP_EBADSHAPE;
   const int a_vec = w_kmajor ? 1 : ((ldw & 3) == 0);            // 16-byte loads along k need aligned rows
-#define MVP_MM_(TM, MODE, MK)                                                                                       \
-  hipLaunchKernelGGL((pointwise_mfma_kernel<TM, 2, 16, MODE, MK>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, cout, \
-                     len, cin, b, w, ldw, a_vec, x, xmask, bias, residual, relu, group, y)
-#define MVP_MM(TM, MODE)              \
-  do {                                \
-    if (xmask) MVP_MM_(TM, MODE, true); \
-    else MVP_MM_(TM, MODE, false);    \
+#define MVP_MM_(TM, MODE, MK, XR)                                                                                       \
+  hipLaunchKernelGGL((pointwise_mfma_kernel<TM, 2, 16, MODE, MK, false, XR>), dim3((unsigned)nwg), dim3(kMmThreads), 0, st, cout, \
+                     len, cin, b, w, ldw, a_vec, x, xmask, bias, residual, flags, group, y, bias_bs, m_split, y2)
+#define MVP_MM(TM, MODE)                                             \
+  do {                                                               \
+    if (xmask) MVP_MM_(TM, MODE, true, false);                       \
+    else if (flags & MVP_PW_X_RELU) MVP_MM_(TM, MODE, false, true);  \
+    else MVP_MM_(TM, MODE, false, false);                            \
   } while (0)
   if (big) {
     if (w_kmajor) MVP_MM(2, kXC);

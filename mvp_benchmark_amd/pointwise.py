@@ -90,16 +90,26 @@ def _mfma_ok(x, cin, cout, weight=None):
         and x.data_ptr() % 16 == 0
 
 
-def mfma_linear(x, w2d, bias=None, relu=False, residual=None, group=1, w_kmajor=False, xmask=None):
+PW_RELU, PW_RELU_AFTER, PW_RES_IS_MASK, PW_X_RELU = 1, 2, 4, 8     # include/mvpops.h MVP_PW_*
+
+
+def mfma_linear(x, w2d, bias=None, relu=False, residual=None, group=1, w_kmajor=False, xmask=None, x_relu=False,
+                relu_after=False, res_is_mask=False, bias_per_cloud=False, m_split=0):
     """y = epilogue(W x) for x (B, Cin, ...) contiguous float32 CUDA, W = w2d (Cout, Cin) -- or its
-    transpose (Cin, Cout) with w_kmajor; with xmask, x counts as 0 where xmask <= 0.  Epilogue
-    (mvp_pointwise_mfma): + bias, ReLU, max over groups of `group` consecutive positions of the
-    flattened trailing dimensions, + residual.  No autograd."""
+    transpose (Cin, Cout) with w_kmajor; with xmask, x counts as 0 where xmask <= 0; with x_relu where it is
+    <= 0 itself.  Epilogue (mvp_pointwise_mfma_ex): + bias (one per cloud with bias_per_cloud: (B, Cout)), ReLU,
+    max over groups of `group` consecutive positions of the flattened trailing dimensions, + residual (or, with
+    res_is_mask, zero where residual <= 0), ReLU again with relu_after.  m_split > 0: two outputs, the rows below
+    m_split and the others -> (y, y2).  No autograd."""
     B = x.size(0)
     cin = x.size(1)
     cout = w2d.size(1) if w_kmajor else w2d.size(0)
     length = x[0, 0].numel()
-    if group == 1:
+    y2 = None
+    if m_split:
+        y = torch.empty((B, m_split) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        y2 = torch.empty((B, cout - m_split) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    elif group == 1:
         y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     else:
         y = torch.empty(B, cout, length // group, dtype=torch.float32, device=x.device)
@@ -109,21 +119,23 @@ def mfma_linear(x, w2d, bias=None, relu=False, residual=None, group=1, w_kmajor=
         # folding layer at 16384 points: 5.49 -> 4.7 ms; the copy is 2 MB)
         w2d = F.pad(w2d, (0, -cin % 4))
         ldw = w2d.size(1)
-    call("mvp_pointwise_mfma", x.device, B, cin, cout, length, x, xmask, w2d, ldw, int(w_kmajor), bias, residual,
-         int(relu), int(group), y)
-    return y
+    flags = (PW_RELU if relu else 0) | (PW_RELU_AFTER if relu_after else 0) | (PW_RES_IS_MASK if res_is_mask else 0) \
+        | (PW_X_RELU if x_relu else 0)
+    call("mvp_pointwise_mfma_ex", x.device, B, cin, cout, length, x, xmask, w2d, ldw, int(w_kmajor), bias, int(bias_per_cloud),
+         residual, flags, int(group), y, int(m_split), y2)
+    return (y, y2) if m_split else y
 
 
-def mfma_wgrad(x, gy, cout, cin, with_bias, gymask=None):
+def mfma_wgrad(x, gy, cout, cin, with_bias, gymask=None, x_relu=False):
     """(gw (Cout, Cin), gb (Cout) | None) of y = W x + b from x (B, Cin, ...) and gy (B, Cout, ...);
-    with gymask, gy counts as 0 where gymask <= 0 (mvp_pointwise_wgrad_mfma)."""
+    with gymask, gy counts as 0 where gymask <= 0; with x_relu, x as 0 where it is <= 0 (mvp_pointwise_wgrad_mfma_ex)."""
     B = x.size(0)
     length = x[0, 0].numel()
     nbytes = pointwise_wgrad_mfma_scratch_bytes(B, cin, cout, length, with_bias)
     scratch = _wgrad_scratch(x.device, nbytes)     # stream-ordered reuse: the reduce kernel has read it before the next call writes
     gw = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
     gb = torch.empty(cout, dtype=torch.float32, device=x.device) if with_bias else None
-    call("mvp_pointwise_wgrad_mfma", x.device, B, cin, cout, length, x, gy, gymask, gw, gb, scratch, nbytes)
+    call("mvp_pointwise_wgrad_mfma_ex", x.device, B, cin, cout, length, x, int(x_relu), gy, gymask, gw, gb, scratch, nbytes)
     return gw, gb
 
 
@@ -227,6 +239,133 @@ def pointwise_conv(x, weight, bias=None, relu=False):
         return mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
     y = conv(x, weight, bias)
     return torch.relu(y) if relu else y
+
+
+def _fused_routes(x, weight, need_x):
+    """All three passes of a layer on the MFMA kernels (the fused prologues / epilogues live there only)?"""
+    cout, cin = weight.shape[:2]
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous()
+            and weight.is_contiguous() and x.numel() > 0 and _mfma_fwd(x, cin, cout, weight)):
+        return False
+    B, length = x.size(0), x[0, 0].numel()
+    if need_x and not (cin % 4 == 0 and _gemm_fits(B, cin, cout, length)):
+        return False
+    return B * length >= MFMA_WGRAD_MIN_POSITIONS and pointwise_wgrad_mfma_scratch_bytes(B, cin, cout, length, True) > 0
+
+
+class _PointwiseConvFused(Function):
+    """y = act2(act1(W in(x) + bias + cloud_bias[b]) + residual) with in = ReLU if relu_in, act1 = ReLU if relu, act2 = ReLU
+    if relu_after, in ONE GEMM (mvp_pointwise_mfma_ex): the pre-activation ReLUs, residual sums and per-cloud vectors of the
+    relational encoder (vrcnet.py:34-57, 151, 172, 283-296) cost no elementwise pass forward.  Backward: ONE pass masks
+    grad_out by the output where a residual or a per-cloud bias needs the masked tensor itself (otherwise the GEMMs mask on
+    load), the data gradient masks its output by x > 0 in its epilogue, the weight gradient takes relu(x) on load."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cloud_bias, residual, relu_in, relu, relu_after):
+        cout, cin = weight.shape[:2]
+        b = bias
+        per_cloud = False
+        if cloud_bias is not None:
+            b = cloud_bias if bias is None else cloud_bias + bias          # (B, Cout): tiny
+            per_cloud = True
+        y = mfma_linear(x, weight.view(cout, cin), b, relu=relu, residual=residual, x_relu=relu_in, relu_after=relu_after,
+                        bias_per_cloud=per_cloud)
+        ctx.has_bias, ctx.has_cloud_bias, ctx.has_residual = bias is not None, cloud_bias is not None, residual is not None
+        ctx.relu_in, ctx.relu_out = relu_in, relu or relu_after
+        ctx.save_for_backward(x, weight, y if ctx.relu_out else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, y = ctx.saved_tensors
+        cout, cin = weight.shape[:2]
+        gy = grad_out.contiguous()
+        mask = None
+        if ctx.relu_out:
+            if ctx.has_residual or ctx.has_cloud_bias:
+                gy = torch.ops.aten.threshold_backward(gy, y, 0)          # the masked tensor itself is an output
+            else:
+                mask = y
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gx = gw = gb = gcb = None
+        if need_x:
+            gx = mfma_linear(gy, weight.view(cout, cin), w_kmajor=True, xmask=mask,
+                             residual=x if ctx.relu_in else None, res_is_mask=ctx.relu_in)
+        if need_w or need_b:
+            gw, gb = mfma_wgrad(x, gy, cout, cin, ctx.has_bias, gymask=mask, x_relu=ctx.relu_in)
+            gw = gw.view_as(weight)
+        if ctx.has_cloud_bias and ctx.needs_input_grad[3]:
+            gcb = gy.flatten(2).sum(2)
+        gres = gy if ctx.has_residual and ctx.needs_input_grad[4] else None
+        return gx, gw, gb, gcb, gres, None, None, None
+
+
+def pointwise_conv_fused(x, weight, bias=None, relu_in=False, relu=False, residual=None, relu_after=False, cloud_bias=None):
+    """act2(act1(W in(x) + bias + cloud_bias[b]) + residual): in = ReLU if relu_in, act1 = ReLU if relu, act2 = ReLU if
+    relu_after; cloud_bias (B, Cout) (summed with the bias first: one addend per output), residual like the output.  One GEMM where all passes of the layer are on the MFMA
+    kernels, the same function composed of pointwise_conv and elementwise passes elsewhere (host tensors, other dtypes,
+    shapes the routing rules give to the library)."""
+    wants_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, bias, residual, cloud_bias))
+    if _fused_routes(x, weight, x.requires_grad and wants_grad) and (residual is None or residual.dtype == torch.float32):
+        if residual is not None and not residual.is_contiguous():
+            residual = residual.contiguous()
+        if wants_grad:
+            return _PointwiseConvFused.apply(x, weight, bias, cloud_bias, residual, relu_in, relu, relu_after)
+        cout, cin = weight.shape[:2]
+        b = bias
+        if cloud_bias is not None:
+            b = cloud_bias if bias is None else cloud_bias + bias
+        return mfma_linear(x, weight.view(cout, cin), b, relu=relu, residual=residual, x_relu=relu_in, relu_after=relu_after,
+                           bias_per_cloud=cloud_bias is not None)
+    if cloud_bias is not None:
+        cb = cloud_bias if bias is None else cloud_bias + bias
+        h = pointwise_conv(torch.relu(x) if relu_in else x, weight, None) + cb.view(cb.shape + (1,) * (x.dim() - 2))
+        h = torch.relu_(h) if relu else h
+    else:
+        h = pointwise_conv(torch.relu(x) if relu_in else x, weight, bias, relu=relu)
+    if residual is not None:
+        h = h + residual
+    return torch.relu(h) if relu_after else h
+
+
+class _PointwiseConvDual(Function):
+    """(W1 x, W2 x) of ONE input as one GEMM with two contiguous outputs (mvp_pointwise_mfma_ex, m_split): a residual unit's
+    conv1 / conv_res (vrcnet.py:160-172).  The stacked convolution of round 4 handed out torch.split views -- a copy for the
+    consumer that needs a contiguous tensor forward, a concatenation of the two gradients backward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        c1, c2, cin = w1.size(0), w2.size(0), w1.size(1)
+        y1, y2 = mfma_linear(x, torch.cat((w1.view(c1, cin), w2.view(c2, cin)), 0), m_split=c1)
+        ctx.save_for_backward(x, w1, w2)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, w1, w2 = ctx.saved_tensors
+        c1, c2, cin = w1.size(0), w2.size(0), w1.size(1)
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = mfma_linear(g1, w1.view(c1, cin), w_kmajor=True)
+            gx = mfma_linear(g2, w2.view(c2, cin), w_kmajor=True, residual=gx)       # W1^T g1 + W2^T g2
+        gw1 = mfma_wgrad(x, g1, c1, cin, False)[0].view_as(w1) if ctx.needs_input_grad[1] else None
+        gw2 = mfma_wgrad(x, g2, c2, cin, False)[0].view_as(w2) if ctx.needs_input_grad[2] else None
+        return gx, gw1, gw2
+
+
+def pointwise_conv_dual(x, w1, w2):
+    """(conv(x, w1), conv(x, w2)), bias-free, both contiguous; one pass over x where the MFMA kernels cover the layer."""
+    c1, c2, cin = w1.size(0), w2.size(0), w1.size(1)
+    need_x = torch.is_grad_enabled() and x.requires_grad
+    stacked_ok = c1 % 32 == 0 and w1.is_contiguous() and w2.is_contiguous() and x.is_cuda \
+        and _fused_routes(x, w1, need_x) and _fused_routes(x, w2, need_x) and _mfma_fwd(x, cin, c1 + c2, None)
+    if not stacked_ok:
+        return pointwise_conv(x, w1), pointwise_conv(x, w2)
+    if torch.is_grad_enabled() and (x.requires_grad or w1.requires_grad or w2.requires_grad):
+        return _PointwiseConvDual.apply(x, w1, w2)
+    return mfma_linear(x, torch.cat((w1.view(c1, cin), w2.view(c2, cin)), 0), m_split=c1)
 
 
 class _PointwiseConvMax(Function):

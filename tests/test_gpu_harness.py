@@ -599,6 +599,135 @@ def test_pointwise_wgrad_mfma_matches_torch(B, cin, cout, L, bias):
     assert torch.equal(gw, gw3)
 
 
+@pytest.mark.parametrize("B,cin,cout,L", [(2, 128, 256, 2048), (3, 16, 64, 3072), (2, 68, 2, 3072), (2, 512, 512, 384),
+                                          (2, 515, 130, 388), (1, 40, 33, 8)])
+def test_pointwise_mfma_ex_prologue_and_epilogues_equal_the_separate_passes(B, cin, cout, L):
+    """mvp_pointwise_mfma_ex (ABI 18): every fused step is the exact float operation of the separate elementwise pass, so
+    each flag combination must equal -- BIT FOR BIT -- the plain GEMM (mvp_pointwise_mfma's arithmetic) between the
+    corresponding torch passes: ReLU of x on load, a bias per cloud, + residual then ReLU, the residual as a mask (the data
+    gradient of conv(relu(x))), two outputs."""
+    from mvp_benchmark_amd.pointwise import mfma_linear
+    g = torch.Generator().manual_seed(cin * 11 + cout)
+    x = torch.randn(B, cin, L, generator=g).to(DEV)
+    w = torch.randn(cout, cin, generator=g).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    cb = torch.randn(B, cout, generator=g).to(DEV)
+    res = torch.randn(B, cout, L, generator=g).to(DEV)
+    plain = mfma_linear(x, w)
+    assert torch.equal(mfma_linear(x, w, x_relu=True), mfma_linear(torch.relu(x), w))
+    assert torch.equal(mfma_linear(x, w, b, x_relu=True, relu=True), torch.relu(mfma_linear(torch.relu(x), w, b)))
+    assert torch.equal(mfma_linear(x, w, cb, bias_per_cloud=True), plain + cb.unsqueeze(2))
+    assert torch.equal(mfma_linear(x, w, cb, bias_per_cloud=True, relu=True), torch.relu(plain + cb.unsqueeze(2)))
+    assert torch.equal(mfma_linear(x, w, b, residual=res, relu_after=True), torch.relu((plain + b.view(1, -1, 1)) + res))
+    assert torch.equal(mfma_linear(x, w, b, residual=res, relu=True, relu_after=True),
+                       torch.relu(torch.relu(plain + b.view(1, -1, 1)) + res))
+    assert torch.equal(mfma_linear(x, w, residual=res, res_is_mask=True), torch.where(res > 0, plain, torch.zeros_like(plain)))
+    assert torch.equal(mfma_linear(x, w, relu_after=True), torch.relu(plain))
+    if cin % 4 == 0:            # the data gradient of conv(relu(.)) masked by the layer's input, with ReLU' of the output on load
+        gy = torch.randn(B, cout, L, generator=g).to(DEV)
+        y = torch.randn(B, cout, L, generator=g).to(DEV)
+        got = mfma_linear(gy, w, w_kmajor=True, xmask=y, residual=x, res_is_mask=True)
+        want = mfma_linear(gy * (y > 0), w, w_kmajor=True) * (x > 0)
+        assert torch.equal(got, want + 0.0)          # (+ 0.0: the product's -0 where a masked-out value was negative)
+    for split in (32, 64, 96):
+        if split < cout:
+            y1, y2 = mfma_linear(x, w, b, m_split=split)
+            full = mfma_linear(x, w, b)
+            assert y1.is_contiguous() and y2.is_contiguous() and y1.shape == (B, split, L) and y2.shape == (B, cout - split, L)
+            assert torch.equal(y1, full[:, :split]) and torch.equal(y2, full[:, split:])
+
+
+def test_pointwise_mfma_ex_rejects_what_it_does_not_cover():
+    from mvp_benchmark_amd import _lib
+    x = torch.randn(2, 32, 64, device=DEV); w = torch.randn(64, 32, device=DEV); y = torch.empty(2, 64, 64, device=DEV)
+    def rc(flags=0, residual=None, m_split=0, y2=None, bias=None, per_cloud=0):
+        try:
+            _lib.call("mvp_pointwise_mfma_ex", x.device, 2, 32, 64, 64, x, None, w, 0, 0, bias, per_cloud, residual, flags, 1, y, m_split, y2)
+            return 0
+        except _lib.MvpOpsError as e:
+            return str(e)
+    assert rc() == 0
+    assert rc(flags=16) != 0                                   # unknown flag
+    assert rc(flags=4) != 0                                    # a mask without the tensor
+    assert rc(m_split=32) != 0                                 # two outputs without the second tensor
+    assert rc(m_split=16, y2=y) != 0                           # not a multiple of 32
+    assert rc(per_cloud=1) != 0                                # a bias per cloud without the bias
+
+
+@pytest.mark.parametrize("B,cin,cout,L", [(8, 128, 128, 3072), (8, 16, 64, 3072), (64, 68, 2, 3072), (64, 512, 512, 384), (16, 256, 128, 1536)])
+def test_pointwise_conv_fused_matches_the_composed_ops_under_autograd(B, cin, cout, L):
+    """pointwise_conv_fused / pointwise_conv_dual (one GEMM with the activations, residual and per-cloud vector inside)
+    against the same function composed of pointwise_conv and torch's elementwise passes: outputs bit for bit, every gradient
+    at summation-order tolerance (the composed route may use other kernels for a small layer's backward pass)."""
+    from mvp_benchmark_amd import pointwise as pw
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    def T(*shape, grad=True):
+        return torch.randn(*shape, generator=g).to(DEV).requires_grad_(grad)
+    x, w, b, res, cb = T(B, cin, 1, L), T(cout, cin, 1, 1), T(cout), T(B, cout, 1, L), T(B, cout)
+    go = torch.randn(B, cout, 1, L, generator=g).to(DEV)
+    assert pw._fused_routes(x, w, True) == (cin % 4 == 0)
+    cases = [dict(relu_in=True), dict(relu_in=True, relu=True), dict(relu_in=True, residual=res, relu_after=True),
+             dict(residual=res, relu_after=True), dict(residual=res), dict(relu=True, cloud_bias=cb), dict(cloud_bias=cb),
+             dict(relu_in=True, relu=True, bias=None)]
+    for kw in cases:
+        bias = kw.pop("bias", b)
+        inputs = [t for t in (x, w, bias, kw.get("residual"), kw.get("cloud_bias")) if t is not None]
+        y = pw.pointwise_conv_fused(x, w, bias, **kw)
+        grads = torch.autograd.grad(y, inputs, go)
+        a = torch.relu(x) if kw.get("relu_in") else x
+        if kw.get("cloud_bias") is not None:            # (the per-cloud vector and the bias are summed first: one addend per output)
+            h = pw.pointwise_conv(a, w, None) + (cb + bias if bias is not None else cb).view(B, cout, 1, 1)
+        else:
+            h = pw.pointwise_conv(a, w, bias)
+        h = torch.relu(h) if kw.get("relu") else h
+        h = h + res if kw.get("residual") is not None else h
+        h = torch.relu(h) if kw.get("relu_after") else h
+        want = torch.autograd.grad(h, inputs, go)
+        assert torch.equal(y, h), kw
+        for got_g, want_g, t in zip(grads, want, inputs):
+            scale = want_g.abs().max().item() + 1e-6
+            assert (got_g - want_g).abs().max().item() < 2e-5 * scale * math.sqrt(max(cin, cout, L)), (kw, tuple(t.shape))
+    if cout % 32 == 0 and cin % 4 == 0:
+        w2 = T(cout // 2 if cout > 32 else cout, cin, 1, 1)
+        y1, y2 = pw.pointwise_conv_dual(x, w, w2)
+        assert y1.is_contiguous() and y2.is_contiguous()
+        r1, r2 = pw.pointwise_conv(x, w), pw.pointwise_conv(x, w2)
+        assert torch.equal(y1, r1) and torch.equal(y2, r2)
+        go2 = torch.randn_like(y2)
+        got = torch.autograd.grad([y1, y2], (x, w, w2), [go, go2])
+        want = torch.autograd.grad([r1, r2], (x, w, w2), [go, go2])
+        for a_, r_ in zip(got, want):
+            assert (a_ - r_).abs().max().item() < 2e-5 * (r_.abs().max().item() + 1e-6) * math.sqrt(max(cin, cout, L))
+
+
+def test_relational_unit_with_fused_activations_equals_the_op_by_op_route():
+    """SKN_Res_unit at two of the shipped levels with op_config.fused_activations on / off: same output bits, gradients at
+    summation-order tolerance."""
+    import op_config
+    from models.relational import SKN_Res_unit
+    torch.manual_seed(5)
+    for cin, c, n in ((4, 64, 3072), (128, 128, 1536)):
+        unit = SKN_Res_unit(cin, c, k=[16], layers=1).to(DEV)
+        x0 = torch.randn(16, cin, 1, n, device=DEV)
+        idx = [torch.randint(0, n, (16, n, 16), device=DEV, dtype=torch.int32)]
+        runs = {}
+        for on in (False, True):
+            old = op_config.configure(fused_activations=on)
+            try:
+                unit.zero_grad()
+                x = x0.clone().requires_grad_()
+                out = unit(x, idx, relu_out=True)
+                out.square().sum().backward()
+                runs[on] = (out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in unit.named_parameters()})
+            finally:
+                op_config.configure(**old)
+        assert torch.equal(runs[True][0], runs[False][0])
+        tol = lambda r: 1e-4 * (r.abs().max().item() + 1e-6)
+        assert (runs[True][1] - runs[False][1]).abs().max().item() < tol(runs[False][1])
+        for k, gr in runs[False][2].items():
+            assert (runs[True][2][k] - gr).abs().max().item() <= tol(gr), k
+
+
 @pytest.mark.parametrize("group", [2, 4, 16, 32])
 def test_pointwise_mfma_group_max(group):
     """The set-abstraction epilogue: conv -> ReLU -> max over the `group`
