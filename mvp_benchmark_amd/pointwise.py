@@ -63,8 +63,8 @@ def _gemm_fits(batch, m, k, length):
     column tile that is half empty: the library splits K there (ECG's bottleneck layers: 1864 -> 768 at
     256 points 0.28 against 0.21 ms, 2824 -> 1024 at 64 points 0.25 against 0.10;
     profiles/r4_conv_passes_ecg.txt)."""
-    if k < 512:
-        return True
+    if k <= 512:   # (round 6: 512 included -- (64, 512 -> 512, 384) 0.127 against the library's 0.145 ms, the data gradient of
+        return True   # (64, 128 -> 512, 384) 0.050 against 0.108: tools/bench_conv_passes.py)
     if length < 128:
         return False
     bm = 128 if m > 64 else 64
@@ -245,9 +245,13 @@ def _fused_routes(x, weight, need_x):
     """All three passes of a layer on the MFMA kernels (the fused prologues / epilogues live there only)?"""
     cout, cin = weight.shape[:2]
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous()
-            and weight.is_contiguous() and x.numel() > 0 and _mfma_fwd(x, cin, cout, weight)):
+            and weight.is_contiguous() and x.numel() > 0 and _mfma_ok(x, cin, cout, weight)):
         return False
     B, length = x.size(0), x[0, 0].numel()
+    # (the skinny-forward rule of _mfma_fwd is not applied: 544 -> 16 at 384 points costs 0.031 ms here against the
+    # library's 0.024, the passes over the 53 MB input that the fused prologue saves cost 0.06)
+    if not _gemm_fits(B, cout, cin, length):
+        return False
     if need_x and not (cin % 4 == 0 and _gemm_fits(B, cin, cout, length)):
         return False
     return B * length >= MFMA_WGRAD_MIN_POSITIONS and pointwise_wgrad_mfma_scratch_bytes(B, cin, cout, length, True) > 0
