@@ -29,6 +29,7 @@ from mm3d_pn2 import knn as knn_op  # noqa: E402
 from op_config import OPS  # noqa: E402
 from mvp_benchmark_amd.mm3d_pn2.functional import (ShareGatherSum, ShareWeightedSum, gather_max, gram_topk,  # noqa: E402
                                                    share_gather_sum, share_weighted_sum)
+from mvp_benchmark_amd.pointwise import pointwise_conv  # noqa: E402
 
 
 # --------------------------------------------------------------------------
@@ -487,18 +488,20 @@ class EF_expansion(nn.Module):
         out = self.output_size
         idx = knn(x, self.k)                                                   # (B, N, k)
         w1 = self.conv1.weight.flatten(1)                                      # (out, 2C) = [centre | neighbour]
-        both1 = F.conv1d(x, torch.cat((w1[:, :c], w1[:, c:]), 0).unsqueeze(2),
-                         torch.cat((self.conv1.bias, torch.zeros_like(self.conv1.bias))))
+        # (pointwise_conv, not F.conv1d / F.conv2d / the nn.Conv2d modules' own forward: on the GPU its backward pass never
+        # calls the library's backward-data convolution kernels -- mvp_benchmark_amd/pointwise.py: _PointwiseConv.backward)
+        both1 = pointwise_conv(x, torch.cat((w1[:, :c], w1[:, c:]), 0).unsqueeze(2),
+                               torch.cat((self.conv1.bias, torch.zeros_like(self.conv1.bias))))
         h = both1[:, :out].unsqueeze(2) + get_edge_features(both1[:, out:], idx)          # conv1(edge_in): (B, out, k, N)
         w2 = self.conv2.weight.flatten(1)                                      # (out*step, out + 2C) = [h | centre | neighbour]
         rx = F.relu(x)                                                         # relu(gather(x)) = gather(relu(x))
         n2 = w2.size(0)
-        both2 = F.conv1d(rx, torch.cat((w2[:, out:out + c], w2[:, out + c:]), 0).unsqueeze(2),
-                         torch.cat((self.conv2.bias, torch.zeros_like(self.conv2.bias))))
-        edge = F.conv2d(F.relu(h), w2[:, :out, None, None]) + both2[:, :n2].unsqueeze(2) \
+        both2 = pointwise_conv(rx, torch.cat((w2[:, out:out + c], w2[:, out + c:]), 0).unsqueeze(2),
+                               torch.cat((self.conv2.bias, torch.zeros_like(self.conv2.bias))))
+        edge = pointwise_conv(F.relu(h), w2[:, :out, None, None].contiguous()) + both2[:, :n2].unsqueeze(2) \
             + get_edge_features(both2[:, n2:], idx)
         edge = F.relu(edge)                                                                        # B C K N
         edge = edge.permute(0, 2, 3, 1).contiguous() \
             .view(batch_size, self.k, num_points * self.step_ratio, self.output_size) \
             .permute(0, 3, 1, 2)
-        return self.conv3(edge).max(dim=2)[0]
+        return pointwise_conv(edge, self.conv3.weight, self.conv3.bias).max(dim=2)[0]

@@ -160,6 +160,10 @@ class _PointwiseConv(Function):
         cout, cin = weight.shape[:2]
         ctx.has_bias = bias is not None
         ctx.relu = relu
+        if not x.is_contiguous():          # (a permuted view: the kernels of the backward pass take dense tensors)
+            x = x.contiguous()
+        if not weight.is_contiguous():
+            weight = weight.contiguous()
         if (MFMA_TRAIN or _covered(x, weight)) and _mfma_fwd(x, cin, cout, weight):
             y = mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
         else:
@@ -201,8 +205,11 @@ class _PointwiseConv(Function):
                 gx = torch.empty_like(x)
                 call("mvp_pointwise_dgrad", x.device, x.size(0), cin, cout, x[0, 0].numel(), weight, gy_masked, gx)
             else:
-                gx = torch.ops.aten.convolution_backward(gy_masked, x, weight, None, [1] * nd, [0] * nd, [1] * nd,
-                                                         False, [0] * nd, 1, [True, False, False])[0]
+                # W^T gy per cloud as a batched library GEMM -- NOT aten.convolution_backward: MIOpen's implicit-GEMM
+                # backward-data kernel (igemm_bwd_gtcx35_nhwc_fp32) reads past its operands on some of these shapes (37- and
+                # 50-point layers of the golden tests: a GPU memory fault whenever the neighbouring page happens to be
+                # unmapped -- rocgdb trace in profiles/NOTES_r6.md section 11); a 1x1 convolution's data gradient is a GEMM
+                gx = torch.matmul(weight.reshape(cout, cin).t(), gy_masked.flatten(2)).view_as(x)
         gy = gy_masked
         if need_w or need_b:
             if gw_mfma:
@@ -216,6 +223,10 @@ class _PointwiseConv(Function):
                 gw = torch.empty_like(weight)
                 gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
                 call("mvp_pointwise_wgrad", x.device, B, cin, cout, length, x, gy, gw, gb, scratch, nbytes)
+            elif x[0, 0].numel() % 4 != 0 or not x.is_contiguous():
+                # (odd shapes: GEMM formulation here too; the aligned layers below are the ones routed to the library on purpose)
+                gw = torch.einsum("bol,bil->oi", gy.flatten(2), x.flatten(2)).view_as(weight) if need_w else None
+                gb = gy.flatten(2).sum((0, 2)) if need_b else None
             else:
                 _, gw, gb = torch.ops.aten.convolution_backward(
                     gy, x, weight, [cout] if ctx.has_bias else None, [1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1,
@@ -230,11 +241,17 @@ def pointwise_conv(x, weight, bias=None, relu=False):
     cout, cin = weight.shape[:2]
     routed = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() \
         and weight.is_contiguous() and x.numel() > 0 and (_mfma_ok(x, cin, cout, weight) or _covered(x, weight))
-    if routed and (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
+    wants_grad = torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad or (bias is not None and bias.requires_grad))
+    if routed and wants_grad:
         if MFMA_TRAIN or _covered(x, weight):
             return _PointwiseConv.apply(x, weight, bias, relu)
         y = conv(x, weight, bias)
         return torch.relu(y) if relu else y
+    if wants_grad and USE_MFMA and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.numel() > 0:
+        # shapes no kernel of ours covers (positions not a multiple of 4, strided tensors): the library's forward, but STILL
+        # _PointwiseConv's backward -- its data gradient is a batched GEMM, never MIOpen's implicit-GEMM backward-data kernel,
+        # which reads out of bounds on such shapes (see _PointwiseConv.backward)
+        return _PointwiseConv.apply(x, weight, bias, relu)
     if routed and _mfma_fwd(x, cin, cout, weight):                 # inference
         return mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
     y = conv(x, weight, bias)
