@@ -16,7 +16,7 @@ constexpr int kIndexReserve = 1728;  // ints of per-cloud scratch the grid of ro
 constexpr int kBidCache = 1024;  // list positions whose bid is cached in LDS
 constexpr int kRecCap = 512;     // list positions whose person record is cached in LDS
 #ifndef MVP_EMD_ROWMIN
-#define MVP_EMD_ROWMIN 96
+#define MVP_EMD_ROWMIN 192   // (96 with the 12^3 grid of rounds 1-5: below)
 #endif
 constexpr int kRowModeMin = MVP_EMD_ROWMIN;  // bidders per round above which 4 bidders share a wave
 constexpr int kRowListCap = 128; // per-row (bidder) list of surviving leaves, flushed when full
@@ -32,7 +32,14 @@ constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens 
 // The lean kernel (emd_lean.hip) takes a cloud over once no workgroup has more than kRowModeMin
 // bidders, at most kLeanCap persons are unassigned (their number never grows, so every later
 // list fits the LDS record cache) and at least kLeanMinRounds rounds are left.
-constexpr int kLeanCap = 384;   // (tuned with kRowModeMin: 64..160 x 384 / 512 all within 0.2 ms at the headline shape)
+// Re-tuned with the leaf index (round 6, same-box sweep of six builds, profiles/r6c_emd_handover_sweep.txt): the one-bidder-
+// per-wave searches got 14 % cheaper and the four-per-wave ones 14 % dearer, so the lean kernel takes over EARLIER --
+// kRowModeMin x kLeanCap = 96 x 384 (rounds 2-5: "64..160 x 384 / 512 all within 0.2 ms") -> 192 x 512 (the record cache's
+// size): headline EMD 29.5 -> 29.0 ms, 256 x 512 the same, 64 x 384 +1.6; every other shape neutral or better.
+#ifndef MVP_EMD_LEANCAP
+#define MVP_EMD_LEANCAP 512
+#endif
+constexpr int kLeanCap = MVP_EMD_LEANCAP;
 constexpr int kLeanMinRounds = 64;
 static_assert(kLeanCap <= kRecCap, "the lean kernel keeps every list entry's record in LDS");
 // The resident kernel (emd_resident.hip) takes a cloud of at most kResMaxN points over once at most
