@@ -379,7 +379,7 @@ def test_emd_second_kernel_really_runs(emd_split):
     np.testing.assert_array_equal(out[0][2], out[1][2])          # same rounds, same bids
     assert (out[0][3]["first_handover"] == 0).all()               # split off: nothing handed over
     assert (out[1][3]["first_handover"] > 0).all() and (out[1][3]["first_handover"] < 1500).all()   # split on: round of the hand-over
-    assert (out[1][3]["unassigned"] <= 384).all()
+    assert (out[1][3]["unassigned"] <= 512).all()                 # kLeanCap (emd_common.h; 384 before the round-6 re-tuning)
     r1 = out[1][3]
     assert (r1["next_round"] == 0).all() and (r1["final_width"] == 8).all() and (r1["final_launch"] == 1).all()   # finished, by the clusters of 8 a batch of 2 gets
 

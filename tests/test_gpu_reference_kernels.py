@@ -263,8 +263,7 @@ def test_reference_emd_kernels_at_the_headline_size(mode, kind):
     replay nearly the same schedule, while the product's policy sits 1.2e-3 (relative) away on one cloud and 6.6e-5 on the
     other.  Two runs therefore UNDERSTATE the outcome set; its width was measured in round 2 by running the oracle under
     both extreme policies (profiles/r2_emd_schedule_sensitivity.txt: 1e-3 .. 2.3e-3).  Tolerance: the larger of three times
-    the measured spread and 2.5e-3 of the cost (the smaller cases above use 5e-3); where the two reference runs agree bit
-    for bit the product must equal them exactly."""
+    the measured spread and 2.5e-3 of the cost (the smaller cases above use 5e-3)."""
     from mvp_benchmark_amd import metrics
     from mvp_benchmark_amd.synthetic import prediction_pair
     v, exact = mode
@@ -280,13 +279,14 @@ def test_reference_emd_kernels_at_the_headline_size(mode, kind):
     cost = lambda d: np.sqrt(host(d).astype(np.float64)).mean(axis=1)            # per cloud
     c1, c2, cm = cost(r1d), cost(r2d), cost(md)
     differ = int((host(r1a) != host(r2a)).sum())
-    if differ == 0 and not exact:
-        same_index(ma, r1a)
+    # (Two agreeing runs do NOT make the reference deterministic here: on an idle GPU its racy GetMax can replay one
+    # schedule twice -- seen in round 6, with a third of the assignments different from the product's pinned policy.  At this
+    # size the comparison is always the cost-level one; the policy-free sizes are pinned exactly by EMD_CASES above.)
     spread = np.abs(c1 - c2)
     print("headline-size EMD vs the reference (%s, %s build): reference runs differ in %d of %d assignments, cost spread %s, "
           "product - reference mean %s (relative %s)" % (kind, v or "default", differ, b * n, spread, cm - (c1 + c2) / 2,
                                                          (cm - (c1 + c2) / 2) / cm))
-    tol = np.maximum(3 * spread, 2.5e-3 * cm) if differ else 1e-5 * cm
+    tol = np.maximum(3 * spread, 2.5e-3 * cm)
     assert (np.abs(cm - (c1 + c2) / 2) <= tol).all(), (cm, c1, c2)
     # and the product's dist is the distance of the assignment it returns
     mh = host(ma).astype(np.int64)
