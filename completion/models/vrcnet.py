@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from model_utils import EF_expansion, calc_cd, furthest_point_sample, gather_points, gen_grid_up
+from model_utils import EF_expansion, GeometryAhead, calc_cd, furthest_point_sample, gather_points, gen_grid_up
 from op_config import OPS
 from models._common import conv_folded_concat, dense, eval_outputs, pointwise1d
 from models.pcn import PCN_encoder
@@ -140,7 +140,10 @@ class MSAP_SKN_decoder(nn.Module):
     def _keep(idx, *tensors):
         return [gather_points(t.contiguous(), idx) for t in tensors]
 
-    def forward(self, global_feat, point_input):
+    def forward(self, global_feat, point_input, meanwhile=None):
+        """meanwhile(coarse_raw, coarse_high): work of the caller that needs only these two outputs (the training losses on
+        them); it is issued on the main stream while the FPS of stage 1 -- 2047 sequential rounds on a quarter of the CUs,
+        non-differentiable -- runs on a side lane (model_utils.GeometryAhead).  Same launches, same values."""
         batch_size = global_feat.size(0)
         coarse_raw = self._coarse_raw(global_feat)
         dense_feat = self.encoder(self._labelled(coarse_raw, point_input))
@@ -152,8 +155,20 @@ class MSAP_SKN_decoder(nn.Module):
         # stage 1: furthest point sampling down to num_fps
         coarse = coarse_high
         if coarse.size(2) > self.num_fps:
-            picked = furthest_point_sample(coarse.transpose(1, 2).contiguous(), self.num_fps)
+            src = coarse.transpose(1, 2).contiguous()
+            if meanwhile is not None and src.is_cuda and OPS.side_lanes > 0 and OPS.fps_beside_losses:
+                geo = GeometryAhead(src.device)
+                geo.run("fps", lambda: furthest_point_sample(src.detach(), self.num_fps))
+                meanwhile(coarse_raw, coarse_high)
+                picked = geo.take("fps")
+                geo.join()
+            else:
+                picked = furthest_point_sample(src, self.num_fps)
+                if meanwhile is not None:
+                    meanwhile(coarse_raw, coarse_high)
             coarse, coarse_features = self._keep(picked, coarse, coarse_features)
+        elif meanwhile is not None:
+            meanwhile(coarse_raw, coarse_high)
         # stage 2: the num_coarse points with the best learned score
         if coarse.size(2) > self.num_coarse:
             hidden = self.af(self.conv_s2(self.af(self.conv_s1(coarse_features))))
@@ -268,7 +283,13 @@ class Model(nn.Module):
             z = self._posterior(feat).rsample()
             feat = F.relu(feat)      # overwritten in place by posterior_infer1 in the reference (:477, :486)
 
-        outputs = self.decoder(feat + self.generator(z), x)
+        early = {}
+        if train and self.train_loss == 'cd':
+            # the losses of the two outputs that exist before the decoder's FPS are issued beside it (decoder: `meanwhile`)
+            def early_losses(raw, high):
+                early['raw'] = calc_cd(raw.transpose(1, 2).contiguous(), gt)[0]
+                early['high'] = calc_cd(high.transpose(1, 2).contiguous(), gt)[0]
+        outputs = self.decoder(feat + self.generator(z), x, meanwhile=early_losses if (train and self.train_loss == 'cd') else None)
         coarse_raw, coarse_high, coarse, fine = [t.transpose(1, 2).contiguous() for t in outputs]
         if prefix == "val":
             return eval_outputs(coarse_raw, fine, gt, self.eval_emd)
@@ -278,6 +299,7 @@ class Model(nn.Module):
         if self.train_loss != 'cd':
             raise NotImplementedError('Only CD is supported')
         latent = self._latent_loss(q, p)     # (raises on an unknown distribution_loss before any CD is run)
-        cd_raw, cd_high, cd_coarse, cd_fine = [calc_cd(o, gt)[0] for o in (coarse_raw, coarse_high, coarse, fine)]
+        cd_raw, cd_high = early['raw'], early['high']
+        cd_coarse, cd_fine = [calc_cd(o, gt)[0] for o in (coarse, fine)]
         total = cd_raw.mean() * 10 + cd_high.mean() * 0.5 + cd_coarse.mean() + cd_fine.mean() * alpha + latent
         return fine, cd_fine, total

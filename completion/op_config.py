@@ -12,13 +12,15 @@ by tests/test_model_golden.py); the defaults are the measured-faster ones (DESIG
   folded_conv          folding layers as three small products instead of tile / repeat / concatenate / convolve
   fused_activations    pre-activation ReLUs, residual sums + ReLU and per-cloud vectors inside the convolutions' GEMMs
                        (mvp_pointwise_mfma_ex), a residual unit's conv1 / conv_res as one GEMM with two outputs
+  fps_beside_losses    VRCNet training: the decoder's FPS on a side lane while the main stream computes the losses of the two
+                       outputs that already exist
   singleton_sk         SK_SA_module with ONE kernel (the shipped cfg): attention == 1 exactly, the fusion passes not issued
 """
 
 
 class OpLayerConfig:
     __slots__ = ("gather_sum", "gather_max", "side_lanes", "stacked_projections", "skip_full_fps_of_gt",
-                 "conv_before_interp", "folded_conv", "singleton_sk", "fused_activations")
+                 "conv_before_interp", "folded_conv", "singleton_sk", "fused_activations", "fps_beside_losses")
 
     def __init__(self):
         self.reset()
@@ -33,6 +35,7 @@ class OpLayerConfig:
         self.folded_conv = True
         self.singleton_sk = True
         self.fused_activations = True
+        self.fps_beside_losses = True
 
     def as_dict(self):
         return {k: getattr(self, k) for k in self.__slots__}
