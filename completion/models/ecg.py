@@ -19,7 +19,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from model_utils import EF_expansion, furthest_point_sample, gather_points, get_uniform_loss
+from model_utils import EF_expansion, GeometryAhead, furthest_point_sample, gather_points, get_uniform_loss
+from op_config import OPS
 from models._common import dense, eval_outputs, pointwise1d, shape_loss
 from models.edge_unet import Dense_conv, EF_encoder, Stack_conv  # noqa: F401
 from models.pcn import PCN_encoder
@@ -54,7 +55,10 @@ class ECG_decoder(nn.Module):
             self.conv1 = pointwise1d(self.dense_feature_size, self.expand_feature_size)
         self.conv2 = pointwise1d(self.expand_feature_size, 3)
 
-    def forward(self, global_feat, point_input):
+    def forward(self, global_feat, point_input, meanwhile=None):
+        """meanwhile(coarse): work of the caller that needs the skeleton only (its training losses); issued on the main
+        stream while the final FPS -- 2047 sequential rounds on an eighth of the CUs, non-differentiable -- runs on a side lane
+        (model_utils.GeometryAhead; op_config fps_beside_losses).  Same launches, same values."""
         batch_size = global_feat.size(0)
         coarse = self.fc3(F.relu(self.fc2(F.relu(self.fc1(global_feat))))).view(batch_size, 3, self.num_coarse)
 
@@ -64,8 +68,19 @@ class ECG_decoder(nn.Module):
         fine = self.conv2(F.relu(self.conv1(dense_feat)))
 
         if fine.size(2) > self.num_fine:      # thin out to exactly num_fine points
-            keep = furthest_point_sample(fine.transpose(1, 2).contiguous(), self.num_fine)
+            src = fine.transpose(1, 2).contiguous()
+            if meanwhile is not None and src.is_cuda and OPS.side_lanes > 0 and OPS.fps_beside_losses:
+                geo = GeometryAhead(src.device)
+                geo.run("fps", lambda: furthest_point_sample(src.detach(), self.num_fine))
+                meanwhile(coarse)
+                meanwhile = None
+                keep = geo.take("fps")
+                geo.join()
+            else:
+                keep = furthest_point_sample(src, self.num_fine)
             fine = gather_points(fine.contiguous(), keep)
+        if meanwhile is not None:
+            meanwhile(coarse)
         return coarse, fine
 
 
@@ -82,15 +97,19 @@ class Model(nn.Module):
     def forward(self, x, gt=None, prefix="train", mean_feature=None, alpha=None):
         if mean_feature:
             raise NotImplementedError
-        out1, out2 = self.decoder(self.encoder(x), x)
+        early = {}
+
+        def skeleton_terms(coarse):          # (needs the skeleton only: issued beside the decoder's final FPS)
+            c = coarse.transpose(1, 2).contiguous()
+            early['term'] = shape_loss(self.train_loss, c, gt).mean() + 0.1 * get_uniform_loss(c).mean()
+        out1, out2 = self.decoder(self.encoder(x), x, meanwhile=skeleton_terms if prefix == "train" else None)
         out1 = out1.transpose(1, 2).contiguous()
         out2 = out2.transpose(1, 2).contiguous()
 
         if prefix == "train":
             # reconstruction + 0.1 x uniformity, on the skeleton and (x alpha) the fine cloud
-            loss_coarse = shape_loss(self.train_loss, out1, gt)
             loss_fine = shape_loss(self.train_loss, out2, gt)
-            term_coarse = loss_coarse.mean() + 0.1 * get_uniform_loss(out1).mean()
+            term_coarse = early['term']
             term_fine = loss_fine.mean() + 0.1 * get_uniform_loss(out2).mean()
             return out2, loss_fine, term_coarse + term_fine * alpha
         if prefix == "val":
