@@ -41,6 +41,16 @@ USE_MFMA = True            # False: nothing is routed to the MFMA kernels (the l
 MFMA_TRAIN = True          # under autograd the routed layers go through _PointwiseConv
 MFMA_DGRAD = True          # data gradient on mvp_pointwise_mfma (W^T, ReLU' on load)
 MFMA_WGRAD_MIN_CIN = 1     # weight gradient on mvp_pointwise_wgrad_mfma from this many input channels
+# Round 6: what "the library" is for a float32 CUDA layer our kernels leave to it -- batched GEMMs (rocBLAS / hipBLASLt
+# through torch.matmul), not MIOpen's convolutions: a 1x1 convolution IS a GEMM per cloud; MIOpen wraps it in NHWC
+# transposes, starts every process on its naive reference kernels (5.4 ms per weight gradient of ECG's bottleneck layers for
+# the first ~150 steps) until its solver search settles on a different kernel from run to run, and its implicit-GEMM
+# backward-data kernel reads out of bounds on odd shapes (profiles/r6_miopen_igemm_bwd_fault.txt; that one is avoided either
+# way: _PointwiseConv.backward).  Measured (tools/ab_flag.py, 12 alternations, ECG -- the model with library-routed layers):
+# first alternation 23.9 -> 18.5 ms (no naive-kernel phase), steady state 16.94 = 16.93 ms in rounds 3-6 but 17.2 -> 17.55 in
+# rounds 8-12; VRCNet 18.39 -> 18.45.  Not faster, so the default stays MIOpen for the forward and the weight gradient of
+# those layers; True = no MIOpen call at all in the training path.
+LIBRARY_IS_GEMM = False
 
 _WGRAD_SCRATCH = {}   # (device, stream) -> one growing workspace for the partial tiles (no allocator churn)
 
@@ -149,6 +159,18 @@ def _covered(x, weight):
         and x.size(0) <= 65535
 
 
+def _library_conv(x, weight, bias):
+    """The layer on the library, no autograd: conv1d / conv2d (MIOpen) or, with LIBRARY_IS_GEMM on float32 CUDA tensors, one
+    batched GEMM W x[b] (+ bias through baddbmm's addend)."""
+    if LIBRARY_IS_GEMM and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
+        cout, cin = weight.shape[:2]
+        x3 = x.flatten(2)
+        w3 = weight.reshape(1, cout, cin).expand(x.size(0), cout, cin)
+        y = torch.bmm(w3, x3) if bias is None else torch.baddbmm(bias.view(1, cout, 1), w3, x3)
+        return y.view((x.size(0), cout) + tuple(x.shape[2:]))
+    return (F.conv1d if x.dim() == 3 else F.conv2d)(x, weight, bias)
+
+
 class _PointwiseConv(Function):
     """y = [relu](W x + bias): forward and data gradient on the MFMA GEMM where the
     shape allows, the small-channel weight gradient through mvp_pointwise_wgrad, the
@@ -167,7 +189,7 @@ class _PointwiseConv(Function):
         if (MFMA_TRAIN or _covered(x, weight)) and _mfma_fwd(x, cin, cout, weight):
             y = mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
         else:
-            y = conv(x, weight, bias)
+            y = _library_conv(x, weight, bias)
             if relu:
                 y = torch.relu_(y)
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -223,8 +245,8 @@ class _PointwiseConv(Function):
                 gw = torch.empty_like(weight)
                 gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
                 call("mvp_pointwise_wgrad", x.device, B, cin, cout, length, x, gy, gw, gb, scratch, nbytes)
-            elif x[0, 0].numel() % 4 != 0 or not x.is_contiguous():
-                # (odd shapes: GEMM formulation here too; the aligned layers below are the ones routed to the library on purpose)
+            elif LIBRARY_IS_GEMM or x[0, 0].numel() % 4 != 0 or not x.is_contiguous():
+                # (the library = GEMMs, see LIBRARY_IS_GEMM; MIOpen's weight-gradient kernels only with the switch off)
                 gw = torch.einsum("bol,bil->oi", gy.flatten(2), x.flatten(2)).view_as(weight) if need_w else None
                 gb = gy.flatten(2).sum((0, 2)) if need_b else None
             else:
@@ -254,7 +276,7 @@ def pointwise_conv(x, weight, bias=None, relu=False):
         return _PointwiseConv.apply(x, weight, bias, relu)
     if routed and _mfma_fwd(x, cin, cout, weight):                 # inference
         return mfma_linear(x, weight.view(cout, cin), bias, relu=relu)
-    y = conv(x, weight, bias)
+    y = _library_conv(x, weight, bias) if (USE_MFMA and not wants_grad) else conv(x, weight, bias)
     return torch.relu(y) if relu else y
 
 

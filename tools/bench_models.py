@@ -64,6 +64,10 @@ for name in ("vrcnet", "ecg", "pcn"):
         opt.step()
     if torch.backends.cudnn.benchmark:
         for _ in range(3): step()       # the solver search happens in the first steps
+    # (ECG settles late: its first ~150 steps run 20-25 ms while the libraries pick their kernels -- tools/ab_vrcnet.py ecg 14
+    # shows the same curve in both settings, profiles/r6b_vrcnet_ab.txt -- so every model gets the same long warm-up)
+    for _ in range(int(os.environ.get("MVP_BENCH_WARMUP", "150"))):
+        step()
     ms = timed(step)
     print("%s train step (batch 32, 2048 pts, MFMA_TRAIN=%s%s): %.1f ms/step (%.1f samples/s); grads %.1f MB fp32" % (
         name, pw.MFMA_TRAIN, ", solver search on" if torch.backends.cudnn.benchmark else "", ms, 32e3 / ms, sum(p.numel() for p in net.parameters()) * 4 / 1e6), flush=True)
