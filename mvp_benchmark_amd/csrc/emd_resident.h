@@ -35,6 +35,9 @@ namespace mvp {
 
 // (kResList, kResMaxN, kResMinRounds: emd_common.h)
 constexpr int kResSub = 16;       // slots per sub-block: a 16-lane row of a visit step
+#ifndef MVP_RES_SOLO
+#define MVP_RES_SOLO 1            // the last bidder's chain of evictions on one wave, without barriers (0: A/B builds)
+#endif
 constexpr int kResBuckets = 256;
 constexpr unsigned short kResFree = 0xFFFFu;
 static_assert(kResList % kEmdWaves == 0, "list positions are dealt out to the waves round-robin, for the life of the launch");
@@ -54,6 +57,7 @@ struct ResShared {
   float s_binc[kResList];                // its increment
   int s_act[3];                          // by round % 3: positions that hold a bidder
   int s_err;
+  int s_solo[2];                         // rounds the last bidder's wave ran alone; 1: it ran the forced last round
 };
 
 // min over each 16-lane row, valid in every lane of the row
@@ -64,6 +68,115 @@ __device__ __forceinline__ float row_min(float v) {
   v = __builtin_fminf(v, dpp_f32<0x141, 0xF>(inf, v));   // row_half_mirror
   v = __builtin_fminf(v, dpp_f32<0x140, 0xF>(inf, v));   // row_mirror
   return v;
+}
+
+#ifdef MVP_EMD_PROFILE
+#define RES_PROF_ARGS , long long &prof_seed, long long &prof_subs, long long &prof_folds
+#define RES_PROF_PASS , prof_seed, prof_subs, prof_folds
+#else
+#define RES_PROF_ARGS
+#define RES_PROF_PASS
+#endif
+
+// Bid of one person (emd_cuda.cu:95-179) by the calling wave against the LDS-resident state: the exact best / second-best
+// value and the best slot, wave-uniform.  (qx, qy, qz): the person's point; p1: the slot it last bid on (its 64-slot block
+// is evaluated first); wl: the wave's list of surviving sub-blocks.
+template <int NMAX>
+__device__ __forceinline__ BidState res_search(ResShared<NMAX> &sh, unsigned short *wl, const float qx, const float qy, const float qz,
+                                               const int p1, const int lane, const int row, const int sl, const int n, const int nsub,
+                                               const int npass, const int tpu, const int *__restrict__ perm RES_PROF_ARGS) {
+  constexpr int kPasses = NMAX / kResSub / kWave;   // sub-block tests per lane this instantiation can need: 2 / 4
+#ifdef MVP_EMD_PROFILE
+  const long long tb0 = __builtin_readcyclecounter();
+#endif
+  const int home = p1 >> 6;   // the 64-slot block (four sub-blocks) that holds the previous best object
+  // every sub-block's box and price bound against the bidder's point (independent of the seed: issued first)
+  float bd2[kPasses], bpl[kPasses];
+  // (straight-line: every pass the instantiation can need is loaded at once -- indices beyond this cloud's
+  // sub-blocks are clamped and their result discarded -- so the loads share one LDS round trip)
+#pragma unroll
+  for (int ps = 0; ps < kPasses; ++ps) {
+    const int sub = min(ps * kWave + lane, nsub - 1);
+    const float4 lo = sh.s_lo[sub], hi = sh.s_hi[sub];
+    const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi.x), 0.f);
+    const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi.y), 0.f);
+    const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi.z), 0.f);
+    bd2[ps] = ps < npass ? sqdist3(dx, dy, dz) : __builtin_inff();
+    bpl[ps] = lo.w;
+  }
+  // The home block evaluated exactly: the lanes that hold its two best values (more on ties) start the
+  // running top two; the second of them is a lower bound of the final second-best value (64 distinct objects).
+  BidState st;
+  st.b1 = -1e9f;
+  st.b2 = -1e9f;
+  st.bk = -1;
+  st.b2k = -1;
+  st.tm = __builtin_inff();
+  {
+    const float4 o = sh.obj[home * kWave + lane];
+    const float v = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
+    // largest value, then the largest of the rest (one holder of the maximum set aside)
+    const float t1 = emd_wave_max(v);
+    const unsigned long long m1 = __ballot(v == t1);
+    const int l1 = (int)__builtin_ctzll(m1);
+    const float t2 = emd_wave_max(lane == l1 ? -1e9f : v);
+    const unsigned long long m2 = __ballot(v >= t2);
+    if (__builtin_expect(t1 > t2 && __builtin_popcountll(m2) == 2, 1)) {
+      // two different values, one holder each: the state emd_fold would arrive at
+      st.b1 = t1;
+      st.bk = home * kWave + l1;
+      st.b2 = t2;
+      st.b2k = home * kWave + (int)__builtin_ctzll(m2 & ~m1);
+      st.tm = (3.0f - t2) + kMargin;
+    } else {
+      emd_fold(st, m2, v, home * kWave + lane, n, tpu, perm);   // equal values: the reference's tie order
+    }
+  }
+#ifdef MVP_EMD_PROFILE
+  prof_seed += __builtin_readcyclecounter() - tb0;
+#endif
+  // surviving sub-blocks (the home block's four excluded) compacted into the wave's list
+  int nl = 0;
+#pragma unroll
+  for (int ps = 0; ps < kPasses; ++ps) {
+    const float tq = st.tm - bpl[ps];
+    const int sub = ps * kWave + lane;
+    const bool pass = tq >= 0.f && bd2[ps] <= tq * tq && (sub >> 2) != home;   // (passes beyond npass: inf)
+    const unsigned long long m = __ballot(pass);
+    if (pass) wl[nl + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)sub;
+    nl += __builtin_popcountll(m);
+  }
+#ifdef MVP_EMD_PROFILE
+  prof_subs += nl;
+#endif
+  // visit: a step = four sub-blocks, one per 16-lane row; four steps in flight
+  for (int k0 = 0; k0 < nl; k0 += 16) {
+    // (the list is read past its end -- the row is padded -- and the entry discarded: four independent reads)
+    int ent[4], slot[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ent[r] = wl[k0 + 4 * r + row];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slot[r] = k0 + 4 * r + row < nl ? ent[r] * kResSub + sl : -1;
+    float4 o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = sh.obj[slot[r] < 0 ? sl : slot[r]];
+    float sd[4];
+    unsigned long long m[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sd[r] = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
+      const float tq = st.tm - o[r].w;
+      m[r] = __ballot(slot[r] >= 0 && tq >= 0.f && sd[r] <= tq * tq);
+    }
+#ifdef MVP_EMD_PROFILE
+    prof_folds += __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) + __builtin_popcountll(m[2]) + __builtin_popcountll(m[3]);
+#endif
+    // (exact values only for the steps that hold a candidate: 1-2 of the four, usually)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (m[r]) emd_fold(st, m[r], emd_value(sd[r], o[r].w), slot[r], n, tpu, perm);
+  }
+  return st;
 }
 
 // The remaining rounds of one cloud, on the calling workgroup (1024 threads), from the hand-over record and the
@@ -85,7 +198,6 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
   const EmdScratch sc = emd_carve(scratch + (size_t)cloud * emd_scratch_per_cloud(n), n);
   dist += (size_t)cloud * n;
   int *ass = assignment + (size_t)cloud * n;
-  constexpr int kPasses = NMAX / kResSub / kWave;   // sub-block tests per lane this instantiation can need: 2 / 4
   const int nsub = n / kResSub;          // n % 1024 == 0: a multiple of 64
   const int npass = nsub / kWave;        // ... and this cloud needs: 1, 2, 3 or 4
 
@@ -129,6 +241,8 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
       sh.s_act[(it0 + 1) % 3] = 0;
       sh.s_act[(it0 + 2) % 3] = 0;
       sh.s_err = (resume->err != 0 || total > kResList) ? 1 : 0;   // (the launcher never hands over more)
+      sh.s_solo[0] = 0;
+      sh.s_solo[1] = 0;
     }
   }
   __syncthreads();
@@ -157,6 +271,10 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
   // ------------------------------------------------------------ the auction
   long long n_rounds = 0, n_bids = 0;
   bool last_done = false;   // the forced last round ran: the positions' bids are their assignment
+  // The single-bidder chain exists in the <= 2048-point instantiation only: a larger cloud is hardly ever down to one bidder
+  // (mean 7-10 after the hand-over at 4096 points) and measured 2-3 % slower with the code present (NOTES_r6 §16).
+  constexpr bool kSolo = MVP_RES_SOLO != 0 && NMAX <= 2048;
+  [[maybe_unused]] int solo_it = -1;   // kSolo: the round from which a single bidder is left (uniform over the workgroup)
   unsigned short *wl = sh.w_list[wave];
 #ifdef MVP_EMD_PROFILE
   long long prof_folds = 0, prof_subs = 0, prof_bidcyc = 0, prof_nbid = 0, cyc_bid = 0, cyc_sync1 = 0, cyc_assign = 0, prof_slow = 0,
@@ -191,6 +309,14 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
       npos = U;
     }
 
+    if constexpr (kSolo) {
+      if (U == 1) {   // the number of bidders never grows: the rest of the auction is one chain of evictions (below the loop)
+        solo_it = it;
+        n_rounds -= 1;
+        n_bids -= 1;
+        break;
+      }
+    }
     // ---------------- Bid (emd_cuda.cu:95-179): the wave bids for the persons at its positions, one after the other
 #ifdef MVP_EMD_PROFILE
     const long long tp0 = __builtin_readcyclecounter();
@@ -209,93 +335,7 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
 #ifdef MVP_EMD_PROFILE
       const long long tb0 = __builtin_readcyclecounter();
 #endif
-      const int home = p1 >> 6;   // the 64-slot block (four sub-blocks) that holds the previous best object
-      // every sub-block's box and price bound against the bidder's point (independent of the seed: issued first)
-      float bd2[kPasses], bpl[kPasses];
-      // (straight-line: every pass the instantiation can need is loaded at once -- indices beyond this cloud's
-      // sub-blocks are clamped and their result discarded -- so the loads share one LDS round trip)
-#pragma unroll
-      for (int ps = 0; ps < kPasses; ++ps) {
-        const int sub = min(ps * kWave + lane, nsub - 1);
-        const float4 lo = sh.s_lo[sub], hi = sh.s_hi[sub];
-        const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi.x), 0.f);
-        const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi.y), 0.f);
-        const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi.z), 0.f);
-        bd2[ps] = ps < npass ? sqdist3(dx, dy, dz) : __builtin_inff();
-        bpl[ps] = lo.w;
-      }
-      // The home block evaluated exactly: the lanes that hold its two best values (more on ties) start the
-      // running top two; the second of them is a lower bound of the final second-best value (64 distinct objects).
-      BidState st;
-      st.b1 = -1e9f;
-      st.b2 = -1e9f;
-      st.bk = -1;
-      st.b2k = -1;
-      st.tm = __builtin_inff();
-      {
-        const float4 o = sh.obj[home * kWave + lane];
-        const float v = emd_value(sqdist3(o.x - qx, o.y - qy, o.z - qz), o.w);
-        // largest value, then the largest of the rest (one holder of the maximum set aside)
-        const float t1 = emd_wave_max(v);
-        const unsigned long long m1 = __ballot(v == t1);
-        const int l1 = (int)__builtin_ctzll(m1);
-        const float t2 = emd_wave_max(lane == l1 ? -1e9f : v);
-        const unsigned long long m2 = __ballot(v >= t2);
-        if (__builtin_expect(t1 > t2 && __builtin_popcountll(m2) == 2, 1)) {
-          // two different values, one holder each: the state emd_fold would arrive at
-          st.b1 = t1;
-          st.bk = home * kWave + l1;
-          st.b2 = t2;
-          st.b2k = home * kWave + (int)__builtin_ctzll(m2 & ~m1);
-          st.tm = (3.0f - t2) + kMargin;
-        } else {
-          emd_fold(st, m2, v, home * kWave + lane, n, tpu, sc.perm);   // equal values: the reference's tie order
-        }
-      }
-#ifdef MVP_EMD_PROFILE
-      prof_seed += __builtin_readcyclecounter() - tb0;
-#endif
-      // surviving sub-blocks (the home block's four excluded) compacted into the wave's list
-      int nl = 0;
-#pragma unroll
-      for (int ps = 0; ps < kPasses; ++ps) {
-        const float tq = st.tm - bpl[ps];
-        const int sub = ps * kWave + lane;
-        const bool pass = tq >= 0.f && bd2[ps] <= tq * tq && (sub >> 2) != home;   // (passes beyond npass: inf)
-        const unsigned long long m = __ballot(pass);
-        if (pass) wl[nl + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)sub;
-        nl += __builtin_popcountll(m);
-      }
-#ifdef MVP_EMD_PROFILE
-      prof_subs += nl;
-#endif
-      // visit: a step = four sub-blocks, one per 16-lane row; four steps in flight
-      for (int k0 = 0; k0 < nl; k0 += 16) {
-        // (the list is read past its end -- the row is padded -- and the entry discarded: four independent reads)
-        int ent[4], slot[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ent[r] = wl[k0 + 4 * r + row];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slot[r] = k0 + 4 * r + row < nl ? ent[r] * kResSub + sl : -1;
-        float4 o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = sh.obj[slot[r] < 0 ? sl : slot[r]];
-        float sd[4];
-        unsigned long long m[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sd[r] = sqdist3(o[r].x - qx, o[r].y - qy, o[r].z - qz);
-          const float tq = st.tm - o[r].w;
-          m[r] = __ballot(slot[r] >= 0 && tq >= 0.f && sd[r] <= tq * tq);
-        }
-#ifdef MVP_EMD_PROFILE
-        prof_folds += __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) + __builtin_popcountll(m[2]) + __builtin_popcountll(m[3]);
-#endif
-        // (exact values only for the steps that hold a candidate: 1-2 of the four, usually)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (m[r]) emd_fold(st, m[r], emd_value(sd[r], o[r].w), slot[r], n, tpu, sc.perm);
-      }
+      BidState st = res_search<NMAX>(sh, wl, qx, qy, qz, p1, lane, row, sl, n, nsub, npass, tpu, sc.perm RES_PROF_PASS);
 #ifdef MVP_EMD_PROFILE
       prof_bidcyc += __builtin_readcyclecounter() - tb0;
       prof_nbid += 1;
@@ -393,6 +433,67 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
            wall_clock64() - w_loop0, 100.0 * (double)(__builtin_readcyclecounter() - t_loop0) / (double)(wall_clock64() - w_loop0));
 #endif
 
+  // ------------------------------------------------------------ one bidder left: a chain of evictions on ONE wave
+  // A single bid is never contested and the person it evicts is the next round's only bidder: the wave that holds the
+  // position runs Bid and Assign of every remaining round back to back -- no barrier, no counters, the next bidder's
+  // point and hint straight from the owner it evicted -- and the other fifteen wait at the barrier below.  Same bids,
+  // same increments, same rounds as the two-barrier round above (20-37 % of the rounds of a 1024-point cloud).
+  if constexpr (kSolo) if (solo_it >= 0) {
+    int mypos = -1;
+    for (int pos = wave; pos < npos; pos += kEmdWaves) {
+      if (__builtin_amdgcn_readfirstlane(__float_as_int(sh.r_q[pos].w)) >= 0)
+        mypos = pos;
+      else if (lane == 0)
+        sh.s_bj[pos] = -1;   // (a bid of an earlier round must not be taken for one of the forced last round)
+    }
+    if (mypos >= 0) {
+      const float4 rq = sh.r_q[mypos];
+      int j = __builtin_amdgcn_readfirstlane(__float_as_int(rq.w));
+      float qx = rq.x, qy = rq.y, qz = rq.z;
+      int p1 = __builtin_amdgcn_readfirstlane(sh.r_p1[mypos]);
+      int ran = 0, forced = 0;
+      for (int it = solo_it; it < iters; ++it) {
+        ran += 1;
+        BidState st = res_search<NMAX>(sh, wl, qx, qy, qz, p1, lane, row, sl, n, nsub, npass, -1, sc.perm RES_PROF_PASS);
+        if (__builtin_expect(st.bk < 0 || st.b2k < 0, 0)) {   // cannot happen: a block holds 64 objects
+          if (lane == 0) sh.s_err = 1;
+          st.bk = st.bk < 0 ? 0 : st.bk;
+        }
+        const int bk = st.bk;
+        if (it == iters - 1) {   // the forced last round (emd_cuda.cu:201-212): the bidder takes what it bid on
+          if (lane == 0) {
+            sh.s_bj[mypos] = j;
+            sh.s_bo[mypos] = bk;
+          }
+          forced = 1;
+          break;
+        }
+        // Assign: the bidder wins; the sub-block's price bound follows the one price that moved
+        const int prev = __builtin_amdgcn_readfirstlane((int)sh.owner[bk]);
+        const float pw = sh.obj[(bk & ~(kResSub - 1)) + sl].w;
+        const float np = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw), bk & (kResSub - 1))) + (st.b1 - st.b2 + eps);
+        const float pm = row_min(sl == (bk & (kResSub - 1)) ? np : pw);
+        if (lane == 0) {
+          sh.owner[bk] = (unsigned short)j;
+          sh.h1[j] = (unsigned short)bk;   // the hint of its next bid, should it be evicted again
+          sh.obj[bk].w = np;
+          sh.s_lo[bk / kResSub].w = pm;
+        }
+        if (prev == kResFree) break;   // a free object: everybody is assigned
+        j = prev;
+        qx = sh.px[prev];
+        qy = sh.py[prev];
+        qz = sh.pz[prev];
+        const int np1 = __builtin_amdgcn_readfirstlane((int)sh.h1[prev]);
+        p1 = np1 == kResFree ? 0 : np1;
+      }
+      if (lane == 0) {
+        sh.s_solo[0] = ran;
+        sh.s_solo[1] = forced;
+      }
+    }
+  }
+
   // ------------------------------------------------------------ assignment + CalcDist (emd_cuda.cu:217-226)
   // person -> slot: what the owners say, then the last round's bids (the reference's last round
   // evicts nobody and gives every bidder the object it bid on: several persons may share one)
@@ -403,6 +504,11 @@ __device__ __forceinline__ void emd_resident_body(ResShared<NMAX> &sh, const int
     if (ow != kResFree) pslot[ow] = (unsigned short)s;
   }
   __syncthreads();
+  if constexpr (kSolo) {
+    n_rounds += sh.s_solo[0];
+    n_bids += sh.s_solo[0];
+    last_done = last_done || sh.s_solo[1] != 0;
+  }
   if (last_done && t < npos && sh.s_bj[t] >= 0) pslot[sh.s_bj[t]] = (unsigned short)sh.s_bo[t];
   __syncthreads();
   for (int p = t; p < n; p += kEmdThreads) {

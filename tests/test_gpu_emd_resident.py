@@ -127,6 +127,33 @@ def test_resident_edge_cases(oracle, kind):
     _check(oracle, x1, x2, eps, iters)
 
 
+@pytest.mark.parametrize("when", ["solo_starts_in_the_forced_last_round", "forced_last_round_inside_the_chain", "chain_ends_on_a_free_object",
+                                  "full"])
+def test_resident_single_bidder_chain(oracle, when):
+    """One bidder left (emd_resident.h, MVP_RES_SOLO): the wave that holds it runs the remaining rounds as one chain of
+    evictions without barriers.  The round counts come from the oracle's trace of unassigned persons per round: the
+    auction is cut off in the very round the chain starts (it runs the forced last round, emd_cuda.cu:201-212, at once),
+    a few rounds into it, is left to end on a free object, and runs the full 3000 rounds; rounds and bids are compared too."""
+    x1, x2 = rand_clouds(611, 6, 1024, 3), rand_clouds(612, 6, 1024, 3)
+    trace = oracle.emd_forward_ex(x1, x2, 0.004, 3000)[3]
+    ones = [int(np.argmax(row == 1)) for row in trace if (row == 1).any()]
+    assert len(ones) >= 2, "the seeds no longer give a single-bidder tail: pick others"
+    ended = [c for c in range(len(trace)) if (trace[c] == 1).any() and trace[c][-1] == 0]
+    if when == "solo_starts_in_the_forced_last_round":
+        for r in sorted(set(ones))[:2]:
+            for d in (0, 1, 2):   # (whichever way the trace counts: the chain's first round is one of these)
+                _check(oracle, x1, x2, 0.004, r + d)
+        return
+    if when == "forced_last_round_inside_the_chain":
+        for r in sorted(set(ones))[:3]:
+            _check(oracle, x1, x2, 0.004, r + 7)
+        return
+    if when == "chain_ends_on_a_free_object":
+        assert ended, "no cloud of these seeds converges from a single bidder: pick others"
+    rec = _check(oracle, x1, x2, 0.004, 3000, expect_resident=True)
+    assert (rec["rounds"] <= 3000).all()
+
+
 @pytest.mark.parametrize("n", [1024, 2048])
 def test_resident_cfg4_full_batch_matches_oracle(oracle, n):
     """BASELINE cfg 4 at its FULL batch through the default path: 64 clouds of 1024 / 2048 points, eval
