@@ -65,6 +65,10 @@ struct LeanShared {
   int s_nwon[2];
   int s_pub;                          // bids this member has published this round
   int s_gc[3][kMaxCluster];           // every member's list length: current round / next / (being zeroed)
+  // rounds of at most 16 bidders on member 0 alone (emd_lean_round_few.inc): bids per bucket of object slots by round
+  // parity, bidders of the round by round % 3
+  alignas(16) int f_cnt[2][256];
+  int f_act[3];
 #ifdef MVP_EMD_PROFILE
   int s_wbusy[kEmdWaves];
   unsigned long long s_hist2[4];
@@ -310,6 +314,10 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 #else
 #define GMT(i)
 #endif
+  // the rounds of at most 16 bidders (emd_lean_round_few.inc): 16-slot leaves (n <= 16384 = the owner map's size), this
+  // launch runs to the auction's end
+  // (a resident hand-over below 16 persons -- a test knob -- keeps the plain rounds: they watch for it)
+  const bool few_ok = MVP_EMD_FEW != 0 && n <= kGMaxN && lshift == 4 && it_stop >= iters && (u_stop <= 0 || u_stop >= kEmdWaves);
   int stop_cnt = -1;   // >= 0: the loop ended before round it + 1 with this many entries in this member's next list
   bool stop_for_res = false;   // ... because at most u_stop persons are left (not because round it_stop is next)
 #ifdef MVP_EMD_PROFILE
@@ -415,6 +423,8 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     if constexpr (GM) { GMT(10) }   // [10] counts, stop checks, price bounds
     cur ^= 1;
     if constexpr (GM) gi = gnxt;
+    // member 0 alone with at most a bidder per wave, no launch boundary ahead: the rounds of emd_lean_round_few.inc
+    if (few_ok && !clustered && Utot > 0 && Utot <= (kSoloMax < kEmdWaves ? kSoloMax : kEmdWaves) && it + 1 < iters) sw = 4;
     if (sw) {
       ++it;
       return sw;
@@ -422,13 +432,19 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
   }
   return 0;
   };
+  auto few = [&](const bool owners_in_lds) {
+#include "emd_lean_round_few.inc"
+  };
   for (;;) {
     int code;
     if constexpr (WB != 1) code = gm_now ? rounds(std::true_type{}) : rounds(std::false_type{});
     else code = rounds(std::false_type{});
     if (code == 2) gm_now = true;
     else if (code == 3) gm_now = false;
-    else break;
+    else {
+      if (code == 4) few(gm_now);   // (gm_now: the loop that ran last kept the owner map in LDS)
+      break;
+    }
   }
   if (ret_early) return 0;
 #ifdef MVP_EMD_PROFILE
