@@ -29,8 +29,13 @@ constexpr int kChgCap = 2048;    // refreshed price bounds a workgroup can broad
 // four-bidders-per-wave schedule were tried in round 2: 5 % / 23 % / 57 % slower at the headline shape)
 constexpr int kSoloMax = MVP_EMD_SOLO;
 #ifndef MVP_EMD_FEW
-#define MVP_EMD_FEW 1   // a collapsed cluster's rounds with at most a bidder per wave: emd_lean_round_few.inc (0: the plain rounds, A/B builds)
+#define MVP_EMD_FEW 1   // a collapsed cluster's rounds with few bidders per wave: emd_lean_round_few.inc (0: the plain rounds, A/B builds)
 #endif
+#ifndef MVP_EMD_FEWPOS
+#define MVP_EMD_FEWPOS 1   // ... list positions per wave there: the lean kernels' cluster collapses to member 0 at 16 x this many persons
+#endif
+constexpr int kFewPos = MVP_EMD_FEWPOS;
+constexpr int kFewMax = kFewPos * kEmdWaves;
 constexpr unsigned kSpinLimit = 1u << 24;  // bound of every cluster wait (tens of seconds), then abort
 // The lean kernel (emd_lean.hip) takes a cloud over once no workgroup has more than kRowModeMin
 // bidders, at most kLeanCap persons are unassigned (their number never grows, so every later
