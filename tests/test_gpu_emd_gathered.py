@@ -137,3 +137,49 @@ def test_cfg4_n8192_full_batch_default_path_matches_oracle(oracle, knobs):
     np.testing.assert_array_equal(a5, a0)
     np.testing.assert_array_equal(d5, d0)
     np.testing.assert_array_equal(r5["bids"], r0["bids"])
+
+
+# ---------------------------------------------------------------- the rounds of at most 16 bidders (emd_lean_round_few.inc)
+def _near_pair(seed, b, n, noise):
+    """A prediction near its ground truth (what a trained completion network hands to the metric): most persons find
+    their object in the first rounds, the auction is down to a few bidders for most of its 3000 rounds."""
+    gt = rand_clouds(seed, b, n, 3)
+    pred = (gt + np.float32(noise) * (rand_clouds(seed + 1, b, n, 3) - np.float32(0.5))).astype(np.float32)
+    return pred, gt
+
+
+@pytest.mark.parametrize("split", [5, 2])
+@pytest.mark.parametrize("b,n,noise", [(2, 8192, 0.08), (2, 16384, 0.05), (3, 6144, 0.1)])
+def test_few_bidder_rounds_match_oracle(oracle, knobs, b, n, noise, split):
+    """Clouds above the LDS-resident tail's 4096 points that get down to <= 16 unassigned persons: member 0 of the
+    cluster finishes the auction with the few-bidders rounds, entered from the gathered-bid rounds (split 5: the owner map
+    is already in LDS) and from the plain rounds (split 2: it is read from the objects' records).  Bits, rounds, bids."""
+    knobs(split=split)
+    x1, x2 = _near_pair(700 + n // 1024, b, n, noise)
+    trace = oracle.emd_forward_ex(x1, x2, 0.004, 3000)[3]
+    assert ((trace <= 16) & (trace > 0)).sum(1).min() > 200, "these seeds no longer give a long few-bidders tail"
+    _check(oracle, x1, x2, 0.004, 3000)
+
+
+@pytest.mark.parametrize("extra", [1, 2, 3, 9, 40])
+def test_few_bidder_rounds_cut_off(oracle, extra):
+    """The auction is cut off 1 / 2 / 3 / 9 / 40 rounds after the first cloud is down to 16 persons (round ~270: before the
+    launch boundary at round 300, the last one behind it): the few-bidders rounds are not entered at all, run the forced
+    last round (emd_cuda.cu:201-212) as their first, or a few rounds before it."""
+    x1, x2 = _near_pair(720, 2, 8192, 0.08)
+    trace = oracle.emd_forward_ex(x1, x2, 0.004, 3000)[3]
+    r16 = min(int(np.argmax(row <= 16)) for row in trace)
+    assert 0 < r16 < 2900
+    _check(oracle, x1, x2, 0.004, r16 + extra)
+
+
+def test_few_bidder_rounds_with_equal_values_and_contests(oracle):
+    """Duplicated points: equal values (the reference's tie order on original indices), several bidders for one object
+    with increments inside GetMax's 1e-6 band (emd_cuda.cu:188), bucket collisions of the bid counters -- all inside the
+    few-bidders rounds (8192 points: no resident tail)."""
+    for seed, m, k in ((733, 2048, 4), (735, 4096, 2)):
+        pred, gt = _near_pair(seed, 2, m, 0.1)
+        x1, x2 = np.tile(pred, (1, k, 1)), np.tile(gt, (1, k, 1))
+        trace = oracle.emd_forward_ex(x1, x2, 0.004, 2000)[3]
+        assert ((trace <= 16) & (trace > 0)).sum(1).min() > 500
+        _check(oracle, x1, x2, 0.004, 2000)
