@@ -314,11 +314,12 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
 #else
 #define GMT(i)
 #endif
-  // the rounds of at most 16 bidders (emd_lean_round_few.inc): 16-slot leaves (n <= 16384 = the owner map's size), this
-  // launch runs to the auction's end
-  // (a resident hand-over below 16 persons -- a test knob -- keeps the plain rounds: they watch for it)
-  const bool few_ok = MVP_EMD_FEW != 0 && n <= kGMaxN && lshift == 4 && it_stop >= iters && (u_stop <= 0 || u_stop >= kFewMax);
-  const int solo_max = few_ok && kFewMax > kSoloMax ? kFewMax : kSoloMax;   // persons at which the cluster collapses to member 0
+  // The rounds of at most 16 bidders (emd_lean_round_few.inc) take a collapsed cluster's cloud when the leaves hold 16 slots
+  // (n <= 16384 = the owner map's size) and this launch runs to the auction's end; a resident hand-over below 16 persons
+  // -- a test knob -- keeps the plain rounds (they watch for it).  (A lambda, evaluated where it is needed: two more
+  // scalars alive through the round loops cost the gathered-bid rounds 900 more SGPR spill moves.)
+  auto few_ok = [&]() { return MVP_EMD_FEW != 0 && n <= kGMaxN && lshift == 4 && it_stop >= iters && (u_stop <= 0 || u_stop >= kFewMax); };
+  constexpr int kLeanSoloMax = kFewMax > kSoloMax ? kFewMax : kSoloMax;   // persons at which the cluster collapses to member 0
   int stop_cnt = -1;   // >= 0: the loop ended before round it + 1 with this many entries in this member's next list
   bool stop_for_res = false;   // ... because at most u_stop persons are left (not because round it_stop is next)
 #ifdef MVP_EMD_PROFILE
@@ -425,7 +426,7 @@ __device__ __forceinline__ int emd_lean_body(LeanShared &sh, const int cloud, co
     cur ^= 1;
     if constexpr (GM) gi = gnxt;
     // member 0 alone with at most a bidder per wave, no launch boundary ahead: the rounds of emd_lean_round_few.inc
-    if (few_ok && !clustered && Utot > 0 && Utot <= kFewMax && it + 1 < iters) sw = 4;
+    if (__builtin_expect(!clustered && Utot > 0 && Utot <= kFewMax && it + 1 < iters, 0) && few_ok()) sw = 4;
     if (sw) {
       ++it;
       return sw;
