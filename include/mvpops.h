@@ -132,7 +132,12 @@ long long mvp_emd_scratch_bytes(int b, int n);
  * are unassigned: a bid is published as a tagged 16-byte record, every workgroup
  * of the cluster settles every bid on its own view of the cloud (owner map in
  * LDS) and a round has one cluster-wide wait instead of a bid atomic and two
- * all-gathers (csrc/emd_lean.hip).  Which workgroups serve a cloud, in which
+ * all-gathers (csrc/emd_lean.hip).  Once at most 16 persons of a cloud of more than
+ * 4096 (and at most 16384) points are unassigned -- most of the 3000 rounds when the
+ * prediction is near its ground truth -- member 0 of the cluster finishes the
+ * auction alone: a wave per bidder with its record in registers, the round's bids and
+ * the owner map in LDS, one barrier between Bid and Assign
+ * (csrc/emd_lean_round_few.inc).  Which workgroups serve a cloud, in which
  * launch and in which kind of round, never changes a bit of the result.
  * If a cluster wait is abandoned (members not co-resident for tens of seconds;
  * never seen) dist is filled with NaN, assignment with -1 and the statistics

@@ -3,7 +3,7 @@ distributions every `split` (0: the first kernel alone; 2: + lean kernel + width
 3: + LDS-resident tail for clouds of <= 4096 points in a launch of its own; 4: fused into the lean launch;
 5, the default: + gathered-bid rounds once at most 256 persons of a cloud are unassigned) must give the same bits and the same statistics.
 
-  python tools/fuzz_emd_tiers.py [cases] [seed]          (log of the round's campaign: profiles/r4_fuzz_emd.txt)
+  python tools/fuzz_emd_tiers.py [cases] [seed] [few]    (few: the cases of draw_case_few; log of the round's campaign: profiles/r4_fuzz_emd.txt)
 
 tests/test_gpu_emd_fuzz.py runs a fixed-seed slice of the same cases under pytest -m gpu."""
 import os
@@ -36,6 +36,21 @@ def draw_case(rng):
     return b, n, iters, eps, str(rng.choice(KINDS)), int(rng.integers(1 << 30)), cluster
 
 
+def draw_case_few(rng):
+    """Round 6: cases for the rounds of at most 16 bidders (emd_lean_round_few.inc) -- clouds above the resident tail's
+    4096 points whose auction thins out: a prediction near its ground truth (noise 0.02 .. 0.1 of the unit cube), small and
+    full batches, every cluster width, short and long auctions.  split 0 (the first kernel alone) never runs those rounds:
+    it is the reference the others are compared with."""
+    b = int(rng.choice([1, 2, 3, 5, 8, 33, 48, 64]))
+    n = int(rng.choice([5120, 6144, 8192, 8192, 12288, 16384]))
+    if b > 8 and n > 8192:
+        b = int(rng.choice([4, 6]))   # (keeps the campaign's run time down)
+    cluster = int(rng.choice([0, 0, 0, 1, 2, 4, 8])) if b <= 8 else 0
+    iters = int(rng.choice([400, 700, 1200, 3000]))
+    eps = float(rng.choice([0.004, 0.002, 0.008]))
+    return b, n, iters, eps, str(rng.choice(["near", "near2", "near5", "neardup"])), int(rng.integers(1 << 30)), cluster
+
+
 def make_inputs(b, n, kind, seed):
     g = torch.Generator().manual_seed(seed)
     x2 = torch.rand(b, n, 3, generator=g)
@@ -47,8 +62,11 @@ def make_inputs(b, n, kind, seed):
     elif kind == "shells":
         s = torch.randn(b, n, 3, generator=g)
         x1 = 0.5 + 0.45 * s / s.norm(dim=2, keepdim=True)
-    elif kind == "near":
-        x1 = (x2 + 0.02 * torch.randn(b, n, 3, generator=g)).clamp(0, 1)
+    elif kind in ("near", "near2", "near5"):
+        x1 = (x2 + {"near": 0.02, "near2": 0.05, "near5": 0.1}[kind] * torch.randn(b, n, 3, generator=g)).clamp(0, 1)
+    elif kind == "neardup":   # duplicated points, near pairs: ties and contests while few persons bid
+        x2 = torch.rand(b, n // 4, 3, generator=g).repeat(1, 4, 1)
+        x1 = (x2 + 0.08 * (torch.rand(b, n // 4, 3, generator=g) - 0.5).repeat(1, 4, 1)).clamp(0, 1)
     elif kind == "dups":
         x1 = torch.rand(b, n // 4, 3, generator=g).repeat(1, 4, 1)
         x2 = torch.rand(b, n // 2, 3, generator=g).repeat(1, 2, 1)
@@ -100,7 +118,7 @@ def main():
     rng = np.random.default_rng(seed)
     bad = 0
     for c in range(cases):
-        case = draw_case(rng)
+        case = draw_case_few(rng) if len(sys.argv) > 3 and sys.argv[3] == "few" else draw_case(rng)
         ok, what = run_case(case)
         print("case %2d: b %3d n %5d iters %4d eps %.3f %-7s cluster %d -> %s | %s" % (
             (c,) + case[:5] + (case[6], "identical" if ok else "MISMATCH", what)), flush=True)
