@@ -702,8 +702,10 @@ def run_pcn_eval(args, rank, world, dev):
     test.py run them per batch.  Weights are random (no checkpoint exists here): a random-init PCN emits one tight
     blob, and an auction between a blob and a spread cloud is a degenerate input that says nothing about the
     eval loop of a trained network (orders of magnitude more bids; measured once below, outside the timed
-    region).  The timed EMD therefore matches an independent spread cloud of the batch's shape against gt --
-    the network's forward pass and the CD / F1 of its real output are timed as they are."""
+    region).  The timed EMD therefore runs on what a TRAINED network's prediction looks like next to its target:
+    ground truth + noise 0.03 on a chair-like surface (mvp_benchmark_amd/synthetic.py; VERDICT r5: the figure with a
+    uniform stand-in flattered the step then -- it is kept beside it in `extra`); the network's forward pass and the
+    CD / F1 of its real output are timed as they are."""
     sys.path.insert(0, os.path.join(ROOT, "completion"))
     import importlib
     import model_utils as mu
@@ -718,15 +720,15 @@ def run_pcn_eval(args, rank, world, dev):
     partial = torch.rand(B, 3, 2048, generator=g).to(dev)
     gt = torch.rand(B, n, 3, generator=g).to(dev)
     pred_like = torch.rand(B, n, 3, generator=g).to(dev)
-    # what a TRAINED network's prediction looks like next to its target: gt + noise 0.03 on a chair-like surface (timed
-    # beside the uniform stand-in, not instead of it: see parts_ms)
+    # what a TRAINED network's prediction looks like next to its target: gt + noise 0.03 on a chair-like surface (the
+    # timed EMD; the independent uniform stand-in of rounds 3-5 is timed beside it: extra)
     from mvp_benchmark_amd.synthetic import prediction_pair
     surf_pred, surf_gt = [t.to(dev) for t in prediction_pair("chair", "0.03", g, B, n)]
 
     def step():
         with torch.no_grad():
             r = net(partial, gt, prefix="val")
-            e = mu.calc_emd(pred_like, gt, eps=args.eps, iterations=args.iters)
+            e = mu.calc_emd(surf_pred, surf_gt, eps=args.eps, iterations=args.iters)
         return r, e
 
     def barrier():
@@ -772,7 +774,7 @@ def run_pcn_eval(args, rank, world, dev):
     ms = elapsed / args.steps * 1e3
     return {
         "metric": "PCN completion eval clouds/sec (cfgs/pcn_eval16k.yaml: 2048 -> 16384 pts, forward + CD + F1 on the network's "
-                  "output + EMD on a STAND-IN prediction (uniform cloud), batch 32 per GPU)",
+                  "output + EMD on a stand-in prediction (chair-like surface, ground truth + noise 0.03), batch 32 per GPU)",
         "value": B * world / (ms * 1e-3),
         "unit": "clouds/s",
         "n_gpus": world,
@@ -784,14 +786,14 @@ def run_pcn_eval(args, rank, world, dev):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (random-init PCN weights, uniform clouds; EMD on an independent uniform stand-in for the prediction)",
+        "data": "synthetic (random-init PCN weights, uniform clouds; EMD on a surface-shaped pair: prediction = ground truth + noise 0.03)",
         "config": {"workload": "PCN eval step: forward (2048 -> %d pts) + calc_cd(f1) on its output + calc_emd eps=%g iters=%d, "
                                "%d clouds per GPU" % (n, args.eps, args.iters, B),
                    "batch_per_gpu": B, "points": n, "parallelism": "batch-sharded x%d" % world},
-        "parts_ms": {"pcn_forward": fwd_ms, "calc_cd_f1_on_network_output": cd_ms, "calc_emd_spread_prediction": emd_ms,
-                     "sum": fwd_ms + cd_ms + emd_ms},
-        "extra": {"calc_emd_chair_gt_plus_noise_0.03_ms": surf_ms,
-                  "clouds_per_s_with_emd_on_chair_gt_plus_noise_0.03": B * world / ((fwd_ms + cd_ms + surf_ms) * 1e-3),
+        "parts_ms": {"pcn_forward": fwd_ms, "calc_cd_f1_on_network_output": cd_ms, "calc_emd_chair_gt_plus_noise_0.03": surf_ms,
+                     "sum": fwd_ms + cd_ms + surf_ms},
+        "extra": {"calc_emd_independent_uniform_stand_in_ms": emd_ms,
+                  "clouds_per_s_with_emd_on_independent_uniform_stand_in": B * world / ((fwd_ms + cd_ms + emd_ms) * 1e-3),
                   "calc_emd_on_random_init_output_ms": blob_ms,
                   "note": "random-init PCN output is one tight blob: the auction against a spread cloud is the degenerate case "
                           "(every person bids every round); shown for completeness, not part of the timed step",
