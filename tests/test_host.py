@@ -245,3 +245,25 @@ def test_pointwise_routing_rules():
     # (tools/bench_conv_passes.py); only (64, 512 -> 192, 384) forward loses 0.015 ms
     assert fits(64, 128, 512, 384) and fits(64, 32, 512, 384) and not fits(64, 128, 516, 384)
     assert fits(64, 512, 128, 384)                                         # the same layers' data gradients
+
+
+def test_bench_settle_and_model_level_note():
+    """bench.py's untimed pre-warm-up of the model-level steps stops once three consecutive steps agree (and gives up at its
+    bound); the note that travels in the bench line formats (a '%' in it once cost the line its model-level figures)."""
+    import importlib
+    import time
+    import types
+    bench = importlib.import_module("bench")
+    durations = iter([0.05, 0.04, 0.03, 0.03, 0.003, 0.003, 0.003, 0.003, 0.003, 0.003])
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(next(durations, 0.003))
+
+    n = bench.settle(step, max_steps=10)
+    assert 7 <= n <= 10 and len(calls) == n
+    jitter = iter([0.002, 0.02] * 10)
+    assert bench.settle(lambda: time.sleep(next(jitter)), max_steps=8) == 8
+    note = bench.model_level_note(types.SimpleNamespace(points=16384, eps=0.004, iters=3000))
+    assert "5 %" in note and "16384" in note and "0.004 x 3000" in note
