@@ -148,6 +148,27 @@ def _near_pair(seed, b, n, noise):
     return pred, gt
 
 
+_ORACLE_RUNS = {}
+
+
+def _oracle_run(oracle, key, x1, x2, eps, iters):
+    """The oracle's full result (dist, assignment, stats, bidders per round) of one input, computed once per module
+    (emd_forward_ex with the pinned GetMax policy IS emd_forward plus the trace: ~9 s for two clouds of 16384 points)."""
+    if key not in _ORACLE_RUNS:
+        _ORACLE_RUNS[key] = oracle.emd_forward_ex(x1, x2, eps, iters)
+    return _ORACLE_RUNS[key]
+
+
+def _check_against(run, x1, x2, eps, iters):
+    d, a, rec = _run(x1, x2, eps, iters)
+    od, oa, ost, _ = run
+    np.testing.assert_array_equal(a, oa)
+    np.testing.assert_array_equal(d, od)
+    np.testing.assert_array_equal(rec["rounds"], ost[:, 0])
+    np.testing.assert_array_equal(rec["bids"], ost[:, 1])
+    assert (rec["next_round"] == 0).all()
+
+
 @pytest.mark.parametrize("split", [5, 2])
 @pytest.mark.parametrize("b,n,noise", [(2, 8192, 0.08), (2, 16384, 0.05), (3, 6144, 0.1)])
 def test_few_bidder_rounds_match_oracle(oracle, knobs, b, n, noise, split):
@@ -156,9 +177,10 @@ def test_few_bidder_rounds_match_oracle(oracle, knobs, b, n, noise, split):
     is already in LDS) and from the plain rounds (split 2: it is read from the objects' records).  Bits, rounds, bids."""
     knobs(split=split)
     x1, x2 = _near_pair(700 + n // 1024, b, n, noise)
-    trace = oracle.emd_forward_ex(x1, x2, 0.004, 3000)[3]
+    run = _oracle_run(oracle, ("few", b, n, noise), x1, x2, 0.004, 3000)
+    trace = run[3]
     assert ((trace <= 16) & (trace > 0)).sum(1).min() > 200, "these seeds no longer give a long few-bidders tail"
-    _check(oracle, x1, x2, 0.004, 3000)
+    _check_against(run, x1, x2, 0.004, 3000)
 
 
 @pytest.mark.parametrize("extra", [1, 2, 3, 9, 40])
@@ -167,7 +189,7 @@ def test_few_bidder_rounds_cut_off(oracle, extra):
     launch boundary at round 300, the last one behind it): the few-bidders rounds are not entered at all, run the forced
     last round (emd_cuda.cu:201-212) as their first, or a few rounds before it."""
     x1, x2 = _near_pair(720, 2, 8192, 0.08)
-    trace = oracle.emd_forward_ex(x1, x2, 0.004, 3000)[3]
+    trace = _oracle_run(oracle, ("cut", 720), x1, x2, 0.004, 3000)[3]
     r16 = min(int(np.argmax(row <= 16)) for row in trace)
     assert 0 < r16 < 2900
     _check(oracle, x1, x2, 0.004, r16 + extra)
@@ -180,6 +202,6 @@ def test_few_bidder_rounds_with_equal_values_and_contests(oracle):
     for seed, m, k in ((733, 2048, 4), (735, 4096, 2)):
         pred, gt = _near_pair(seed, 2, m, 0.1)
         x1, x2 = np.tile(pred, (1, k, 1)), np.tile(gt, (1, k, 1))
-        trace = oracle.emd_forward_ex(x1, x2, 0.004, 2000)[3]
-        assert ((trace <= 16) & (trace > 0)).sum(1).min() > 500
-        _check(oracle, x1, x2, 0.004, 2000)
+        run = _oracle_run(oracle, ("dups", seed), x1, x2, 0.004, 2000)
+        assert ((run[3] <= 16) & (run[3] > 0)).sum(1).min() > 500
+        _check_against(run, x1, x2, 0.004, 2000)
